@@ -1,0 +1,319 @@
+"""ctypes front-end of the CPU ORACLE (oracle/libvisp_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg. The product (vision.cpp_amd) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+_LIB = _DIR / "libvisp_oracle.so"
+
+F32, F16, I32 = 0, 1, 26
+RGBA_U8, BGRA_U8, ARGB_U8, RGB_U8, ALPHA_U8, RGBA_F32, RGB_F32, ALPHA_F32 = range(8)
+LAYOUT_UNKNOWN, LAYOUT_WHCN, LAYOUT_CWHN = 0, 1, 2
+GELU_GGML_F16_LUT, GELU_TANH_F32, GELU_ERF_F32 = 0, 1, 2
+
+_NP_TYPE = {np.dtype(np.float32): F32, np.dtype(np.float16): F16, np.dtype(np.int32): I32}
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("type", C.c_int32), ("ne", C.c_int64 * 4)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("patch_size", C.c_int), ("embed_dim", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int),
+        ("image_size", C.c_int), ("image_multiple", C.c_int), ("feature_layers", C.c_int * 4),
+        ("max_depth", C.c_float), ("gelu_mode", C.c_int),
+    ]
+
+
+class Capture(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dst", C.POINTER(C.c_float)), ("capacity", C.c_int64), ("written", C.c_int64)]
+
+
+def build(force: bool = False) -> Path:
+    src = [_DIR / "visp_oracle.c", _DIR / "visp_oracle.h"]
+    if force or not _LIB.exists() or any(s.stat().st_mtime > _LIB.stat().st_mtime for s in src):
+        subprocess.run(["make", "-B", "-C", str(_DIR)], check=True, capture_output=True)
+    return _LIB
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB.exists():
+            build()
+        L = C.CDLL(str(_LIB))
+        fp, u8p, u16p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
+        L.vo_last_error.restype = C.c_char_p
+        L.vo_model_create.restype = C.c_void_p
+        L.vo_model_create.argtypes = [C.POINTER(Tensor), C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int]
+        L.vo_model_destroy.argtypes = [C.c_void_p]
+        L.vo_model_tensor.restype = fp
+        L.vo_model_tensor.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+        L.vo_depthany_predict.argtypes = [C.c_void_p, C.POINTER(Params), fp, C.c_int, C.c_int, fp, C.POINTER(Capture), C.c_int]
+        L.vo_depthany_compute.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_int, C.c_int, fp, fp]
+        L.vo_dino_layer.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, fp, C.c_int64, C.c_int64]
+        L.vo_f16_to_f32.argtypes = [u16p, fp, C.c_int64]
+        L.vo_f32_to_f16.argtypes = [fp, u16p, C.c_int64]
+        L.vo_image_u8_to_f32.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int]
+        L.vo_image_f32_to_u8.argtypes = [fp, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_float, C.c_float]
+        L.vo_image_normalize.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.vo_depthany_image_extent.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vo_transfer_tensor.argtypes = [C.POINTER(Tensor), C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
+        L.vo_linear.argtypes = [fp, C.c_int64, C.c_int64, fp, fp, C.c_int64, fp]
+        L.vo_layer_norm.argtypes = [fp, C.c_int64, C.c_int64, fp, fp, C.c_float, fp]
+        L.vo_gelu.argtypes = [fp, fp, C.c_int64, C.c_int]
+        L.vo_attention.argtypes = [fp, fp, fp, C.c_int64, C.c_int, C.c_int, C.c_float, fp]
+        L.vo_conv2d_nhwc.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.vo_conv_transpose2d_nhwc.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.vo_interpolate_bilinear_nhwc.argtypes = [fp] + [C.c_int] * 7 + [fp]
+        L.vo_interpolate_bicubic_nhwc.argtypes = [fp] + [C.c_int] * 7 + [fp]
+        L.vo_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _fp(a: np.ndarray | None):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _check(ok: int):
+    if not ok:
+        raise RuntimeError(lib().vo_last_error().decode())
+
+
+def num_threads() -> int:
+    return lib().vo_num_threads()
+
+
+def set_num_threads(n: int):
+    lib().vo_set_num_threads(n)
+
+
+# ---- scalar / image ---------------------------------------------------------------------
+
+def f16_to_f32(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a).view(np.uint16)
+    out = np.empty(a.shape, np.float32)
+    lib().vo_f16_to_f32(a.ctypes.data_as(C.POINTER(C.c_uint16)), _fp(out), a.size)
+    return out
+
+
+def f32_to_f16(a: np.ndarray) -> np.ndarray:
+    a = _f32(a)
+    out = np.empty(a.shape, np.uint16)
+    lib().vo_f32_to_f16(_fp(a), out.ctypes.data_as(C.POINTER(C.c_uint16)), a.size)
+    return out.view(np.float16)
+
+
+_CH = {RGBA_U8: 4, BGRA_U8: 4, ARGB_U8: 4, RGB_U8: 3, ALPHA_U8: 1, RGBA_F32: 4, RGB_F32: 3, ALPHA_F32: 1}
+
+
+def image_u8_to_f32(src: np.ndarray, sformat: int, dformat: int, offset=(0, 0, 0, 0), scale=(1, 1, 1, 1),
+                    dst_extent=None, tile_offset=(0, 0)) -> np.ndarray:
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape[:2]
+    dw, dh = dst_extent if dst_extent else (w, h)
+    out = np.empty((dh, dw, _CH[dformat]), np.float32)
+    off, sc = _f32(offset), _f32(scale)
+    _check(lib().vo_image_u8_to_f32(src.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, w * _CH[sformat], sformat,
+                                    _fp(out), dw, dh, dformat, _fp(off), _fp(sc), tile_offset[0], tile_offset[1]))
+    return out
+
+
+def image_f32_to_u8(src: np.ndarray, sformat: int, dformat: int, scale=1.0, offset=0.0) -> np.ndarray:
+    src = _f32(src)
+    h, w = src.shape[:2]
+    out = np.empty((h, w, _CH[dformat]), np.uint8)
+    _check(lib().vo_image_f32_to_u8(_fp(src), w, h, sformat, out.ctypes.data_as(C.POINTER(C.c_uint8)), dformat, scale, offset))
+    return out
+
+
+def image_normalize(src: np.ndarray, mn=0.0, mx=1.0) -> np.ndarray:
+    src = _f32(src)
+    h, w = src.shape[:2]
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    out = np.empty_like(src)
+    lib().vo_image_normalize(_fp(src), _fp(out), w, h, ch, mn, mx)
+    return out
+
+
+def depthany_image_extent(w: int, h: int, image_size=518, image_multiple=14):
+    ow, oh = C.c_int(), C.c_int()
+    lib().vo_depthany_image_extent(w, h, image_size, image_multiple, C.byref(ow), C.byref(oh))
+    return ow.value, oh.value
+
+
+# ---- tensors ------------------------------------------------------------------------------
+
+def _mk_tensor(name: str, arr: np.ndarray, keep: list) -> Tensor:
+    """numpy array in torch order (slowest axis first) -> vo_tensor in ggml order."""
+    a = np.ascontiguousarray(arr)
+    if a.dtype not in _NP_TYPE:
+        raise TypeError(f"unsupported dtype {a.dtype} for {name}")
+    shape = list(a.shape)[::-1]
+    assert len(shape) <= 4
+    shape += [1] * (4 - len(shape))
+    nm = name.encode()
+    keep += [a, nm]
+    return Tensor(nm, a.ctypes.data, _NP_TYPE[a.dtype], (C.c_int64 * 4)(*shape))
+
+
+def transfer_tensor(arr: np.ndarray, whcn_to_cwhn: bool) -> np.ndarray:
+    keep: list = []
+    t = _mk_tensor("t", arr, keep)
+    out = np.empty(arr.size, np.int32 if arr.dtype == np.int32 else np.float32)
+    ne = (C.c_int64 * 4)()
+    _check(lib().vo_transfer_tensor(C.byref(t), int(whcn_to_cwhn), out.ctypes.data, ne))
+    return out.reshape(tuple(ne)[::-1])
+
+
+# ---- primitives (torch-order numpy in / out) ------------------------------------------------
+
+def linear(x, w, b=None):
+    x, w = _f32(x), _f32(w)
+    b = None if b is None else _f32(b)
+    M, K, N = int(np.prod(x.shape[:-1])), x.shape[-1], w.shape[0]
+    y = np.empty(x.shape[:-1] + (N,), np.float32)
+    lib().vo_linear(_fp(x), M, K, _fp(w), _fp(b), N, _fp(y))
+    return y
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    x, w, b = _f32(x), _f32(w), _f32(b)
+    y = np.empty_like(x)
+    lib().vo_layer_norm(_fp(x), int(np.prod(x.shape[:-1])), x.shape[-1], _fp(w), _fp(b), eps, _fp(y))
+    return y
+
+
+def gelu(x, mode=GELU_GGML_F16_LUT):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().vo_gelu(_fp(x), _fp(y), x.size, mode)
+    return y
+
+
+def attention(q, k, v, n_heads, scale):
+    """q,k,v: [N, C]; returns [N, C]."""
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    N, Cc = q.shape
+    o = np.empty_like(q)
+    lib().vo_attention(_fp(q), _fp(k), _fp(v), N, n_heads, Cc // n_heads, scale, _fp(o))
+    return o
+
+
+def conv2d_nhwc(x, w, b=None, stride=1, pad=0):
+    """x [B,H,W,Cin], w [Cout,kh,kw,Cin]"""
+    x, w = _f32(x), _f32(w)
+    b = None if b is None else _f32(b)
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, _ = w.shape
+    OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = np.empty((B, OH, OW, Cout), np.float32)
+    lib().vo_conv2d_nhwc(_fp(x), B, H, W, Cin, _fp(w), _fp(b), Cout, kh, kw, stride, pad, _fp(y))
+    return y
+
+
+def conv_transpose2d_nhwc(x, w, b=None, stride=1):
+    """x [B,H,W,Cin], w torch layout [Cin,Cout,kh,kw]"""
+    x, w = _f32(x), _f32(w)
+    b = None if b is None else _f32(b)
+    B, H, W, Cin = x.shape
+    _, Cout, kh, kw = w.shape
+    y = np.empty((B, (H - 1) * stride + kh, (W - 1) * stride + kw, Cout), np.float32)
+    lib().vo_conv_transpose2d_nhwc(_fp(x), B, H, W, Cin, _fp(w), _fp(b), Cout, kh, kw, stride, _fp(y))
+    return y
+
+
+def interpolate_nhwc(x, size, mode="bilinear", align_corners=False):
+    x = _f32(x)
+    B, H, W, Cc = x.shape
+    OH, OW = size
+    y = np.empty((B, OH, OW, Cc), np.float32)
+    fn = lib().vo_interpolate_bilinear_nhwc if mode == "bilinear" else lib().vo_interpolate_bicubic_nhwc
+    fn(_fp(x), B, H, W, Cc, OH, OW, int(align_corners), _fp(y))
+    return y
+
+
+# ---- model ------------------------------------------------------------------------------------
+
+class Model:
+    """Oracle-side model: tensors as they sit in the GGUF (numpy, torch axis order)."""
+
+    def __init__(self, tensors: dict[str, np.ndarray], conv2d_weights: list[int], layout: str = "whcn"):
+        self._keep: list = []
+        arr = (Tensor * len(tensors))(*[_mk_tensor(k, v, self._keep) for k, v in tensors.items()])
+        idx = (C.c_int32 * max(1, len(conv2d_weights)))(*conv2d_weights)
+        lay = {"whcn": LAYOUT_WHCN, "cwhn": LAYOUT_CWHN}.get(layout, LAYOUT_UNKNOWN)
+        self._h = lib().vo_model_create(arr, len(tensors), idx, len(conv2d_weights), lay)
+        if not self._h:
+            raise RuntimeError(lib().vo_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vo_model_destroy(self._h)
+            self._h = None
+
+    def tensor(self, name: str) -> np.ndarray:
+        ne = (C.c_int64 * 4)()
+        p = lib().vo_model_tensor(self._h, name.encode(), ne)
+        if not p:
+            raise KeyError(name)
+        shape = tuple(ne)[::-1]
+        return np.ctypeslib.as_array(p, shape=(int(np.prod(shape)),)).reshape(shape).copy()
+
+    def predict(self, params: Params, image_f32: np.ndarray, captures: dict[str, int] | None = None):
+        """image_f32: [h, w, 3] normalised. Returns raw depth [h, w] (+ dict of captures)."""
+        img = _f32(image_f32)
+        h, w = img.shape[:2]
+        out = np.empty((h, w), np.float32)
+        caps = captures or {}
+        bufs = {k: np.empty(n, np.float32) for k, n in caps.items()}
+        names = [k.encode() for k in caps]
+        carr = (Capture * max(1, len(caps)))(*[Capture(nm, _fp(bufs[k]), bufs[k].size, 0) for nm, k in zip(names, caps)])
+        _check(lib().vo_depthany_predict(self._h, C.byref(params), _fp(img), w, h, _fp(out), carr, len(caps)))
+        if captures is None:
+            return out
+        res = {}
+        for i, k in enumerate(caps):
+            if carr[i].written > bufs[k].size:
+                raise RuntimeError(f"capture {k}: needs {carr[i].written} floats")
+            res[k] = bufs[k][: carr[i].written].copy()
+        return out, res
+
+    def compute(self, params: Params, rgb_u8: np.ndarray):
+        """rgb_u8: [h, w, 3]. Returns (normalised [h,w], raw [h,w])."""
+        img = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+        h, w = img.shape[:2]
+        out, raw = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+        _check(lib().vo_depthany_compute(self._h, C.byref(params), img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, _fp(out), _fp(raw)))
+        return out, raw
+
+    def dino_layer(self, prefix: str, x: np.ndarray, n_heads: int, gelu_mode=GELU_GGML_F16_LUT):
+        x = _f32(x).copy()
+        _check(lib().vo_dino_layer(self._h, prefix.encode(), n_heads, gelu_mode, _fp(x), x.shape[0], x.shape[1]))
+        return x
+
+
+def make_params(patch_size=14, embed_dim=384, n_layers=12, n_heads=6, image_size=518, image_multiple=14,
+                feature_layers=(2, 5, 8, 11), max_depth=1.0, gelu_mode=GELU_GGML_F16_LUT) -> Params:
+    return Params(patch_size, embed_dim, n_layers, n_heads, image_size, image_multiple,
+                  (C.c_int * 4)(*feature_layers), max_depth, gelu_mode)

@@ -1,0 +1,985 @@
+/*
+ * visp_oracle.c -- CPU ORACLE (test infrastructure, NOT product code). See visp_oracle.h.
+ *
+ * Every function cites the reference lines it restates (paths relative to the reference
+ * repository root). ggml itself (github.com/Acly/llama.cpp, subdir ggml; un-vendored
+ * submodule, pinned commit unrecoverable) is restated from its published CPU algorithms and
+ * from the torch functionals the reference's tests/test_primitives.py pins it to.
+ */
+#include "visp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static __thread char g_err[256];
+const char* vo_last_error(void) { return g_err; }
+#define VO_FAIL(...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return 0; } while (0)
+
+int vo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void vo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* f16 <-> f32 (IEEE binary16, round-to-nearest-even; what ggml_fp16_to_fp32 / fp32_to_fp16 do) */
+
+static inline float f16_bits_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1f;
+    uint32_t man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal */
+            int e = -1;
+            do { e++; man <<= 1; } while ((man & 0x400u) == 0);
+            man &= 0x3ffu;
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static inline uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) { /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x200u | ((ax >> 13) & 0x3ffu) : 0));
+    }
+    if (ax >= 0x477ff000u) { /* rounds to >= 65520 -> inf */
+        return (uint16_t)(sign | 0x7c00u);
+    }
+    if (ax < 0x33000001u) { /* < 2^-25 (or exactly 2^-25, ties-to-even -> 0) */
+        return (uint16_t)sign;
+    }
+    int e = (int)(ax >> 23) - 127;
+    uint32_t man = (ax & 0x7fffffu) | 0x800000u;
+    int shift;
+    uint32_t hexp;
+    if (e < -14) { /* subnormal half */
+        shift = 13 + (-14 - e);
+        hexp = 0;
+    } else {
+        shift = 13;
+        hexp = (uint32_t)(e + 15);
+    }
+    uint32_t q = man >> shift;
+    uint32_t rem = man & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    uint32_t h;
+    if (hexp == 0) {
+        h = q; /* may carry into exponent 1: correct */
+    } else {
+        h = ((hexp - 1) << 10) + q; /* q includes the implicit bit (0x400) */
+    }
+    return (uint16_t)(sign | h);
+}
+
+void vo_f16_to_f32(const uint16_t* src, float* dst, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) dst[i] = f16_bits_to_f32(src[i]);
+}
+void vo_f32_to_f16(const float* src, uint16_t* dst, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) dst[i] = f32_to_f16_bits(src[i]);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* image ops */
+
+static int fmt_channels(int f) {
+    switch (f) {
+        case VO_RGBA_U8: case VO_BGRA_U8: case VO_ARGB_U8: case VO_RGBA_F32: return 4;
+        case VO_RGB_U8: case VO_RGB_F32: return 3;
+        case VO_ALPHA_U8: case VO_ALPHA_F32: return 1;
+    }
+    return 0;
+}
+static int fmt_is_float(int f) { return f >= VO_RGBA_F32; }
+
+/* src/visp/image.cpp get_channel_map: bgra -> {2,1,0,3}, argb -> {1,2,3,0} */
+static void channel_map(int f, int m[4]) {
+    m[0] = 0; m[1] = 1; m[2] = 2; m[3] = 3;
+    if (f == VO_BGRA_U8) { m[0] = 2; m[1] = 1; m[2] = 0; m[3] = 3; }
+    if (f == VO_ARGB_U8) { m[0] = 1; m[1] = 2; m[2] = 3; m[3] = 0; }
+}
+
+/* src/visp/image-impl.h:17-34 (image_load) */
+static void load_u8_pixel(const uint8_t* p, int ch, const int map[4], float v[4]) {
+    if (ch == 1) {
+        float a = (float)p[0] / 255.0f;
+        v[0] = v[1] = v[2] = v[3] = a;
+    } else if (ch == 3) {
+        v[0] = (float)p[0] / 255.0f; v[1] = (float)p[1] / 255.0f; v[2] = (float)p[2] / 255.0f;
+        v[3] = 1.0f / 255.0f; /* f32x4{r,g,b,1} / 255 */
+    } else {
+        for (int c = 0; c < 4; ++c) v[c] = (float)p[map[c]] / 255.0f;
+    }
+}
+
+/* src/visp/image.cpp:215-255 convert<Src,Dst>: dst(x,y) = (src(min(i+tile, extent-1)) + offset) * scale */
+int vo_image_u8_to_f32(const uint8_t* src, int sw, int sh, int sstride, int sformat,
+                       float* dst, int dw, int dh, int dformat,
+                       const float offset[4], const float scale[4], int tile_x, int tile_y) {
+    int sch = fmt_channels(sformat), dch = fmt_channels(dformat);
+    if (fmt_is_float(sformat) || !fmt_is_float(dformat)) VO_FAIL("u8_to_f32: bad formats");
+    if ((dch == 1 && sch != 1) || (dch != 1 && sch == 1)) VO_FAIL("u8_to_f32: incompatible channels");
+    int map[4];
+    channel_map(sformat, map);
+    for (int y = 0; y < dh; ++y) {
+        for (int x = 0; x < dw; ++x) {
+            int sx = x + tile_x, sy = y + tile_y;
+            if (sx > sw - 1) sx = sw - 1;
+            if (sy > sh - 1) sy = sh - 1;
+            float v[4];
+            load_u8_pixel(src + (size_t)sy * sstride + (size_t)sx * sch, sch, map, v);
+            float* d = dst + ((size_t)y * dw + x) * dch;
+            for (int c = 0; c < dch; ++c) d[c] = (v[c] + offset[c]) * scale[c];
+        }
+    }
+    return 1;
+}
+
+/* src/visp/image.cpp:257-288 convert2: store(load * scale + offset); image-impl.h:36-43 */
+int vo_image_f32_to_u8(const float* src, int w, int h, int sformat, uint8_t* dst, int dformat,
+                       float scale, float offset) {
+    int sch = fmt_channels(sformat), dch = fmt_channels(dformat);
+    if (!fmt_is_float(sformat) || fmt_is_float(dformat)) VO_FAIL("f32_to_u8: bad formats");
+    if (!((dch == 1 && sch == 1) || (dch == 4 && sch >= 3))) VO_FAIL("f32_to_u8: incompatible channels");
+    for (int64_t i = 0; i < (int64_t)w * h; ++i) {
+        float v[4];
+        if (sch == 1) { v[0] = v[1] = v[2] = v[3] = src[i]; }
+        else if (sch == 3) { v[0] = src[i * 3]; v[1] = src[i * 3 + 1]; v[2] = src[i * 3 + 2]; v[3] = 1.0f; }
+        else { for (int c = 0; c < 4; ++c) v[c] = src[i * 4 + c]; }
+        for (int c = 0; c < dch; ++c) {
+            float t = v[c] * scale + offset;
+            t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+            dst[i * dch + c] = (uint8_t)(t * 255.0f);
+        }
+    }
+    return 1;
+}
+
+/* src/visp/image.cpp:537-576 */
+void vo_image_normalize(const float* src, float* dst, int w, int h, int channels, float mn, float mx) {
+    float minv[4], maxv[4];
+    for (int c = 0; c < 4; ++c) { minv[c] = FLT_MAX; maxv[c] = -FLT_MAX; }
+    int64_t n = (int64_t)w * h;
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < channels; ++c) {
+            float v = src[i * channels + c];
+            if (v < minv[c]) minv[c] = v;
+            if (v > maxv[c]) maxv[c] = v;
+        }
+    float scale[4], offset[4];
+    for (int c = 0; c < channels; ++c) {
+        float delta = maxv[c] - minv[c];
+        if (delta < 1e-5f) delta = 1.0f;
+        scale[c] = (mx - mn) / delta;
+        offset[c] = -minv[c] * scale[c] + mn;
+    }
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < channels; ++c) dst[i * channels + c] = src[i * channels + c] * scale[c] + offset[c];
+}
+
+/* src/visp/arch/depth-anything.cpp:112-117, src/util/math.h:16-18,59-61 */
+void vo_depthany_image_extent(int w, int h, int image_size, int image_multiple, int* ow, int* oh) {
+    int min_side = w < h ? w : h;
+    int nm = ((min_side + image_multiple - 1) / image_multiple) * image_multiple;
+    int tgt = image_size > nm ? image_size : nm;
+    int tw = w * tgt / min_side, th = h * tgt / min_side;
+    *ow = ((tw + image_multiple - 1) / image_multiple) * image_multiple;
+    *oh = ((th + image_multiple - 1) / image_multiple) * image_multiple;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* weight transfer: src/visp/ml.cpp:331-340 (permute_whcn_to_cwhn), 342-433, 449-503 */
+
+static int64_t nelem4(const int64_t ne[4]) { return ne[0] * ne[1] * ne[2] * ne[3]; }
+
+int vo_transfer_tensor(const vo_tensor* t, int whcn_to_cwhn, void* dst, int64_t out_ne[4]) {
+    int64_t n = nelem4(t->ne);
+    if (t->type == VO_I32) {
+        memcpy(dst, t->data, (size_t)n * 4);
+        memcpy(out_ne, t->ne, sizeof(int64_t) * 4);
+        return 1;
+    }
+    if (t->type != VO_F32 && t->type != VO_F16) VO_FAIL("unsupported tensor type %d", t->type);
+    float* out = (float*)dst;
+    float* tmp = out;
+    if (whcn_to_cwhn) {
+        tmp = (float*)malloc((size_t)n * 4);
+        if (!tmp) VO_FAIL("out of memory");
+    }
+    if (t->type == VO_F16) vo_f16_to_f32((const uint16_t*)t->data, tmp, n);
+    else memcpy(tmp, t->data, (size_t)n * 4);
+    if (!whcn_to_cwhn) {
+        memcpy(out_ne, t->ne, sizeof(int64_t) * 4);
+        return 1;
+    }
+    /* source strides in elements (ggml nb / type size) */
+    int64_t sne[4], snb[4];
+    memcpy(sne, t->ne, sizeof sne);
+    snb[0] = 1;
+    for (int i = 1; i < 4; ++i) snb[i] = snb[i - 1] * sne[i - 1];
+    int64_t pne[4], pnb[4];
+    if (sne[2] == 1) { /* depthwise wh1c -> c1wh : perm = {n[3], n[2], n[0], n[1]} */
+        pne[0] = sne[3]; pne[1] = sne[2]; pne[2] = sne[0]; pne[3] = sne[1];
+        pnb[0] = snb[3]; pnb[1] = snb[2]; pnb[2] = snb[0]; pnb[3] = snb[1];
+    } else { /* swap(0,2) then swap(1,2): [w,h,c,o] -> [c,w,h,o] */
+        pne[0] = sne[2]; pne[1] = sne[0]; pne[2] = sne[1]; pne[3] = sne[3];
+        pnb[0] = snb[2]; pnb[1] = snb[0]; pnb[2] = snb[1]; pnb[3] = snb[3];
+    }
+    int64_t o = 0;
+    for (int64_t i3 = 0; i3 < pne[3]; ++i3)
+        for (int64_t i2 = 0; i2 < pne[2]; ++i2)
+            for (int64_t i1 = 0; i1 < pne[1]; ++i1)
+                for (int64_t i0 = 0; i0 < pne[0]; ++i0)
+                    out[o++] = tmp[i0 * pnb[0] + i1 * pnb[1] + i2 * pnb[2] + i3 * pnb[3]];
+    memcpy(out_ne, pne, sizeof pne);
+    free(tmp);
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* GEMM core: y[M][N] (+)= x[M][K] * wt[K][N]; k summed in ascending order per output */
+
+static void gemm_nn(const float* x, int64_t ldx, const float* wt, int64_t ldw, float* y, int64_t ldy,
+                    int64_t M, int64_t K, int64_t N, const float* bias) {
+    enum { MB = 8, NB = 128 };
+    int64_t mblocks = (M + MB - 1) / MB;
+#pragma omp parallel for schedule(static)
+    for (int64_t mb = 0; mb < mblocks; ++mb) {
+        int64_t m0 = mb * MB, mr = (M - m0 < MB) ? (M - m0) : MB;
+        float acc[MB][NB];
+        for (int64_t n0 = 0; n0 < N; n0 += NB) {
+            int64_t nr = (N - n0 < NB) ? (N - n0) : NB;
+            for (int r = 0; r < MB; ++r)
+                for (int j = 0; j < NB; ++j) acc[r][j] = 0.0f;
+            if (mr == MB && nr == NB) {
+                for (int64_t k = 0; k < K; ++k) {
+                    const float* wrow = wt + k * ldw + n0;
+                    float xs[MB];
+                    for (int r = 0; r < MB; ++r) xs[r] = x[(m0 + r) * ldx + k];
+                    for (int r = 0; r < MB; ++r)
+                        for (int j = 0; j < NB; ++j) acc[r][j] += xs[r] * wrow[j];
+                }
+            } else {
+                for (int64_t k = 0; k < K; ++k) {
+                    const float* wrow = wt + k * ldw + n0;
+                    for (int r = 0; r < mr; ++r) {
+                        float xv = x[(m0 + r) * ldx + k];
+                        for (int j = 0; j < nr; ++j) acc[r][j] += xv * wrow[j];
+                    }
+                }
+            }
+            for (int r = 0; r < mr; ++r)
+                for (int j = 0; j < nr; ++j)
+                    y[(m0 + r) * ldy + n0 + j] = acc[r][j] + (bias ? bias[n0 + j] : 0.0f);
+        }
+    }
+}
+
+static float* transpose_new(const float* w, int64_t N, int64_t K) { /* [N][K] -> [K][N] */
+    float* wt = (float*)malloc((size_t)N * K * 4);
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t k = 0; k < K; ++k) wt[k * N + n] = w[n * K + k];
+    return wt;
+}
+
+/* src/visp/nn.cpp:6-12: mul_mat(weight, x) + bias; weight ne=[K,N] == torch [N][K] */
+void vo_linear(const float* x, int64_t M, int64_t K, const float* w, const float* b, int64_t N, float* y) {
+    float* wt = transpose_new(w, N, K);
+    gemm_nn(x, K, wt, N, y, N, M, K, N, b);
+    free(wt);
+}
+
+/* src/visp/nn.cpp:14-19: ggml_norm (biased variance, eps inside sqrt, sums in double), *w, +b */
+void vo_layer_norm(const float* x, int64_t M, int64_t C, const float* w, const float* b, float eps, float* y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const float* xr = x + m * C;
+        float* yr = y + m * C;
+        double sum = 0.0;
+        for (int64_t c = 0; c < C; ++c) sum += (double)xr[c];
+        float mean = (float)(sum / (double)C);
+        double sum2 = 0.0;
+        for (int64_t c = 0; c < C; ++c) {
+            float v = xr[c] - mean;
+            yr[c] = v;
+            sum2 += (double)(v * v);
+        }
+        float variance = (float)(sum2 / (double)C);
+        float scale = 1.0f / sqrtf(variance + eps);
+        for (int64_t c = 0; c < C; ++c) {
+            float v = yr[c] * scale;
+            v = v * w[c];
+            yr[c] = v + b[c];
+        }
+    }
+}
+
+/* ggml_gelu on the CPU backend: tanh approximation through a 64K-entry fp16 table
+ * (docs/model-implementation-guide.md:284-288; ggml-cpu vec.h ggml_vec_gelu_f32) */
+static float gelu_tanh_f32(float x) {
+    const float GELU_COEF_A = 0.044715f;
+    const float SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    return 0.5f * x * (1.0f + tanhf(SQRT_2_OVER_PI * x * (1.0f + GELU_COEF_A * x * x)));
+}
+static uint16_t* g_gelu_lut = NULL;
+static void gelu_lut_init(void) {
+#pragma omp critical(vo_gelu_lut)
+    {
+        if (!g_gelu_lut) {
+            uint16_t* t = (uint16_t*)malloc(65536 * 2);
+            for (uint32_t i = 0; i < 65536; ++i) t[i] = f32_to_f16_bits(gelu_tanh_f32(f16_bits_to_f32((uint16_t)i)));
+            g_gelu_lut = t;
+        }
+    }
+}
+void vo_gelu(const float* x, float* y, int64_t n, int mode) {
+    if (mode == VO_GELU_GGML_F16_LUT) {
+        if (!g_gelu_lut) gelu_lut_init();
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            float v = x[i];
+            if (v <= -10.0f) y[i] = 0.0f;
+            else if (v >= 10.0f) y[i] = v;
+            else y[i] = f16_bits_to_f32(g_gelu_lut[f32_to_f16_bits(v)]);
+        }
+    } else if (mode == VO_GELU_TANH_F32) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) y[i] = gelu_tanh_f32(x[i]);
+    } else {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) y[i] = 0.5f * x[i] * (1.0f + erff(x[i] * 0.70710678118654752440f));
+    }
+}
+
+/* src/visp/nn.cpp:210-244 non-flash branch: S = mul_mat(k,q); soft_max_ext(S, scale); mul_mat(v^T, S) */
+void vo_attention(const float* q, const float* k, const float* v, int64_t N, int H, int hd, float scale, float* out) {
+    int64_t C = (int64_t)H * hd;
+    enum { QB = 8 };
+    int64_t qblocks = (N + QB - 1) / QB;
+    for (int h = 0; h < H; ++h) {
+        /* kt [hd][N] so the score GEMM runs in axpy form */
+        float* kt = (float*)malloc((size_t)hd * N * 4);
+        float* vh = (float*)malloc((size_t)N * hd * 4);
+        for (int64_t j = 0; j < N; ++j)
+            for (int d = 0; d < hd; ++d) {
+                kt[(int64_t)d * N + j] = k[j * C + h * hd + d];
+                vh[j * hd + d] = v[j * C + h * hd + d];
+            }
+#pragma omp parallel
+        {
+            float* s = (float*)malloc((size_t)QB * N * 4);
+#pragma omp for schedule(static)
+            for (int64_t qb = 0; qb < qblocks; ++qb) {
+                int64_t q0 = qb * QB, qr = (N - q0 < QB) ? (N - q0) : QB;
+                for (int64_t r = 0; r < qr; ++r) {
+                    float* sr = s + r * N;
+                    const float* qr_ = q + (q0 + r) * C + h * hd;
+                    for (int64_t j = 0; j < N; ++j) sr[j] = 0.0f;
+                    for (int d = 0; d < hd; ++d) {
+                        float qv = qr_[d];
+                        const float* krow = kt + (int64_t)d * N;
+                        for (int64_t j = 0; j < N; ++j) sr[j] += qv * krow[j];
+                    }
+                    /* ggml_soft_max_ext: x*scale, max, expf(x-max), sum (double), /sum */
+                    float mx = -INFINITY;
+                    for (int64_t j = 0; j < N; ++j) { sr[j] *= scale; if (sr[j] > mx) mx = sr[j]; }
+                    double sum = 0.0;
+                    for (int64_t j = 0; j < N; ++j) { float e = expf(sr[j] - mx); sr[j] = e; sum += (double)e; }
+                    float inv = (float)(1.0 / sum);
+                    for (int64_t j = 0; j < N; ++j) sr[j] *= inv;
+                    float* o = out + (q0 + r) * C + h * hd;
+                    float acc[256];
+                    for (int d = 0; d < hd; ++d) acc[d] = 0.0f;
+                    for (int64_t j = 0; j < N; ++j) {
+                        float p = sr[j];
+                        const float* vrow = vh + j * hd;
+                        for (int d = 0; d < hd; ++d) acc[d] += p * vrow[d];
+                    }
+                    for (int d = 0; d < hd; ++d) o[d] = acc[d];
+                }
+            }
+            free(s);
+        }
+        free(kt);
+        free(vh);
+    }
+}
+
+/* src/visp/nn.cpp:72-100 (CWHN branch) + add_bias_2d :62-70: torch conv2d semantics, NHWC data,
+ * weight [Cout][kh][kw][Cin]. Implemented as chunked im2col + GEMM (what ggml's CPU conv_2d does). */
+void vo_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias,
+                    int Cout, int kh, int kw, int stride, int pad, float* y) {
+    int OH = (H + 2 * pad - kh) / stride + 1;
+    int OW = (W + 2 * pad - kw) / stride + 1;
+    int64_t K = (int64_t)kh * kw * Cin;
+    float* wt = transpose_new(w, Cout, K);
+    if (kh == 1 && kw == 1 && stride == 1 && pad == 0) {
+        gemm_nn(x, Cin, wt, Cout, y, Cout, (int64_t)B * H * W, K, Cout, bias);
+        free(wt);
+        return;
+    }
+    int64_t total = (int64_t)B * OH * OW;
+    int64_t chunk = 4096;
+    float* col = (float*)malloc((size_t)chunk * K * 4);
+    for (int64_t p0 = 0; p0 < total; p0 += chunk) {
+        int64_t pn = (total - p0 < chunk) ? (total - p0) : chunk;
+#pragma omp parallel for schedule(static)
+        for (int64_t p = 0; p < pn; ++p) {
+            int64_t idx = p0 + p;
+            int b = (int)(idx / ((int64_t)OH * OW));
+            int rem = (int)(idx % ((int64_t)OH * OW));
+            int oy = rem / OW, ox = rem % OW;
+            float* c = col + p * K;
+            for (int ky = 0; ky < kh; ++ky) {
+                int iy = oy * stride - pad + ky;
+                for (int kx = 0; kx < kw; ++kx) {
+                    int ix = ox * stride - pad + kx;
+                    float* cc = c + ((int64_t)ky * kw + kx) * Cin;
+                    if (iy < 0 || iy >= H || ix < 0 || ix >= W) {
+                        memset(cc, 0, (size_t)Cin * 4);
+                    } else {
+                        memcpy(cc, x + (((int64_t)b * H + iy) * W + ix) * Cin, (size_t)Cin * 4);
+                    }
+                }
+            }
+        }
+        gemm_nn(col, K, wt, Cout, y + p0 * Cout, Cout, pn, K, Cout, bias);
+    }
+    free(col);
+    free(wt);
+}
+
+/* src/visp/nn.cpp:117-129: ggml_conv_transpose_2d_p0 == torch conv_transpose2d(padding=0),
+ * weight ne [kw,kh,Cout,Cin] == torch [Cin][Cout][kh][kw]; then + bias */
+void vo_conv_transpose2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w,
+                              const float* bias, int Cout, int kh, int kw, int stride, float* y) {
+    int OH = (H - 1) * stride + kh, OW = (W - 1) * stride + kw;
+    int64_t on = (int64_t)B * OH * OW * Cout;
+    for (int64_t i = 0; i < on; ++i) y[i] = 0.0f;
+    /* wr[ky][kx][ci][co] for contiguous inner loop */
+    float* wr = (float*)malloc((size_t)kh * kw * Cin * Cout * 4);
+    for (int ci = 0; ci < Cin; ++ci)
+        for (int co = 0; co < Cout; ++co)
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx)
+                    wr[(((int64_t)ky * kw + kx) * Cin + ci) * Cout + co] = w[(((int64_t)ci * Cout + co) * kh + ky) * kw + kx];
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        for (int iy = 0; iy < H; ++iy)
+            for (int ix = 0; ix < W; ++ix) {
+                const float* xp = x + (((int64_t)b * H + iy) * W + ix) * Cin;
+                for (int ky = 0; ky < kh; ++ky)
+                    for (int kx = 0; kx < kw; ++kx) {
+                        float* yp = y + (((int64_t)b * OH + iy * stride + ky) * OW + ix * stride + kx) * Cout;
+                        const float* wk = wr + ((int64_t)ky * kw + kx) * Cin * Cout;
+                        for (int ci = 0; ci < Cin; ++ci) {
+                            float xv = xp[ci];
+                            const float* wrow = wk + (int64_t)ci * Cout;
+                            for (int co = 0; co < Cout; ++co) yp[co] += xv * wrow[co];
+                        }
+                    }
+            }
+    }
+    if (bias) {
+#pragma omp parallel for schedule(static)
+        for (int64_t p = 0; p < (int64_t)B * OH * OW; ++p)
+            for (int co = 0; co < Cout; ++co) y[p * Cout + co] += bias[co];
+    }
+    free(wr);
+}
+
+/* src/visp/ml.cpp:782-788 -> ggml_interpolate(BILINEAR [| ALIGN_CORNERS]); ggml's CPU upscale:
+ * align_corners: sf = (out-1)/(in-1), src = i / sf; else src = (i + 0.5)/sf - 0.5 with sf = out/in.
+ * Pinned to torch.nn.functional.interpolate by the reference's tests/test_primitives.py:165-184. */
+static void interp_axis_bilinear(int in, int out, int align, int* i0, int* i1, float* t) {
+    float sf = (float)out / (float)in;
+    float off = 0.5f;
+    if (align) {
+        off = 0.0f;
+        if (out > 1 && in > 1) sf = (float)(out - 1) / (float)(in - 1);
+    }
+    for (int i = 0; i < out; ++i) {
+        float s = ((float)i + off) / sf - off;
+        int a = (int)floorf(s);
+        int b = a + 1;
+        if (a < 0) a = 0; if (a > in - 1) a = in - 1;
+        if (b < 0) b = 0; if (b > in - 1) b = in - 1;
+        float d = s - (float)a;
+        if (d < 0.0f) d = 0.0f; if (d > 1.0f) d = 1.0f;
+        i0[i] = a; i1[i] = b; t[i] = d;
+    }
+}
+
+void vo_interpolate_bilinear_nhwc(const float* x, int B, int H, int W, int C, int OH, int OW,
+                                  int align_corners, float* y) {
+    int* y0 = (int*)malloc(sizeof(int) * OH); int* y1 = (int*)malloc(sizeof(int) * OH);
+    int* x0 = (int*)malloc(sizeof(int) * OW); int* x1 = (int*)malloc(sizeof(int) * OW);
+    float* ty = (float*)malloc(4 * OH); float* tx = (float*)malloc(4 * OW);
+    interp_axis_bilinear(H, OH, align_corners, y0, y1, ty);
+    interp_axis_bilinear(W, OW, align_corners, x0, x1, tx);
+#pragma omp parallel for schedule(static)
+    for (int64_t row = 0; row < (int64_t)B * OH; ++row) {
+        int b = (int)(row / OH), oy = (int)(row % OH);
+        const float* r0 = x + ((int64_t)b * H + y0[oy]) * W * C;
+        const float* r1 = x + ((int64_t)b * H + y1[oy]) * W * C;
+        float dy = ty[oy];
+        for (int ox = 0; ox < OW; ++ox) {
+            float dx = tx[ox];
+            const float* a = r0 + (int64_t)x0[ox] * C; const float* bb = r0 + (int64_t)x1[ox] * C;
+            const float* c = r1 + (int64_t)x0[ox] * C; const float* d = r1 + (int64_t)x1[ox] * C;
+            float* o = y + (row * OW + ox) * C;
+            for (int ch = 0; ch < C; ++ch)
+                o[ch] = a[ch] * (1 - dx) * (1 - dy) + bb[ch] * dx * (1 - dy) + c[ch] * (1 - dx) * dy + d[ch] * dx * dy;
+        }
+    }
+    free(y0); free(y1); free(x0); free(x1); free(ty); free(tx);
+}
+
+/* ggml_interpolate(BICUBIC): cubic convolution a=-0.75 with clamped taps (torch upsample_bicubic2d) */
+static void cubic_coeffs(float t, float c[4]) {
+    const float a = -0.75f;
+    float x;
+    x = t + 1.0f; c[0] = ((a * x - 5.0f * a) * x + 8.0f * a) * x - 4.0f * a;
+    x = t;        c[1] = ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t; c[2] = ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t; c[3] = ((a * x - 5.0f * a) * x + 8.0f * a) * x - 4.0f * a;
+}
+void vo_interpolate_bicubic_nhwc(const float* x, int B, int H, int W, int C, int OH, int OW,
+                                 int align_corners, float* y) {
+    float sfy = (float)OH / (float)H, sfx = (float)OW / (float)W, off = 0.5f;
+    if (align_corners) {
+        off = 0.0f;
+        if (OH > 1 && H > 1) sfy = (float)(OH - 1) / (float)(H - 1);
+        if (OW > 1 && W > 1) sfx = (float)(OW - 1) / (float)(W - 1);
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t row = 0; row < (int64_t)B * OH; ++row) {
+        int b = (int)(row / OH), oy = (int)(row % OH);
+        float sy = ((float)oy + off) / sfy - off;
+        int iy = (int)floorf(sy);
+        float cy[4];
+        cubic_coeffs(sy - (float)iy, cy);
+        for (int ox = 0; ox < OW; ++ox) {
+            float sx = ((float)ox + off) / sfx - off;
+            int ix = (int)floorf(sx);
+            float cx[4];
+            cubic_coeffs(sx - (float)ix, cx);
+            float* o = y + (row * OW + ox) * C;
+            for (int ch = 0; ch < C; ++ch) o[ch] = 0.0f;
+            for (int j = 0; j < 4; ++j) {
+                int yy = iy - 1 + j; if (yy < 0) yy = 0; if (yy > H - 1) yy = H - 1;
+                for (int i = 0; i < 4; ++i) {
+                    int xx = ix - 1 + i; if (xx < 0) xx = 0; if (xx > W - 1) xx = W - 1;
+                    float wgt = cy[j] * cx[i];
+                    const float* s = x + (((int64_t)b * H + yy) * W + xx) * C;
+                    for (int ch = 0; ch < C; ++ch) o[ch] += wgt * s[ch];
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* model */
+
+typedef struct {
+    char name[64];
+    int32_t type; /* VO_F32 or VO_I32 after transfer */
+    int64_t ne[4];
+    void* data;
+} vo_mtensor;
+
+struct vo_model {
+    int n;
+    vo_mtensor* t;
+};
+
+/* src/visp/ml.cpp:449-503 with float_type=F32, dst_layout=cwhn (backend_device::preferred_*, :115-135) */
+vo_model* vo_model_create(const vo_tensor* tensors, int n_tensors, const int32_t* conv2d_idx, int n_conv2d, int src_layout) {
+    vo_model* m = (vo_model*)calloc(1, sizeof *m);
+    m->n = n_tensors;
+    m->t = (vo_mtensor*)calloc((size_t)n_tensors, sizeof(vo_mtensor));
+    int to_cwhn = (src_layout == VO_LAYOUT_WHCN);
+    int ci = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        int is2d = (ci < n_conv2d && conv2d_idx[ci] == i);
+        if (is2d) ++ci;
+        vo_mtensor* d = &m->t[i];
+        strncpy(d->name, tensors[i].name, 63);
+        d->type = tensors[i].type == VO_I32 ? VO_I32 : VO_F32;
+        d->data = malloc((size_t)nelem4(tensors[i].ne) * 4);
+        if (!vo_transfer_tensor(&tensors[i], is2d && to_cwhn, d->data, d->ne)) {
+            vo_model_destroy(m);
+            return NULL;
+        }
+    }
+    return m;
+}
+void vo_model_destroy(vo_model* m) {
+    if (!m) return;
+    for (int i = 0; i < m->n; ++i) free(m->t[i].data);
+    free(m->t);
+    free(m);
+}
+int vo_model_n_tensors(const vo_model* m) { return m->n; }
+
+static const vo_mtensor* find_t(const vo_model* m, const char* name) {
+    for (int i = 0; i < m->n; ++i)
+        if (strcmp(m->t[i].name, name) == 0) return &m->t[i];
+    return NULL;
+}
+const float* vo_model_tensor(const vo_model* m, const char* name, int64_t ne[4]) {
+    const vo_mtensor* t = find_t(m, name);
+    if (!t) return NULL;
+    if (ne) memcpy(ne, t->ne, sizeof t->ne);
+    return (const float*)t->data;
+}
+
+/* model_ref::weights / find with dotted prefix (src/visp/ml.cpp:567-625) */
+static const float* W(const vo_model* m, const char* prefix, const char* name, int64_t ne[4], int required) {
+    char full[160];
+    snprintf(full, sizeof full, "%s.%s", prefix, name);
+    const float* p = vo_model_tensor(m, full, ne);
+    if (!p && required) snprintf(g_err, sizeof g_err, "tensor not found: %s", full);
+    return p;
+}
+
+static void capture(vo_capture* caps, int n, const char* name, const float* data, int64_t count) {
+    for (int i = 0; i < n; ++i)
+        if (strcmp(caps[i].name, name) == 0) {
+            caps[i].written = count;
+            if (count <= caps[i].capacity) memcpy(caps[i].dst, data, (size_t)count * 4);
+        }
+}
+
+static int linear_m(const vo_model* m, const char* prefix, const float* x, int64_t M, int64_t K, int64_t* N_out, float** y) {
+    int64_t ne[4];
+    const float* w = W(m, prefix, "weight", ne, 1);
+    if (!w) return 0;
+    if (ne[0] != K) VO_FAIL("linear %s: K mismatch (%lld vs %lld)", prefix, (long long)ne[0], (long long)K);
+    const float* b = W(m, prefix, "bias", NULL, 0);
+    int64_t N = ne[1];
+    *y = (float*)malloc((size_t)M * N * 4);
+    vo_linear(x, M, K, w, b, N, *y);
+    *N_out = N;
+    return 1;
+}
+
+/* src/visp/arch/dino.cpp:48-90 */
+int vo_dino_layer(const vo_model* m, const char* prefix, int n_heads, int gelu_mode, float* x, int64_t N, int64_t C) {
+    char p[128];
+    int64_t n_out;
+    float* t = (float*)malloc((size_t)N * C * 4);
+    /* attn = layer_norm(norm1, x, 1e-6) */
+    snprintf(p, sizeof p, "%s.norm1", prefix);
+    const float *lw = W(m, p, "weight", NULL, 1), *lb = W(m, p, "bias", NULL, 1);
+    if (!lw || !lb) { free(t); return 0; }
+    vo_layer_norm(x, N, C, lw, lb, 1e-6f, t);
+    /* self_attention: q,k,v projections, attention(), output.dense */
+    float *q = NULL, *k = NULL, *v = NULL, *o = NULL;
+    snprintf(p, sizeof p, "%s.attention.attention.query", prefix);
+    if (!linear_m(m, p, t, N, C, &n_out, &q)) { free(t); return 0; }
+    snprintf(p, sizeof p, "%s.attention.attention.key", prefix);
+    if (!linear_m(m, p, t, N, C, &n_out, &k)) { free(t); free(q); return 0; }
+    snprintf(p, sizeof p, "%s.attention.attention.value", prefix);
+    if (!linear_m(m, p, t, N, C, &n_out, &v)) { free(t); free(q); free(k); return 0; }
+    float scale = 1.0f / sqrtf((float)C / (float)n_heads);
+    float* a = (float*)malloc((size_t)N * C * 4);
+    vo_attention(q, k, v, N, n_heads, (int)(C / n_heads), scale, a);
+    free(q); free(k); free(v);
+    snprintf(p, sizeof p, "%s.attention.output.dense", prefix);
+    if (!linear_m(m, p, a, N, C, &n_out, &o)) { free(t); free(a); return 0; }
+    free(a);
+    /* layer_scale1 then residual add */
+    snprintf(p, sizeof p, "%s.layer_scale1", prefix);
+    const float* l1 = W(m, p, "lambda1", NULL, 1);
+    if (!l1) { free(t); free(o); return 0; }
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t c = 0; c < C; ++c) {
+            float s = o[i * C + c] * l1[c];
+            x[i * C + c] = x[i * C + c] + s;
+        }
+    free(o);
+    /* ffn */
+    snprintf(p, sizeof p, "%s.norm2", prefix);
+    lw = W(m, p, "weight", NULL, 1); lb = W(m, p, "bias", NULL, 1);
+    if (!lw || !lb) { free(t); return 0; }
+    vo_layer_norm(x, N, C, lw, lb, 1e-6f, t);
+    float *h1 = NULL, *h2 = NULL;
+    int64_t hid;
+    snprintf(p, sizeof p, "%s.mlp.fc1", prefix);
+    if (!linear_m(m, p, t, N, C, &hid, &h1)) { free(t); return 0; }
+    vo_gelu(h1, h1, N * hid, gelu_mode);
+    snprintf(p, sizeof p, "%s.mlp.fc2", prefix);
+    if (!linear_m(m, p, h1, N, hid, &n_out, &h2)) { free(t); free(h1); return 0; }
+    free(h1);
+    snprintf(p, sizeof p, "%s.layer_scale2", prefix);
+    const float* l2 = W(m, p, "lambda1", NULL, 1);
+    if (!l2) { free(t); free(h2); return 0; }
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t c = 0; c < C; ++c) {
+            float s = h2[i * C + c] * l2[c];
+            x[i * C + c] = x[i * C + c] + s;
+        }
+    free(h2);
+    free(t);
+    return 1;
+}
+
+static int conv_m(const vo_model* m, const char* prefix, const float* x, int B, int H, int Wd, int Cin,
+                  int stride, int pad, int* OH, int* OW, int* Cout, float** y) {
+    int64_t ne[4];
+    const float* w = W(m, prefix, "weight", ne, 1); /* cwhn: ne = [Cin, kw, kh, Cout] */
+    if (!w) return 0;
+    if (ne[0] != Cin) VO_FAIL("conv %s: Cin mismatch (%lld vs %d)", prefix, (long long)ne[0], Cin);
+    const float* b = W(m, prefix, "bias", NULL, 0);
+    int kw = (int)ne[1], kh = (int)ne[2], co = (int)ne[3];
+    *OH = (H + 2 * pad - kh) / stride + 1;
+    *OW = (Wd + 2 * pad - kw) / stride + 1;
+    *Cout = co;
+    *y = (float*)malloc((size_t)B * *OH * *OW * co * 4);
+    vo_conv2d_nhwc(x, B, H, Wd, Cin, w, b, co, kh, kw, stride, pad, *y);
+    return 1;
+}
+
+static void relu_new(const float* x, float* y, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) y[i] = x[i] > 0.0f ? x[i] : 0.0f;
+}
+
+/* src/visp/arch/depth-anything.cpp:15-23: x + conv2(relu(conv1(relu(x)))) ; in-place on x */
+static int residual_conv(const vo_model* m, const char* prefix, float* x, int H, int Wd, int C) {
+    char p[160];
+    int64_t n = (int64_t)H * Wd * C;
+    float* t = (float*)malloc((size_t)n * 4);
+    relu_new(x, t, n);
+    int oh, ow, co;
+    float *c1 = NULL, *c2 = NULL;
+    snprintf(p, sizeof p, "%s.convolution1", prefix);
+    if (!conv_m(m, p, t, 1, H, Wd, C, 1, 1, &oh, &ow, &co, &c1)) { free(t); return 0; }
+    relu_new(c1, c1, n);
+    snprintf(p, sizeof p, "%s.convolution2", prefix);
+    if (!conv_m(m, p, c1, 1, H, Wd, C, 1, 1, &oh, &ow, &co, &c2)) { free(t); free(c1); return 0; }
+    for (int64_t i = 0; i < n; ++i) x[i] = x[i] + c2[i];
+    free(t); free(c1); free(c2);
+    return 1;
+}
+
+/* src/visp/arch/depth-anything.cpp:25-42; x0 is consumed (modified in place), result newly allocated */
+static int feature_fusion(const vo_model* m, const char* prefix, float* x0, const float* x1, int H, int Wd, int C,
+                          int OH, int OW, float** out) {
+    char p[160];
+    int64_t n = (int64_t)H * Wd * C;
+    if (x1) {
+        float* r = (float*)malloc((size_t)n * 4);
+        memcpy(r, x1, (size_t)n * 4);
+        snprintf(p, sizeof p, "%s.residual_layer1", prefix);
+        if (!residual_conv(m, p, r, H, Wd, C)) { free(r); return 0; }
+        for (int64_t i = 0; i < n; ++i) x0[i] = x0[i] + r[i];
+        free(r);
+    }
+    snprintf(p, sizeof p, "%s.residual_layer2", prefix);
+    if (!residual_conv(m, p, x0, H, Wd, C)) return 0;
+    float* up = (float*)malloc((size_t)OH * OW * C * 4);
+    vo_interpolate_bilinear_nhwc(x0, 1, H, Wd, C, OH, OW, 1, up);
+    int oh, ow, co;
+    snprintf(p, sizeof p, "%s.projection", prefix);
+    int ok = conv_m(m, p, up, 1, OH, OW, C, 1, 0, &oh, &ow, &co, out);
+    free(up);
+    return ok;
+}
+
+/* depthany_predict: src/visp/arch/depth-anything.cpp:100-110, dino.cpp:32-46,92-110, depth-anything.cpp:44-96 */
+int vo_depthany_predict(const vo_model* m, const vo_depthany_params* P, const float* image, int w, int h,
+                        float* out, vo_capture* caps, int ncap) {
+    char p[160], cname[64];
+    int ps = P->patch_size;
+    if (w % ps || h % ps) VO_FAIL("image extent %dx%d not a multiple of patch size %d", w, h, ps);
+    int pw = w / ps, ph = h / ps;
+    int64_t C = P->embed_dim, N = (int64_t)pw * ph + 1;
+
+    /* prepare_tokens (dino.cpp:32-46): patch_embed conv (nn.cpp:166-180), cls concat, + pos */
+    int oh, ow, co;
+    float* pe = NULL;
+    if (!conv_m(m, "backbone.embeddings.patch_embeddings.projection", image, 1, h, w, 3, ps, 0, &oh, &ow, &co, &pe)) return 0;
+    if (co != C || oh != ph || ow != pw) { free(pe); VO_FAIL("patch embed shape mismatch"); }
+    int64_t pne[4];
+    const float* cls = vo_model_tensor(m, "backbone.embeddings.cls_token", NULL);
+    const float* pos = vo_model_tensor(m, "backbone.embeddings.position_embeddings", pne);
+    if (!cls || !pos) { free(pe); VO_FAIL("missing cls_token / position_embeddings"); }
+    float* x = (float*)malloc((size_t)N * C * 4);
+    memcpy(x, cls, (size_t)C * 4);
+    memcpy(x + C, pe, (size_t)(N - 1) * C * 4);
+    free(pe);
+    /* interpolate_pos_encoding (dino.cpp:10-30) */
+    int64_t n_stored = pne[1] - 1;
+    if (n_stored == N - 1 && w == h) {
+        for (int64_t i = 0; i < N * C; ++i) x[i] += pos[i];
+    } else {
+        int sq = (int)(sqrtf((float)n_stored) + 0.01f);
+        float* ip = (float*)malloc((size_t)(N - 1) * C * 4);
+        vo_interpolate_bicubic_nhwc(pos + C, 1, sq, sq, (int)C, ph, pw, 0, ip);
+        for (int64_t c = 0; c < C; ++c) x[c] += pos[c];
+        for (int64_t i = 0; i < (N - 1) * C; ++i) x[C + i] += ip[i];
+        free(ip);
+    }
+    capture(caps, ncap, "tokens", x, N * C);
+
+    /* get_intermediate_layers (dino.cpp:92-110) */
+    float* feats[4] = {0, 0, 0, 0};
+    int nf = 0;
+    const float* fw = vo_model_tensor(m, "backbone.layernorm.weight", NULL);
+    const float* fb = vo_model_tensor(m, "backbone.layernorm.bias", NULL);
+    if (!fw || !fb) { free(x); VO_FAIL("missing backbone.layernorm"); }
+    for (int i = 0; i < P->n_layers; ++i) {
+        snprintf(p, sizeof p, "backbone.encoder.layer.%d", i);
+        if (!vo_dino_layer(m, p, P->n_heads, P->gelu_mode, x, N, C)) { free(x); return 0; }
+        snprintf(cname, sizeof cname, "layer_%d", i);
+        capture(caps, ncap, cname, x, N * C);
+        for (int f = 0; f < 4; ++f)
+            if (P->feature_layers[f] == i && nf < 4) {
+                float* o = (float*)malloc((size_t)N * C * 4);
+                vo_layer_norm(x, N, C, fw, fb, 1e-6f, o);
+                snprintf(cname, sizeof cname, "dino_layer_%d", i);
+                capture(caps, ncap, cname, o, N * C);
+                feats[nf++] = o;
+            }
+    }
+    free(x);
+    if (nf != 4) { for (int f = 0; f < nf; ++f) free(feats[f]); VO_FAIL("expected 4 feature layers, got %d", nf); }
+
+    /* dpt::neck (depth-anything.cpp:44-79) */
+    float* layer[4];
+    int lh[4], lw[4], lc[4];
+    int ok = 1;
+    for (int i = 0; i < 4 && ok; ++i) {
+        float* xin = feats[i] + C; /* slice off cls: rows 1..N-1 == [ph][pw][C] */
+        float* pr = NULL;
+        snprintf(p, sizeof p, "neck.reassemble_stage.layers.%d.projection", i);
+        ok = conv_m(m, p, xin, 1, ph, pw, (int)C, 1, 0, &oh, &ow, &co, &pr);
+        if (!ok) break;
+        snprintf(p, sizeof p, "neck.reassemble_stage.layers.%d.resize", i);
+        if (i == 0 || i == 1) {
+            int s = (i == 0) ? 4 : 2;
+            int64_t ne[4];
+            const float* wt = W(m, p, "weight", ne, 1); /* ne = [kw,kh,Cout,Cin] */
+            if (!wt) { free(pr); ok = 0; break; }
+            const float* b = W(m, p, "bias", NULL, 0);
+            int kw = (int)ne[0], kh = (int)ne[1], cout = (int)ne[2];
+            int OH = (ph - 1) * s + kh, OW = (pw - 1) * s + kw;
+            float* y = (float*)malloc((size_t)OH * OW * cout * 4);
+            vo_conv_transpose2d_nhwc(pr, 1, ph, pw, co, wt, b, cout, kh, kw, s, y);
+            free(pr);
+            layer[i] = y; lh[i] = OH; lw[i] = OW; lc[i] = cout;
+        } else if (i == 3) {
+            float* y = NULL;
+            ok = conv_m(m, p, pr, 1, ph, pw, co, 2, 1, &oh, &ow, &co, &y);
+            free(pr);
+            if (!ok) break;
+            layer[i] = y; lh[i] = oh; lw[i] = ow; lc[i] = co;
+        } else {
+            layer[i] = pr; lh[i] = ph; lw[i] = pw; lc[i] = co;
+        }
+        snprintf(cname, sizeof cname, "reassemble_%d", i);
+        capture(caps, ncap, cname, layer[i], (int64_t)lh[i] * lw[i] * lc[i]);
+    }
+    for (int f = 0; f < 4; ++f) free(feats[f]);
+    if (!ok) return 0;
+    for (int i = 0; i < 4; ++i) {
+        float* y = NULL;
+        snprintf(p, sizeof p, "neck.convs.%d", i);
+        if (!conv_m(m, p, layer[i], 1, lh[i], lw[i], lc[i], 1, 1, &oh, &ow, &co, &y)) return 0;
+        free(layer[i]);
+        layer[i] = y; lc[i] = co;
+        snprintf(cname, sizeof cname, "neck_conv_%d", i);
+        capture(caps, ncap, cname, y, (int64_t)lh[i] * lw[i] * co);
+    }
+    int FC = lc[0];
+    float* fused = NULL;
+    float* nxt = NULL;
+    /* fusion[0](layer3, null, size(layer2)) */
+    if (!feature_fusion(m, "neck.fusion_stage.layers.0", layer[3], NULL, lh[3], lw[3], FC, lh[2], lw[2], &fused)) return 0;
+    capture(caps, ncap, "fusion_0", fused, (int64_t)lh[2] * lw[2] * FC);
+    if (!feature_fusion(m, "neck.fusion_stage.layers.1", fused, layer[2], lh[2], lw[2], FC, lh[1], lw[1], &nxt)) return 0;
+    free(fused); fused = nxt;
+    capture(caps, ncap, "fusion_1", fused, (int64_t)lh[1] * lw[1] * FC);
+    if (!feature_fusion(m, "neck.fusion_stage.layers.2", fused, layer[1], lh[1], lw[1], FC, lh[0], lw[0], &nxt)) return 0;
+    free(fused); fused = nxt;
+    capture(caps, ncap, "fusion_2", fused, (int64_t)lh[0] * lw[0] * FC);
+    int fh = lh[0] * 2, fwd = lw[0] * 2;
+    if (!feature_fusion(m, "neck.fusion_stage.layers.3", fused, layer[0], lh[0], lw[0], FC, fh, fwd, &nxt)) return 0;
+    free(fused); fused = nxt;
+    capture(caps, ncap, "fusion_3", fused, (int64_t)fh * fwd * FC);
+    for (int i = 0; i < 4; ++i) free(layer[i]);
+
+    /* dpt::head (depth-anything.cpp:81-96) */
+    float* c1 = NULL;
+    if (!conv_m(m, "head.conv1", fused, 1, fh, fwd, FC, 1, 1, &oh, &ow, &co, &c1)) return 0;
+    free(fused);
+    capture(caps, ncap, "head_conv1", c1, (int64_t)oh * ow * co);
+    float* up = (float*)malloc((size_t)h * w * co * 4);
+    vo_interpolate_bilinear_nhwc(c1, 1, oh, ow, co, h, w, 1, up);
+    free(c1);
+    float* c2 = NULL;
+    int c2c;
+    if (!conv_m(m, "head.conv2", up, 1, h, w, co, 1, 1, &oh, &ow, &c2c, &c2)) return 0;
+    free(up);
+    relu_new(c2, c2, (int64_t)h * w * c2c);
+    float* c3 = NULL;
+    int c3c;
+    if (!conv_m(m, "head.conv3", c2, 1, h, w, c2c, 1, 0, &oh, &ow, &c3c, &c3)) return 0;
+    free(c2);
+    relu_new(c3, c3, (int64_t)h * w * c3c);
+    if (P->max_depth != 1.0f)
+        for (int64_t i = 0; i < (int64_t)h * w; ++i) c3[i] *= P->max_depth;
+    memcpy(out, c3, (size_t)h * w * 4);
+    capture(caps, ncap, "depth", c3, (int64_t)h * w);
+    free(c3);
+    return 1;
+}
+
+/* src/visp/vision.cpp:147-167 with image.extent == depthany_image_extent(image.extent) */
+int vo_depthany_compute(const vo_model* m, const vo_depthany_params* P, const uint8_t* rgb, int w, int h,
+                        float* out_normalized, float* out_raw) {
+    /* depthany_process_input (depth-anything.cpp:130-140) */
+    const float mean[4] = {0.485f, 0.456f, 0.406f, 0.0f};
+    const float std_[4] = {0.229f, 0.224f, 0.225f, 1.0f};
+    float offset[4], scale[4];
+    for (int c = 0; c < 4; ++c) { offset[c] = -mean[c]; scale[c] = 1.0f / std_[c]; }
+    float* img = (float*)malloc((size_t)w * h * 3 * 4);
+    if (!vo_image_u8_to_f32(rgb, w, h, w * 3, VO_RGB_U8, img, w, h, VO_RGB_F32, offset, scale, 0, 0)) { free(img); return 0; }
+    float* raw = out_raw ? out_raw : (float*)malloc((size_t)w * h * 4);
+    int ok = vo_depthany_predict(m, P, img, w, h, raw, NULL, 0);
+    free(img);
+    if (ok) vo_image_normalize(raw, out_normalized, w, h, 1, 0.0f, 1.0f); /* depthany_process_output :142-149 */
+    if (!out_raw) free(raw);
+    return ok;
+}

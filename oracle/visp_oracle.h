@@ -1,0 +1,144 @@
+/*
+ * visp_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C f32 restatement of what the reference's ggml CPU backend computes on the
+ * Depth-Anything-V2 hot path: f16 weights widened to f32 at load
+ * (reference src/visp/ml.cpp:115-135, 449-516), CWHN (=NHWC) layout, f32 arithmetic,
+ * tanh-GELU through an fp16 look-up table (docs/model-implementation-guide.md:284-288).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library. The product (vision.cpp_amd/csrc) never links, includes or calls it.
+ *
+ * PINNING: the reference's own implementation (C++ on the un-vendored ggml submodule)
+ * cannot be compiled in this environment, and it ships no DINO/DPT module tests.
+ * The oracle is pinned (tests/test_oracle_*.py) against
+ *   - every literal vector the reference's tests hold for this path
+ *     (tests/test-image.cpp:62-184,283-301; tests/test-ml.cpp:18-103),
+ *   - the torch functionals the reference's tests/test_primitives.py pins ggml ops to
+ *     (linear, layer_norm, interpolate, conv_transpose2d), fixtures in tests/golden/,
+ *   - HuggingFace transformers' DepthAnythingForDepthEstimation (the model whose
+ *     state-dict names the reference's GGUF uses verbatim, scripts/convert.py:428-475).
+ * Whole-path parity against the reference *binary* stays unpinned (no ggml, no GGUF).
+ */
+#ifndef VISP_ORACLE_H
+#define VISP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ggml type ids used by the reference's files (tests/workbench.py:14-19) */
+enum { VO_F32 = 0, VO_F16 = 1, VO_I32 = 26 };
+/* visp::image_format (include/visp/image.h:17-29) */
+enum {
+    VO_RGBA_U8 = 0, VO_BGRA_U8, VO_ARGB_U8, VO_RGB_U8, VO_ALPHA_U8,
+    VO_RGBA_F32, VO_RGB_F32, VO_ALPHA_F32
+};
+enum { VO_LAYOUT_UNKNOWN = 0, VO_LAYOUT_WHCN = 1, VO_LAYOUT_CWHN = 2 };
+enum { VO_GELU_GGML_F16_LUT = 0, VO_GELU_TANH_F32 = 1, VO_GELU_ERF_F32 = 2 };
+
+/* A tensor as it sits in a GGUF file: ne[0] is the contiguous axis (ggml order). */
+typedef struct {
+    const char* name;
+    const void* data;
+    int32_t type;
+    int64_t ne[4];
+} vo_tensor;
+
+typedef struct {
+    int patch_size, embed_dim, n_layers, n_heads; /* dino_params, vision.h:124-129 */
+    int image_size, image_multiple;               /* depthany_params, vision.h:236-243 */
+    int feature_layers[4];
+    float max_depth;
+    int gelu_mode;
+} vo_depthany_params;
+
+typedef struct vo_model vo_model;
+
+/* Named intermediate capture (the reference workbench's capture idea, tests/workbench.cpp:754-760). */
+typedef struct {
+    const char* name;
+    float* dst;
+    int64_t capacity; /* in floats */
+    int64_t written;  /* out: number of floats produced (may exceed capacity: nothing copied then) */
+} vo_capture;
+
+int vo_num_threads(void);
+void vo_set_num_threads(int n);
+
+/* ---- scalar conversions ------------------------------------------------------------ */
+void vo_f16_to_f32(const uint16_t* src, float* dst, int64_t n);
+void vo_f32_to_f16(const float* src, uint16_t* dst, int64_t n);
+
+/* ---- image ops (src/visp/image.cpp) -------------------------------------------------- */
+/* image.cpp:215-255 + image-impl.h:17-34: dst = (src/255 + offset) * scale, clamped tile reads */
+int vo_image_u8_to_f32(const uint8_t* src, int sw, int sh, int sstride, int sformat,
+                       float* dst, int dw, int dh, int dformat,
+                       const float offset[4], const float scale[4], int tile_x, int tile_y);
+/* image.cpp:257-288 + image-impl.h:36-43: uint8(clamp(v*scale+offset,0,1)*255) */
+int vo_image_f32_to_u8(const float* src, int w, int h, int sformat, uint8_t* dst, int dformat,
+                       float scale, float offset);
+/* image.cpp:537-576 */
+void vo_image_normalize(const float* src, float* dst, int w, int h, int channels, float mn, float mx);
+/* depth-anything.cpp:112-117 */
+void vo_depthany_image_extent(int w, int h, int image_size, int image_multiple, int* ow, int* oh);
+
+/* ---- weight transfer (src/visp/ml.cpp:331-340, 449-516) ------------------------------- */
+/* Converts one tensor to f32 and, if whcn_to_cwhn, permutes a conv2d kernel
+ * [kw,kh,Cin,Cout] -> [Cin,kw,kh,Cout] (depthwise [kw,kh,1,C] -> [C,1,kw,kh]).
+ * out_ne receives the permuted shape. dst must hold nelements floats (int32 copied raw). */
+int vo_transfer_tensor(const vo_tensor* src, int whcn_to_cwhn, void* dst, int64_t out_ne[4]);
+
+/* ---- primitives (src/visp/nn.cpp; semantics in SURVEY Appendix A) ---------------------- */
+void vo_linear(const float* x, int64_t M, int64_t K, const float* w /*[N][K]*/, const float* b,
+               int64_t N, float* y);
+void vo_layer_norm(const float* x, int64_t M, int64_t C, const float* w, const float* b, float eps,
+                   float* y);
+void vo_gelu(const float* x, float* y, int64_t n, int mode);
+/* q,k,v: [N][H*hd] (head h at column h*hd), out [N][H*hd]; softmax(q k^T * scale) v */
+void vo_attention(const float* q, const float* k, const float* v, int64_t N, int H, int hd,
+                  float scale, float* out);
+/* NHWC conv, weight [Cout][kh][kw][Cin] (cwhn after transfer), cross-correlation */
+void vo_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias,
+                    int Cout, int kh, int kw, int stride, int pad, float* y);
+/* torch conv_transpose2d(padding=0); weight torch [Cin][Cout][kh][kw] == ggml ne [kw,kh,Cout,Cin] */
+void vo_conv_transpose2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w,
+                              const float* bias, int Cout, int kh, int kw, int stride, float* y);
+/* ggml_interpolate BILINEAR (|ALIGN_CORNERS) on NHWC data */
+void vo_interpolate_bilinear_nhwc(const float* x, int B, int H, int W, int C, int OH, int OW,
+                                  int align_corners, float* y);
+/* ggml_interpolate BICUBIC (a = -0.75, torch semantics) on NHWC data */
+void vo_interpolate_bicubic_nhwc(const float* x, int B, int H, int W, int C, int OH, int OW,
+                                 int align_corners, float* y);
+
+/* ---- model --------------------------------------------------------------------------- */
+/* Mirrors model_transfer(file, weights, cpu-device, F32, cwhn): every float tensor -> f32,
+ * tensors whose index is listed in conv2d_idx are permuted when src_layout is whcn. */
+vo_model* vo_model_create(const vo_tensor* tensors, int n_tensors, const int32_t* conv2d_idx,
+                          int n_conv2d, int src_layout);
+void vo_model_destroy(vo_model*);
+int vo_model_n_tensors(const vo_model*);
+/* returns f32 data and shape (post-transfer) or NULL */
+const float* vo_model_tensor(const vo_model*, const char* name, int64_t ne[4]);
+const char* vo_last_error(void);
+
+/* depthany_predict (depth-anything.cpp:100-110): image = normalised rgb_f32 [h][w][3],
+ * w,h multiples of patch_size; out = raw depth [h][w] (before image_normalize). */
+int vo_depthany_predict(const vo_model*, const vo_depthany_params*, const float* image, int w, int h,
+                        float* out, vo_capture* captures, int n_captures);
+
+/* depthany_compute (vision.cpp:147-167) for an rgb_u8 image whose extent already equals
+ * depthany_image_extent(extent): process_input, predict, process_output (min-max to [0,1]). */
+int vo_depthany_compute(const vo_model*, const vo_depthany_params*, const uint8_t* rgb, int w, int h,
+                        float* out_normalized, float* out_raw /*nullable*/);
+
+/* dino building blocks, exposed for module-level parity tests */
+int vo_dino_layer(const vo_model*, const char* prefix, int n_heads, int gelu_mode, float* x /*[N][C] in/out*/,
+                  int64_t N, int64_t C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,243 @@
+"""Pins the CPU oracle (oracle/) against
+  * the literal vectors the reference's C++ tests hold for this path
+    (tests/test-image.cpp:62-184, 283-301; tests/test-ml.cpp:18-103), restated here as data;
+  * torch functionals, with the inputs the reference's tests/test_primitives.py uses to pin
+    ggml's ops (fixtures: tests/golden/ops.npz);
+  * HuggingFace transformers' Depth-Anything (fixtures: tests/golden/depthany_*.npz).
+Tolerances follow the reference's tensors_match default (rtol 1e-3, atol 1e-5,
+tests/workbench.py:376-391) unless a test states a tighter one.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from visioncpp_amd import synth
+
+RTOL, ATOL = 1e-3, 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    return np.load(golden_dir / "ops.npz")
+
+
+# ---- literal vectors from the reference's tests/test-image.cpp ------------------------------
+
+OFFSET, SCALE = (0.1, 0.2, 0.3, 0.4), (0.5, 1.0, -1.0, 1.0)
+RGB_EXPECTED = [0.05, 0.7, -1.05, 0.55, 0.2, -0.8, 0.3, 1.2, -0.3, 0.3, 0.45, -1.3]
+
+
+@pytest.mark.parametrize("sfmt,dfmt,data,expected", [
+    (oracle.ALPHA_U8, oracle.ALPHA_F32, [0, 128, 190, 255], [0.05, 0.3, 0.4225, 0.55]),
+    (oracle.RGB_U8, oracle.RGB_F32, [0, 128, 192, 255, 0, 128, 128, 255, 0, 128, 64, 255], RGB_EXPECTED),
+    (oracle.RGBA_U8, oracle.RGB_F32, [0, 128, 192, 42, 255, 0, 128, 42, 128, 255, 0, 42, 128, 64, 255, 42], RGB_EXPECTED),
+    (oracle.RGBA_U8, oracle.RGBA_F32, [0, 128, 192, 0, 255, 0, 128, 64, 128, 255, 0, 128, 128, 64, 255, 255],
+     [0.05, 0.7, -1.05, 0.4, 0.55, 0.2, -0.8, 0.65, 0.3, 1.2, -0.3, 0.9, 0.3, 0.45, -1.3, 1.4]),
+    (oracle.BGRA_U8, oracle.RGB_F32, [192, 128, 0, 42, 128, 0, 255, 42, 0, 255, 128, 42, 255, 64, 128, 42], RGB_EXPECTED),
+    (oracle.ARGB_U8, oracle.RGB_F32, [42, 0, 128, 192, 42, 255, 0, 128, 42, 128, 255, 0, 42, 128, 64, 255], RGB_EXPECTED),
+])
+def test_image_u8_to_f32_reference_vectors(sfmt, dfmt, data, expected):
+    ch = len(data) // 4
+    src = np.array(data, np.uint8).reshape(2, 2, ch)
+    out = oracle.image_u8_to_f32(src, sfmt, dfmt, OFFSET, SCALE)
+    np.testing.assert_allclose(out.ravel(), expected, atol=0.01)  # test_with_tolerance{0.01}
+
+
+def test_image_u8_to_f32_tiled_pad():
+    src = np.array([0, 0, 102, 0, 0, 255, 0, 0, 102], np.uint8).reshape(3, 3, 1)
+    out = oracle.image_u8_to_f32(src, oracle.ALPHA_U8, oracle.ALPHA_F32, dst_extent=(2, 2), tile_offset=(2, 1))
+    np.testing.assert_allclose(out.ravel(), [1.0, 1.0, 0.4, 0.4], atol=1e-6)
+
+
+def test_image_f32_to_u8_reference_vectors():
+    a = np.array([0.0, 0.3, 0.4225, 1.1], np.float32).reshape(2, 2, 1)
+    assert oracle.image_f32_to_u8(a, oracle.ALPHA_F32, oracle.ALPHA_U8).ravel().tolist() == [0, 76, 107, 255]
+    b = np.array([0.0, 0.31, -0.51, 1.0, 0.2, 1.8], np.float32).reshape(1, 2, 3)
+    assert oracle.image_f32_to_u8(b, oracle.RGB_F32, oracle.RGBA_U8).ravel().tolist() == [0, 79, 0, 255, 255, 51, 255, 255]
+
+
+def test_image_normalize_reference_vectors():
+    a = np.array([[-1.0, 4.2, 0.5], [5.0, 4.2, 0.0], [-5.0, 4.2, 0.6], [1.0, 4.2, 1.0]], np.float32).reshape(2, 2, 3)
+    e = np.array([[0.4, 0.0, 0.5], [1.0, 0.0, 0.0], [0.0, 0.0, 0.6], [0.6, 0.0, 1.0]], np.float32).reshape(2, 2, 3)
+    np.testing.assert_allclose(oracle.image_normalize(a), e, atol=1e-6)
+
+
+# ---- literal vectors from the reference's tests/test-ml.cpp ---------------------------------
+
+def test_transfer_type_conversion():
+    assert oracle.transfer_tensor(np.array([4, -1], np.int32), False).ravel().tolist() == [4, -1]
+    assert oracle.transfer_tensor(np.array([2.5, -0.5], np.float16), False).ravel().tolist() == [2.5, -0.5]
+
+
+def test_transfer_layout_conversion():
+    dw = np.arange(1, 13, dtype=np.float32).reshape(3, 1, 2, 2)  # ggml ne [2,2,1,3] wh1c
+    out = oracle.transfer_tensor(dw, True)
+    assert out.ravel().tolist() == [1, 5, 9, 2, 6, 10, 3, 7, 11, 4, 8, 12]
+    conv = np.arange(1, 49, dtype=np.float32).reshape(3, 4, 2, 2)  # ggml ne [2,2,4,3] whco
+    out = oracle.transfer_tensor(conv, True)
+    expected = [1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15, 4, 8, 12, 16,
+                17, 21, 25, 29, 18, 22, 26, 30, 19, 23, 27, 31, 20, 24, 28, 32,
+                33, 37, 41, 45, 34, 38, 42, 46, 35, 39, 43, 47, 36, 40, 44, 48]
+    assert out.ravel().tolist() == expected
+    assert out.shape == (3, 2, 2, 4)  # [Cout, kh, kw, Cin]
+    assert oracle.transfer_tensor(np.array([1, 2], np.float32), False).ravel().tolist() == [1, 2]
+
+
+def test_image_extent():  # depth-anything.cpp:112-117; SURVEY section 8a row a3
+    assert oracle.depthany_image_extent(518, 518) == (518, 518)
+    assert oracle.depthany_image_extent(640, 480) == (700, 518)
+    assert oracle.depthany_image_extent(64, 64) == (518, 518)
+    assert oracle.depthany_image_extent(1024, 768) == (1036, 770)
+
+
+def test_f16_roundtrip_all_values():
+    bits = np.arange(65536, dtype=np.uint16)
+    f = oracle.f16_to_f32(bits.view(np.float16))
+    ref = bits.view(np.float16).astype(np.float32)
+    np.testing.assert_array_equal(f[~np.isnan(ref)], ref[~np.isnan(ref)])
+    back = oracle.f32_to_f16(f).view(np.uint16)
+    ok = ~np.isnan(ref)
+    np.testing.assert_array_equal(back[ok], bits[ok])
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(100000).astype(np.float32) * s for s in (1e-8, 1e-4, 1, 1e3, 1e5)])
+    np.testing.assert_array_equal(oracle.f32_to_f16(x).view(np.uint16), x.astype(np.float16).view(np.uint16))
+
+
+# ---- ops pinned to torch functionals ---------------------------------------------------------
+
+def test_linear(ops):
+    y = oracle.linear(ops["linear_x"], ops["linear_w"], ops["linear_b"])
+    np.testing.assert_allclose(y, ops["linear_y"], rtol=RTOL, atol=ATOL)
+
+
+def test_layer_norm(ops):
+    np.testing.assert_allclose(oracle.layer_norm(ops["ln_x"], ops["ln_w"], ops["ln_b"], 1e-5), ops["ln_y_1e5"], atol=1e-6)
+    np.testing.assert_allclose(oracle.layer_norm(ops["ln_x"], ops["ln_w"], ops["ln_b"], 1e-6), ops["ln_y_1e6"], atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+@pytest.mark.parametrize("align", [1, 0])
+@pytest.mark.parametrize("size", ["one", "small", "large"])
+@pytest.mark.parametrize("scale", [0.6, 2.0])
+def test_interpolate(ops, mode, align, size, scale):
+    b, c, h, w = {"one": (1, 2, 1, 3), "small": (1, 3, 2, 3), "large": (4, 19, 20, 30)}[size]
+    x = np.arange(b * c * h * w, dtype=np.float32).reshape(b, c, h, w)
+    want = ops[f"interp_{size}_{scale}_{mode}_{align}"]
+    got = oracle.interpolate_nhwc(x.transpose(0, 2, 3, 1), want.shape[2:], mode, bool(align)).transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-3 if size == "large" else ATOL)
+
+
+@pytest.mark.parametrize("name,k,s", [("3x3", 3, 1), ("5x5", 5, 1), ("stride2", 3, 2)])
+def test_conv_transpose_reference_cases(ops, name, k, s):
+    x = (np.arange(2 * 11 * 4 * 5, dtype=np.float32) / (2 * 11 * 4 * 5)).reshape(2, 11, 4, 5)
+    w = (np.arange(11 * 2 * k * k, dtype=np.float32) / (11 * 2 * k * k)).reshape(11, 2, k, k)
+    got = oracle.conv_transpose2d_nhwc(x.transpose(0, 2, 3, 1), w, None, s).transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(got, ops[f"convT_{name}"], rtol=1e-2, atol=ATOL)  # reference uses rtol 1e-2
+
+
+@pytest.mark.parametrize("name,k", [("k4s4", 4), ("k2s2", 2)])
+def test_conv_transpose_path_shapes(ops, name, k):
+    x, w, b = ops[f"convT_{name}_x"], ops[f"convT_{name}_w"], ops[f"convT_{name}_b"]
+    got = oracle.conv_transpose2d_nhwc(x.transpose(0, 2, 3, 1), w, b, k).transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(got, ops[f"convT_{name}_y"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("name,s,p", [("3x3", 1, 1), ("3x3s2", 2, 1), ("1x1", 1, 0), ("patch", 14, 0)])
+def test_conv2d(ops, name, s, p):
+    x, w, b = ops[f"conv_{name}_x"], ops[f"conv_{name}_w"], ops[f"conv_{name}_b"]
+    got = oracle.conv2d_nhwc(x.transpose(0, 2, 3, 1), w.transpose(0, 2, 3, 1), b, s, p).transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(got, ops[f"conv_{name}_y"], rtol=RTOL, atol=ATOL)
+
+
+def test_attention(ops):
+    got = oracle.attention(ops["attn_q"], ops["attn_k"], ops["attn_v"], 2, 1.0 / np.sqrt(8.0))
+    np.testing.assert_allclose(got, ops["attn_o"], rtol=RTOL, atol=ATOL)
+
+
+def test_gelu(ops):
+    x, want = ops["gelu_x"], ops["gelu_tanh"]
+    np.testing.assert_allclose(oracle.gelu(x, oracle.GELU_TANH_F32), want, rtol=1e-5, atol=1e-6)
+    # ggml's fp16 table: input and output both rounded to f16 -> ~2^-11 relative
+    lut = oracle.gelu(x, oracle.GELU_GGML_F16_LUT)
+    np.testing.assert_allclose(lut, want, rtol=2e-3, atol=2e-3)
+    assert np.abs(lut - want).max() > 0  # the table really is coarser than f32
+
+
+# ---- whole model pinned to HuggingFace transformers -------------------------------------------
+
+def _sha(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.astype(np.float16)).tobytes())
+    return h.hexdigest()
+
+
+def _oracle_model(cfg, seed):
+    sd = synth.state_dict(cfg, seed)
+    tensors, conv2d = synth.gguf_tensors(sd)
+    return sd, oracle.Model(tensors, conv2d, "whcn")
+
+
+def _params(cfg, gelu):
+    return oracle.make_params(cfg.patch_size, cfg.embed_dim, cfg.n_layers, cfg.n_heads, cfg.image_size, 14,
+                              cfg.feature_layers, 1.0, gelu)
+
+
+def _pre(img):
+    return oracle.image_u8_to_f32(img, oracle.RGB_U8, oracle.RGB_F32, (-0.485, -0.456, -0.406, 0),
+                                  (1 / 0.229, 1 / 0.224, 1 / 0.225, 1))
+
+
+def test_depthany_tiny_every_module_boundary(golden_dir):
+    g = np.load(golden_dir / "depthany_tiny.npz")
+    cfg = synth.TINY
+    sd, om = _oracle_model(cfg, int(g["weights_seed"]))
+    assert _sha(sd) == bytes(g["sd_sha256"]).decode(), "synthetic weights drifted from the fixture"
+    img = synth.images(1, 70, 70, seed=int(g["image_seed"]))[0]
+    names = [k for k in g.files if k not in ("image_seed", "weights_seed", "extent", "sd_sha256", "depth")]
+    caps = {k: int(g[k].size) for k in names}
+    depth, got = om.predict(_params(cfg, oracle.GELU_TANH_F32), _pre(img), caps)
+    for k in names:
+        np.testing.assert_allclose(got[k].reshape(g[k].shape), g[k], rtol=RTOL, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(depth, g["depth"], rtol=RTOL, atol=2e-5)
+    # ggml's fp16-LUT GELU (what the reference CPU backend runs) stays within fp16 noise of that
+    depth_lut = om.predict(_params(cfg, oracle.GELU_GGML_F16_LUT), _pre(img))
+    assert np.abs(depth_lut - g["depth"]).max() < 2e-2 * np.abs(g["depth"]).max()
+
+
+def test_depthany_mini(golden_dir):
+    g = np.load(golden_dir / "depthany_mini.npz")
+    cfg = synth.MINI
+    sd, om = _oracle_model(cfg, int(g["weights_seed"]))
+    assert _sha(sd) == bytes(g["sd_sha256"]).decode()
+    img = synth.images(1, 112, 112, seed=int(g["image_seed"]))[0]
+    depth = om.predict(_params(cfg, oracle.GELU_TANH_F32), _pre(img))
+    np.testing.assert_allclose(depth, g["depth_sample"], rtol=RTOL, atol=5e-5)
+
+
+def test_depthany_small_518(golden_dir):
+    """The north-star configuration: Depth-Anything-V2-Small at 518x518 (one image)."""
+    g = np.load(golden_dir / "depthany_small.npz")
+    cfg = synth.SMALL
+    sd, om = _oracle_model(cfg, int(g["weights_seed"]))
+    assert _sha(sd) == bytes(g["sd_sha256"]).decode()
+    img = synth.images(1, 518, 518, seed=int(g["image_seed"]))[0]
+    caps = {"tokens": 1370 * 384, "fusion_3": 296 * 296 * 64, "head_conv1": 296 * 296 * 32}
+    for li in cfg.feature_layers:
+        caps[f"layer_{li}"] = 1370 * 384
+    depth, got = om.predict(_params(cfg, oracle.GELU_TANH_F32), _pre(img), caps)
+    np.testing.assert_allclose(got["tokens"].reshape(1370, 384)[::37, ::8], g["tokens_sample"], rtol=RTOL, atol=2e-5)
+    for li in cfg.feature_layers:
+        np.testing.assert_allclose(got[f"layer_{li}"].reshape(1370, 384)[::37, ::8], g[f"layer_{li}_sample"],
+                                   rtol=RTOL, atol=2e-4, err_msg=f"layer_{li}")
+    np.testing.assert_allclose(got["fusion_3"].reshape(296, 296, 64)[::8, ::8, ::4], g["fusion_3_sample"], rtol=RTOL, atol=5e-4)
+    np.testing.assert_allclose(got["head_conv1"].reshape(296, 296, 32)[::8, ::8, ::4], g["head_conv1_sample"], rtol=RTOL, atol=5e-4)
+    np.testing.assert_allclose(depth[::7, ::7], g["depth_sample"], rtol=RTOL, atol=5e-4)
+    st = g["depth_stats"]
+    np.testing.assert_allclose([depth.min(), depth.max(), depth.mean(), depth.std()], st, rtol=1e-3)
+    # normalised output (what depthany_compute returns): MAE far below the 1e-3 north-star bar
+    norm = oracle.image_normalize(depth)
+    assert 0.0 <= norm.min() and norm.max() <= 1.0 + 1e-6

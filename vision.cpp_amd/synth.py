@@ -1,0 +1,179 @@
+"""Synthetic Depth-Anything-V2 checkpoints and inputs (no network: random-init weights).
+
+`state_dict()` produces tensors with the HuggingFace `transformers` names and torch shapes
+(SURVEY.md Appendix C), in state-dict order. `write_gguf()` applies exactly the on-disk
+contract of the reference's scripts/convert.py:428-475 (convert_depth_anything with
+`--quantize f16`, default layout): patch-embed and reassemble projections stored NHWC,
+ConvTranspose kernels untouched, every other conv kernel left OIHW and listed in
+`depthanything.conv2d_weights`, cls/pos embeddings kept f32, everything else f16.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+from .gguf import GGUFWriter
+
+
+@dataclass
+class Config:
+    embed_dim: int = 384
+    n_layers: int = 12
+    n_heads: int = 6
+    patch_size: int = 14
+    image_size: int = 518  # pos-embed grid = (image_size / patch_size)^2
+    mlp_ratio: int = 4
+    neck_sizes: tuple = (48, 96, 192, 384)
+    fusion_size: int = 64
+    head_size: int = 32
+    feature_layers: tuple = (2, 5, 8, 11)
+    name: str = "small"
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+
+SMALL = Config()
+# tiny config for fast CPU parity runs: 5x5 patches, 2 heads x 16
+TINY = Config(embed_dim=32, n_layers=4, n_heads=2, image_size=70, neck_sizes=(8, 16, 32, 32), fusion_size=16,
+              head_size=8, feature_layers=(0, 1, 2, 3), name="tiny")
+# "mini": real head_dim 64 and 2 heads, 8x8 patches; exercises the same kernels as SMALL at 1/100 the cost
+MINI = Config(embed_dim=128, n_layers=4, n_heads=2, image_size=112, neck_sizes=(48, 96, 192, 384),
+              fusion_size=64, head_size=32, feature_layers=(0, 1, 2, 3), name="mini")
+
+
+def state_dict(cfg: Config = SMALL, seed: int = 0) -> dict[str, np.ndarray]:
+    """float32 tensors, HF names, torch shapes, HF state-dict order."""
+    rng = np.random.default_rng(seed)
+    D, Hd = cfg.embed_dim, cfg.embed_dim * cfg.mlp_ratio
+    sd: dict[str, np.ndarray] = {}
+
+    def normal(shape, std):
+        return (rng.standard_normal(shape) * std).astype(np.float32)
+
+    def lin(name, out_f, in_f, gain=1.0):
+        sd[f"{name}.weight"] = normal((out_f, in_f), gain / np.sqrt(in_f))
+        sd[f"{name}.bias"] = normal((out_f,), 0.02)
+
+    def conv(name, out_c, in_c, k, bias=True, gain=1.0):
+        sd[f"{name}.weight"] = normal((out_c, in_c, k, k), gain / np.sqrt(in_c * k * k))
+        if bias:
+            sd[f"{name}.bias"] = normal((out_c,), 0.02)
+
+    def norm(name):
+        sd[f"{name}.weight"] = (1.0 + rng.standard_normal(D) * 0.05).astype(np.float32)
+        sd[f"{name}.bias"] = normal((D,), 0.02)
+
+    e = "backbone.embeddings"
+    sd[f"{e}.cls_token"] = normal((1, 1, D), 0.5)
+    sd[f"{e}.mask_token"] = np.zeros((1, D), np.float32)
+    sd[f"{e}.position_embeddings"] = normal((1, cfg.grid * cfg.grid + 1, D), 0.5)
+    conv(f"{e}.patch_embeddings.projection", D, 3, cfg.patch_size, gain=1.0)
+    for i in range(cfg.n_layers):
+        p = f"backbone.encoder.layer.{i}"
+        norm(f"{p}.norm1")
+        lin(f"{p}.attention.attention.query", D, D, gain=1.5)
+        lin(f"{p}.attention.attention.key", D, D, gain=1.5)
+        lin(f"{p}.attention.attention.value", D, D)
+        lin(f"{p}.attention.output.dense", D, D)
+        sd[f"{p}.layer_scale1.lambda1"] = (0.3 + rng.standard_normal(D) * 0.05).astype(np.float32)
+        norm(f"{p}.norm2")
+        lin(f"{p}.mlp.fc1", Hd, D, gain=1.4)
+        lin(f"{p}.mlp.fc2", D, Hd, gain=1.4)
+        sd[f"{p}.layer_scale2.lambda1"] = (0.3 + rng.standard_normal(D) * 0.05).astype(np.float32)
+    norm("backbone.layernorm")
+
+    r = "neck.reassemble_stage.layers"
+    for i, c in enumerate(cfg.neck_sizes):
+        conv(f"{r}.{i}.projection", c, D, 1)
+        if i == 0:  # ConvTranspose2d(c, c, 4, stride 4): weight [Cin, Cout, 4, 4]
+            sd[f"{r}.{i}.resize.weight"] = normal((c, c, 4, 4), 1.0 / np.sqrt(c))
+            sd[f"{r}.{i}.resize.bias"] = normal((c,), 0.02)
+        elif i == 1:  # ConvTranspose2d(c, c, 2, stride 2)
+            sd[f"{r}.{i}.resize.weight"] = normal((c, c, 2, 2), 1.0 / np.sqrt(c))
+            sd[f"{r}.{i}.resize.bias"] = normal((c,), 0.02)
+        elif i == 3:  # Conv2d(c, c, 3, stride 2, pad 1)
+            conv(f"{r}.{i}.resize", c, c, 3)
+    F = cfg.fusion_size
+    for i, c in enumerate(cfg.neck_sizes):
+        conv(f"neck.convs.{i}", F, c, 3, bias=False)
+    for i in range(4):
+        p = f"neck.fusion_stage.layers.{i}"
+        conv(f"{p}.projection", F, F, 1)
+        for rl in ("residual_layer1", "residual_layer2"):
+            conv(f"{p}.{rl}.convolution1", F, F, 3, gain=1.2)
+            conv(f"{p}.{rl}.convolution2", F, F, 3, gain=0.7)
+    conv("head.conv1", cfg.head_size, F, 3)
+    conv("head.conv2", cfg.head_size, cfg.head_size, 3, gain=1.4)
+    conv("head.conv3", 1, cfg.head_size, 1, gain=1.0)
+    # non-negative 1x1 weights + positive bias: the final ReLU stays active, so the min-max
+    # normalised depth map is well conditioned (a real checkpoint behaves the same way)
+    sd["head.conv3.weight"] = np.abs(sd["head.conv3.weight"])
+    sd["head.conv3.bias"] = np.array([0.1], np.float32)
+    return sd
+
+
+def _is_conv_2d(name: str, t: np.ndarray) -> bool:  # scripts/convert.py:111-117
+    return t.ndim == 4 and t.shape[2] == t.shape[3] and t.shape[2] in (1, 3, 4, 7, 14) and name.endswith("weight")
+
+
+def gguf_tensors(sd: dict[str, np.ndarray]):
+    """Applies convert_depth_anything's per-tensor rules (scripts/convert.py:460-475).
+
+    Returns (ordered dict name -> array as stored, conv2d_weights index list)."""
+    out: dict[str, np.ndarray] = {}
+    conv2d: list[int] = []
+    for name, t in sd.items():
+        if _is_conv_2d(name, t):
+            if "patch_embeddings" in name or ("projection" in name and "fusion" not in name):
+                t = np.ascontiguousarray(t.transpose(0, 2, 3, 1))  # conv_2d_to_nhwc: Cout H W Cin
+            elif "0.resize" in name or "1.resize" in name:
+                pass  # ConvTranspose2d, layout untouched
+            else:
+                conv2d.append(len(out))  # Writer.convert_tensor_2d with layout nchw
+        if "position_embeddings" in name or "cls_token" in name:
+            out[name] = t.astype(np.float32)
+        else:
+            out[name] = t.astype(np.float16)
+    return out, conv2d
+
+
+def write_gguf(path: str | Path, cfg: Config = SMALL, seed: int = 0, sd: dict[str, np.ndarray] | None = None) -> Path:
+    sd = sd if sd is not None else state_dict(cfg, seed)
+    tensors, conv2d = gguf_tensors(sd)
+    w = GGUFWriter(path, "depthanything")
+    w.add_string("depthanything.tensor_data_layout", "whcn")  # set_tensor_layout_default(nchw)
+    w.add_int32("dino.patch_size", cfg.patch_size)
+    w.add_int32("dino.embed_dim", cfg.embed_dim)
+    w.add_int32("depthanything.image_size", cfg.image_size)
+    w.add_int32("dino.n_heads", cfg.n_heads)
+    w.add_int32("dino.n_layers", cfg.n_layers)
+    w.add_array_i32("depthanything.feature_layers", cfg.feature_layers)
+    w.add_uint32("general.quantization_version", 2)
+    w.add_uint32("general.file_type", 1)  # f16
+    w.add_array_i32("depthanything.conv2d_weights", conv2d)
+    for name, t in tensors.items():
+        w.add_tensor(name, t)
+    w.write()
+    return Path(path)
+
+
+def images(n: int, w: int = 518, h: int = 518, seed: int = 1234) -> np.ndarray:
+    """n synthetic rgb_u8 images [n, h, w, 3]: low-frequency structure + noise, so that the
+    min-max normalised depth output is well conditioned."""
+    out = np.empty((n, h, w, 3), np.uint8)
+    yy, xx = np.meshgrid(np.linspace(0, 1, h, dtype=np.float32), np.linspace(0, 1, w, dtype=np.float32), indexing="ij")
+    for i in range(n):
+        rng = np.random.default_rng(seed + i)
+        img = np.zeros((h, w, 3), np.float32)
+        for c in range(3):
+            for _ in range(4):
+                fx, fy = rng.uniform(0.5, 4.0, 2)
+                ph = rng.uniform(0, 2 * np.pi, 2)
+                img[..., c] += rng.uniform(0.1, 0.3) * np.sin(2 * np.pi * fx * xx + ph[0]) * np.cos(2 * np.pi * fy * yy + ph[1])
+        img = 0.5 + img + rng.uniform(-0.08, 0.08, img.shape).astype(np.float32)
+        out[i] = np.clip(img * 255.0, 0, 255).astype(np.uint8)
+    return out
