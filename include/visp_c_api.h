@@ -1,0 +1,124 @@
+/*
+ * visp_c_api.h -- the drop-in C ABI of the MI355X backend (lib/libvisioncpp.so).
+ *
+ * Part 1 re-exports, with identical names, signatures and semantics, the 11 symbols of the
+ * reference's C API (reference src/visp/c-api.cpp:145-253), i.e. exactly what the reference's
+ * ctypes binding (bindings/python/visioncpp/_lib.py:118-171) binds. Return value 1 = ok,
+ * 0 = error with the message available from visp_get_last_error() (thread-local,
+ * c-api.cpp:6-21). Only the Depth-Anything family is implemented behind it; the other
+ * families return an error ("not built in this backend").
+ *
+ * Part 2 is the batched, device-resident extension the reference does not have (its
+ * depthany_compute is batch 1, src/visp/vision.cpp:155): it is what bench.py and a
+ * data-parallel caller use.
+ */
+#ifndef VISP_C_API_H
+#define VISP_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VISP_API __attribute__((visibility("default")))
+
+/* visp::image_format, include/visp/image.h:17-29 */
+enum visp_image_format {
+    VISP_RGBA_U8 = 0, VISP_BGRA_U8, VISP_ARGB_U8, VISP_RGB_U8, VISP_ALPHA_U8,
+    VISP_RGBA_F32, VISP_RGB_F32, VISP_ALPHA_F32
+};
+/* visp::backend_type, include/visp/ml.h:32-36 */
+enum visp_backend_type { VISP_BACKEND_AUTO = 0, VISP_BACKEND_CPU = 1, VISP_BACKEND_GPU = 2, VISP_BACKEND_VULKAN = 258 };
+/* visp::model_family, include/visp/vision.h:86-94 */
+enum visp_model_family { VISP_SAM = 0, VISP_BIREFNET, VISP_DEPTH_ANYTHING, VISP_MIGAN, VISP_ESRGAN, VISP_FAMILY_COUNT };
+
+/* == visp::image_view {i32x2 extent; int stride; image_format format; void const* data}
+ * (include/visp/image.h:37-41) == c-api.cpp:121-127 visp_image_view == _lib.py:36-43 ImageView */
+typedef struct visp_image_view {
+    int32_t width;
+    int32_t height;
+    int32_t stride; /* bytes per row */
+    int32_t format;
+    void* data;
+} visp_image_view;
+
+typedef struct visp_image_data visp_image_data; /* visp::image_data, owned by the library */
+typedef struct visp_device visp_device;         /* visp::backend_device */
+typedef struct visp_model visp_model;           /* any_model (c-api.cpp:193) */
+
+/* ---- Part 1: the reference's symbols ------------------------------------------------- */
+VISP_API char const* visp_get_last_error(void);                                   /* c-api.cpp:147 */
+VISP_API void visp_image_destroy(visp_image_data* img);                           /* :153 */
+VISP_API int32_t visp_backend_load_all(char const* dir);                          /* :159 (no-op here: returns 1 backend) */
+VISP_API int32_t visp_device_init(int32_t type, visp_device** out_device);        /* :164 */
+VISP_API void visp_device_destroy(visp_device* d);                                /* :174 */
+VISP_API int32_t visp_device_type(visp_device const* d);                          /* :178 */
+VISP_API char const* visp_device_name(visp_device const* d);                      /* :182 */
+VISP_API char const* visp_device_description(visp_device const* d);               /* :188 */
+VISP_API int32_t visp_model_detect_family(char const* filepath, int32_t* out_family); /* :198 */
+VISP_API int32_t visp_model_load(char const* filepath, visp_device const* dev, int32_t arch, visp_model** out); /* :206 */
+VISP_API void visp_model_destroy(visp_model* model, int32_t arch);                /* :222 */
+/* Depth-Anything: inputs[0] any u8 format; returns alpha_u8 after image_normalize (c-api.cpp:72-77) */
+VISP_API int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* inputs, int32_t n_inputs,
+                                    int32_t* args, int32_t n_args, visp_image_view* out_image,
+                                    visp_image_data** out_data);                  /* :230 */
+
+/* ---- Part 2: MI355X extension ---------------------------------------------------------- */
+/* like visp_device_init(GPU) but on an explicit HIP device index (one process per GPU) */
+VISP_API int32_t visp_hip_device_init(int32_t device_index, visp_device** out_device);
+
+enum { VISP_LOAD_DEFAULT = 0, VISP_LOAD_NO_UPLOAD = 1 /* parse + allocate only; weights arrive by broadcast */ };
+VISP_API int32_t visp_model_load_ex(char const* filepath, visp_device const* dev, int32_t arch, int32_t flags,
+                                    visp_model** out);
+/* packed device weight arena (one allocation) -- the unit RCCL broadcasts at load */
+VISP_API int32_t visp_depthany_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes);
+/* call after a VISP_LOAD_NO_UPLOAD model's arena has been filled by the broadcast */
+VISP_API int32_t visp_depthany_weights_ready(visp_model* m);
+
+typedef struct visp_depthany_info {
+    int32_t patch_size, embed_dim, n_layers, n_heads;
+    int32_t image_size, image_multiple;
+    int32_t feature_layers[4];
+    float max_depth;
+} visp_depthany_info;
+VISP_API int32_t visp_depthany_get_info(visp_model const* m, visp_depthany_info* out);
+/* depthany_image_extent (depth-anything.cpp:112-117) */
+VISP_API int32_t visp_depthany_image_extent(visp_model const* m, int32_t w, int32_t h, int32_t* out_w, int32_t* out_h);
+
+/* Pre-allocates the activation workspace for `batch` images of w x h (w,h multiples of the
+ * patch size). Also called implicitly on the first compute of a new shape. */
+VISP_API int32_t visp_depthany_reserve(visp_model* m, int32_t batch, int32_t w, int32_t h);
+
+/* Batched hot path, everything on the device: rgb_u8 [batch,h,w,3] -> out [batch,h,w] f32 in [0,1]
+ * (depthany_compute semantics per image: process_input, predict, image_normalize).
+ * raw_out (nullable) receives the un-normalised depth. Asynchronous on `stream` (hipStream_t,
+ * NULL = the model's own stream, in which case the call returns after synchronising). */
+VISP_API int32_t visp_depthany_compute_batch_device(visp_model* m, void const* rgb_u8_dev, int32_t batch, int32_t w,
+                                                    int32_t h, void* out_dev, void* raw_out_dev, void* stream);
+/* same with host buffers (H2D + compute + D2H on the model's stream, blocking) */
+VISP_API int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w,
+                                                  int32_t h, float* out, float* raw_out);
+/* capture the launch sequence of the current reserved shape into a hipGraph and replay it on
+ * every later compute of that shape (enable = 0 turns it off) */
+VISP_API int32_t visp_depthany_use_graph(visp_model* m, int32_t enable);
+
+/* Named intermediate tensors of the last compute, converted to f32 on the host (parity tests;
+ * the reference's counterpart is the workbench capture, tests/workbench.cpp:754-760).
+ * Names: tokens, layer_<i>, dino_layer_<i>, reassemble_<i>, neck_conv_<i>, fusion_<i>, head_conv1, depth.
+ * Only available when captures were enabled before the compute. */
+VISP_API int32_t visp_depthany_enable_captures(visp_model* m, int32_t enable);
+VISP_API int32_t visp_depthany_read_capture(visp_model* m, char const* name, float* host_out, int64_t capacity,
+                                            int64_t* n_written, int64_t shape[4]);
+
+/* per-kernel-group timing of the last compute (HIP events on the compute stream); writes up to
+ * cap entries, returns count via n. Only when enabled. */
+typedef struct visp_timing { char name[32]; float ms; int32_t launches; double flops; double bytes; } visp_timing;
+VISP_API int32_t visp_depthany_enable_timing(visp_model* m, int32_t enable);
+VISP_API int32_t visp_depthany_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,144 @@
+/*
+ * visp_hip_kernels.h -- thin C ABI between the host C++ of the backend and its HIP
+ * translation units (gfx950 / MI355X only). Host code never includes HIP headers; every
+ * pointer below is a device pointer unless it says "host", `stream` is a hipStream_t.
+ *
+ * Each launcher replaces the ggml ops the reference's graph emits for the Depth-Anything
+ * path; the reference call sites are cited per entry.
+ * All functions return 1 on success and 0 on error (message via vx_last_error()), the
+ * convention of the reference's C API (src/visp/c-api.cpp:6-21).
+ */
+#ifndef VISP_HIP_KERNELS_H
+#define VISP_HIP_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_API __attribute__((visibility("default")))
+
+/* ---- runtime ------------------------------------------------------------------------- */
+VX_API const char* vx_last_error(void);
+VX_API int vx_device_count(void);
+VX_API int vx_set_device(int index);
+/* name/arch strings are copied into caller buffers; total/free memory in bytes */
+VX_API int vx_device_info(int index, char* name, int name_cap, char* arch, int arch_cap,
+                          size_t* total_mem, size_t* free_mem, int* n_cu);
+VX_API int vx_malloc(void** ptr, size_t bytes);
+VX_API int vx_free(void* ptr);
+VX_API int vx_memset(void* ptr, int value, size_t bytes, void* stream);
+VX_API int vx_memcpy_h2d(void* dst, const void* host_src, size_t bytes, void* stream);
+VX_API int vx_memcpy_d2h(void* host_dst, const void* src, size_t bytes, void* stream);
+VX_API int vx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+VX_API int vx_stream_create(void** stream);
+VX_API int vx_stream_destroy(void* stream);
+VX_API int vx_stream_sync(void* stream);
+VX_API int vx_event_create(void** ev);
+VX_API int vx_event_destroy(void* ev);
+VX_API int vx_event_record(void* ev, void* stream);
+VX_API int vx_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+/* hipGraph capture of a launch sequence */
+VX_API int vx_graph_begin_capture(void* stream);
+VX_API int vx_graph_end_capture(void* stream, void** graph_exec);
+VX_API int vx_graph_launch(void* graph_exec, void* stream);
+VX_API int vx_graph_destroy(void* graph_exec);
+
+/* ---- GEMM family: C[M,N] = A[M,K] * W[N,K]^T (f16 in, f32 accumulate on MFMA) ----------
+ * replaces ggml_mul_mat (+ggml_add bias, +ggml_gelu, +ggml_mul lambda, +ggml_add residual)
+ * emitted by linear() src/visp/nn.cpp:6-12, conv_2d 1x1 nn.cpp:76-81, dino.cpp:48-90,
+ * conv_transpose_2d nn.cpp:117-129 (k == stride => a GEMM + pixel shuffle),
+ * and ggml_conv_2d 3x3 (nn.cpp:83-97) as an implicit GEMM over NHWC input. */
+enum vx_epilogue {
+    VX_EPI_F16 = 0,       /* out f16 [M, ldo] = acc + bias                                      */
+    VX_EPI_F16_GELU = 1,  /* ... then tanh-GELU (ggml_gelu, dino.cpp:54)                        */
+    VX_EPI_F16_RELU = 2,  /* ... then ReLU                                                      */
+    VX_EPI_RESID_F32 = 3, /* x f32 [M, ldo] += lambda[n] * (acc + bias)   (dino.cpp:48-50,80-87) */
+    VX_EPI_TOKENS = 4,    /* patch embed: x f32 [(m/P)*(P+1) + 1 + m%P, n] = acc + bias + pos[1 + m%P, n]
+                             (dino.cpp:32-46, pos-embed add fused)                              */
+    VX_EPI_QKV = 5,       /* scatter into q,k [B,H,T,64] and v^T [B,H,64,Tp] f16; q scaled      */
+    VX_EPI_PIXSHUF = 6,   /* conv-transpose k==s: n = (dy*s+dx)*Cout + co ->
+                             out f16 [b, y*s+dy, x*s+dx, co]  (nn.cpp:117-129)                  */
+    VX_EPI_F16_ADD = 7,   /* out f16 = [relu](acc + bias) + res1 + res2 (nullable), conv residual units
+                             (depth-anything.cpp:15-30)                                          */
+};
+
+typedef struct {
+    /* A operand: plain rows, or implicit im2col over an NHWC image when conv_kh > 0 */
+    const void* A;      /* f16 */
+    int64_t lda;        /* elements between consecutive A rows (plain mode)                      */
+    int a_group;        /* plain mode row remap: arow = (m / a_group) * a_group_stride + a_row_off + m % a_group */
+    int a_group_stride; /* (a_group == 0: identity). Used to skip the cls token (depth-anything.cpp:50) */
+    int a_row_off;
+    /* implicit-GEMM conv (conv_kh > 0): A is [B, H, W, Cin] f16, m = (b, oy, ox), k = (ky, kx, c) */
+    int conv_kh, conv_kw, conv_stride, conv_pad;
+    int conv_H, conv_W, conv_Cin, conv_OH, conv_OW;
+    int a_relu;         /* apply ReLU to A elements while loading (depth-anything.cpp:17,19)    */
+
+    const void* W;      /* f16 [N, K], K padded to a multiple of 64 with zeros                   */
+    const float* bias;  /* f32 [N] or NULL                                                      */
+    int M, N, K;
+
+    int epi;            /* enum vx_epilogue */
+    void* out;
+    int64_t ldo;
+    int relu;           /* VX_EPI_F16_ADD: apply ReLU before adding residuals                   */
+    const float* lambda; /* VX_EPI_RESID_F32: f32 [N]                                           */
+    const float* pos;   /* VX_EPI_TOKENS: f32 [(P+1), N]                                        */
+    int tokens_P;       /* VX_EPI_TOKENS: patches per image                                     */
+    /* VX_EPI_QKV */
+    void* q; void* k; void* vt;
+    int qkv_T, qkv_Tp, qkv_H; /* tokens per image, padded tokens (v^T row length), heads        */
+    float q_scale;
+    /* VX_EPI_PIXSHUF */
+    int ps_s, ps_Cout, ps_H, ps_W; /* stride, real Cout, input H, W; ldo = output channel stride */
+    /* VX_EPI_F16_ADD */
+    const void* res1; const void* res2; /* f16 [M, ldo] or NULL */
+    int n_valid;        /* columns >= n_valid are not stored (N padded for tiling); 0 = N        */
+} vx_gemm_args;
+
+VX_API int vx_gemm_f16(const vx_gemm_args* args, void* stream);
+
+/* ---- fused multi-head attention, head_dim 64 (nn.cpp:210-244, dino.cpp:59-74) ------------
+ * q,k: f16 [B,H,T,64] (q pre-scaled by 1/sqrt(64)); vt: f16 [B,H,64,Tp] (pad columns finite);
+ * out: f16 [B*T, H*64]. softmax in f32, S never leaves registers. */
+VX_API int vx_attention_f16(const void* q, const void* k, const void* vt, void* out, int B, int H, int T,
+                            int Tp, void* stream);
+
+/* ---- LayerNorm (nn.cpp:14-19): x f32 [M,C] -> y f16 [M,C]; biased variance, eps in sqrt --- */
+VX_API int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y, int M, int C,
+                                float eps, void* stream);
+
+/* ---- pre-processing (depth-anything.cpp:130-140, image.cpp:215-255) + im2col of the 14x14
+ * stride-14 patch embedding (nn.cpp:166-180): rgb_u8 [B,H,W,3] -> f16 [B*P, Kp],
+ * k = (ky*ps + kx)*3 + c, zero padded to Kp; value = (u8/255 - mean[c]) / std[c] ----------- */
+VX_API int vx_preprocess_patches(const uint8_t* rgb, void* patches, int B, int H, int W, int ps, int Kp,
+                                 const float mean[3], const float inv_std[3], void* stream);
+/* same normalisation to plain NHWC f32 [B,H,W,3] (the tensor the reference uploads) */
+VX_API int vx_preprocess_f32(const uint8_t* rgb, float* out, int B, int H, int W, const float mean[3],
+                             const float inv_std[3], void* stream);
+/* cls token rows: x[b*(P+1), :] = cls + pos[0, :]  (dino.cpp:37-44) */
+VX_API int vx_write_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int C, void* stream);
+
+/* ---- bilinear resize, align_corners (ml.cpp:782-788, depth-anything.cpp:36-38,83-85),
+ * NHWC f16 [B,H,W,C] -> [B,OH,OW,C], C % 8 == 0 ------------------------------------------- */
+VX_API int vx_bilinear_ac_f16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, void* stream);
+
+/* ---- head tail: depth[b,y,x] = max_depth * relu(sum_c x[b,y,x,c]*w[c] + bias), x f16 NHWC
+ * (already ReLU-ed conv2 output), C <= 64 (depth-anything.cpp:89-94) ----------------------- */
+VX_API int vx_head_out_f32(const void* x, const float* w, float bias, float max_depth, float* depth,
+                           int64_t n_pixels, int C, void* stream);
+
+/* ---- post-processing: per-image min/max then (v-min)/(max-min) (image.cpp:537-576);
+ * minmax: f32 [B,2] scratch ------------------------------------------------------------------ */
+VX_API int vx_minmax_normalize(const float* depth, float* out, float* minmax, int B, int64_t pixels_per_image,
+                               void* stream);
+/* alpha_f32 -> alpha_u8: uint8(clamp(v,0,1)*255) (image-impl.h:36-38) */
+VX_API int vx_f32_to_u8(const float* src, uint8_t* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,297 @@
+"""-m gpu: every HIP kernel behind the vx_* C ABI against the CPU oracle (oracle/) on the same
+seeded inputs. f16 operands / f32 accumulation: tolerance is stated per test as the maximum
+absolute error relative to the largest reference magnitude."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from visioncpp_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    api = L.get_lib()
+    assert api.vx_device_count() > 0, "no HIP device visible: the product path has no CPU fallback"
+    L.vx_check(api.vx_set_device(0))
+    name, arch = C.create_string_buffer(256), C.create_string_buffer(64)
+    L.vx_check(api.vx_device_info(0, name, 256, arch, 64, None, None, None))
+    assert arch.value.decode().startswith("gfx950"), arch.value
+    yield
+
+
+@pytest.fixture(autouse=True)
+def _release_buffers():
+    yield
+    release()
+
+
+from gpu_util import api, dev, empty, gemm, pad_vec, pad_weight, rel_err, release, sync  # noqa: E402
+
+F16_TOL = 4e-3  # one f16 rounding of the output (2^-11) plus f16-rounded operands over K <= 1536
+
+
+def _rand(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def _h(a):  # round through f16 (what the device operands hold)
+    return a.astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 384), (1370 * 2, 1536, 384), (257, 384, 1536), (131, 64, 64), (128, 32, 320), (77, 96, 128)])
+@pytest.mark.parametrize("epi", ["f16", "gelu", "relu"])
+def test_gemm_f16_epilogues(M, N, K, epi):
+    rng = np.random.default_rng(M + N + K)
+    a, w, b = _h(_rand(rng, M, K)), _h(_rand(rng, N, K, scale=K ** -0.5)), _rand(rng, N, scale=0.1)
+    wp = pad_weight(w)
+    out = empty(M * wp.shape[0] * 2)
+    code = {"f16": L.EPI_F16, "gelu": L.EPI_F16_GELU, "relu": L.EPI_F16_RELU}[epi]
+    gemm(dev(a.astype(np.float16)), wp, pad_vec(b, wp.shape[0]), M, code, lda=K, out=out, ldo=wp.shape[0], n_valid=N)
+    got = out.to_numpy(np.float16, (M, wp.shape[0]))[:, :N].astype(np.float32)
+    want = oracle.linear(a, w, b)
+    if epi == "gelu":
+        want = oracle.gelu(want, oracle.GELU_TANH_F32)
+    elif epi == "relu":
+        want = np.maximum(want, 0)
+    assert rel_err(got, want) < F16_TOL
+    if wp.shape[0] > N:  # columns >= n_valid must stay untouched (zero-initialised buffer)
+        assert not out.to_numpy(np.float16, (M, wp.shape[0]))[:, N:].any()
+
+
+def test_gemm_row_remap_skips_cls_token():
+    """a_group remap: neck projections read rows 1..P of each image's T = P+1 tokens (depth-anything.cpp:50)."""
+    rng = np.random.default_rng(5)
+    B, P, K, N = 3, 50, 128, 64
+    feats = _h(_rand(rng, B * (P + 1), K))
+    w, b = _h(_rand(rng, N, K, scale=K ** -0.5)), _rand(rng, N)
+    out = empty(B * P * N * 2)
+    gemm(dev(feats.astype(np.float16)), pad_weight(w), b, B * P, L.EPI_F16, lda=K, out=out, ldo=N, a_group=P,
+         a_group_stride=P + 1, a_row_off=1)
+    got = out.to_numpy(np.float16, (B, P, N)).astype(np.float32)
+    want = oracle.linear(feats.reshape(B, P + 1, K)[:, 1:], w, b)
+    assert rel_err(got, want) < F16_TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(1370, 384, 384), (200, 128, 512)])
+def test_gemm_residual_layerscale(M, N, K):
+    """x += lambda * (A W^T + b): attention out-proj / fc2 epilogue (dino.cpp:48-50, 80-87)."""
+    rng = np.random.default_rng(7)
+    a, w, b = _h(_rand(rng, M, K)), _h(_rand(rng, N, K, scale=K ** -0.5)), _rand(rng, N, scale=0.1)
+    lam, x = _rand(rng, N, scale=0.3), _rand(rng, M, N)
+    xd = dev(x)
+    gemm(dev(a.astype(np.float16)), pad_weight(w), b, M, L.EPI_RESID_F32, lda=K, out=xd, ldo=N, lambda_=dev(lam))
+    got = xd.to_numpy(np.float32, (M, N))
+    want = x + oracle.linear(a, w, b) * lam
+    assert rel_err(got, want) < 1e-3  # f32 output: only operand rounding + accumulation order
+
+
+def test_gemm_tokens_epilogue():
+    """patch-embed GEMM writes rows 1.. of each image and adds the position embedding (dino.cpp:32-46)."""
+    rng = np.random.default_rng(8)
+    B, P, K, N = 2, 37, 588, 128
+    a, w, b = _h(_rand(rng, B * P, K)), _h(_rand(rng, N, K, scale=K ** -0.5)), _rand(rng, N)
+    pos = _rand(rng, P + 1, N)
+    wp = pad_weight(w, 128)
+    ap = np.zeros((B * P, wp.shape[1]), np.float16)
+    ap[:, :K] = a
+    x = empty(B * (P + 1) * N * 4)
+    gemm(dev(ap), wp, b, B * P, L.EPI_TOKENS, lda=wp.shape[1], out=x, ldo=N, pos=dev(pos), tokens_P=P)
+    got = x.to_numpy(np.float32, (B, P + 1, N))
+    want = oracle.linear(a, w, b).reshape(B, P, N) + pos[1:]
+    assert rel_err(got[:, 1:], want) < 1e-3
+    assert not got[:, 0].any()  # cls rows are written by vx_write_cls_rows, not by the GEMM
+
+
+def test_gemm_qkv_scatter():
+    rng = np.random.default_rng(9)
+    B, T, H = 2, 70, 2
+    Cc, Tp = H * 64, 128
+    a = _h(_rand(rng, B * T, Cc))
+    w, b = _h(_rand(rng, 3 * Cc, Cc, scale=Cc ** -0.5)), _rand(rng, 3 * Cc, scale=0.1)
+    q, k, vt = empty(B * H * T * 64 * 2), empty(B * H * T * 64 * 2), empty(B * H * 64 * Tp * 2)
+    gemm(dev(a.astype(np.float16)), pad_weight(w), b, B * T, L.EPI_QKV, lda=Cc, q=q, k=k, vt=vt, qkv_T=T, qkv_Tp=Tp, qkv_H=H,
+         q_scale=0.125)
+    y = oracle.linear(a, w, b).reshape(B, T, 3, H, 64)
+    gq = q.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32)
+    gk = k.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32)
+    gv = vt.to_numpy(np.float16, (B, H, 64, Tp)).astype(np.float32)
+    assert rel_err(gq, y[:, :, 0].transpose(0, 2, 1, 3) * 0.125) < F16_TOL
+    assert rel_err(gk, y[:, :, 1].transpose(0, 2, 1, 3)) < F16_TOL
+    assert rel_err(gv[..., :T], y[:, :, 2].transpose(0, 2, 3, 1)) < F16_TOL
+    assert not gv[..., T:].any()  # pad columns untouched
+
+
+@pytest.mark.parametrize("s,c", [(4, 48), (2, 96)])
+def test_conv_transpose_as_gemm_pixel_shuffle(s, c):
+    """conv_transpose_2d with k == stride (nn.cpp:117-129) vs the oracle's torch-semantics convT."""
+    rng = np.random.default_rng(s)
+    B, Hh, Ww = 2, 5, 7
+    x = _h(_rand(rng, B, Hh, Ww, c))
+    w, b = _h(_rand(rng, c, c, s, s, scale=c ** -0.5)), _rand(rng, c, scale=0.1)  # torch [Cin, Cout, kh, kw]
+    kp = -(-c // 64) * 64
+    rows = np.zeros((s * s * c, kp), np.float32)
+    rows[:, :c] = w.transpose(2, 3, 1, 0).reshape(s * s * c, c)  # n = (dy*s+dx)*Cout + co, k = ci
+    xp = np.zeros((B * Hh * Ww, kp), np.float16)
+    xp[:, :c] = x.reshape(-1, c)
+    out = empty(B * Hh * s * Ww * s * c * 2)
+    gemm(dev(xp), pad_weight(rows), np.tile(b, s * s), B * Hh * Ww, L.EPI_PIXSHUF, lda=kp, out=out, ldo=c, ps_s=s, ps_Cout=c,
+         ps_H=Hh, ps_W=Ww, n_valid=s * s * c)
+    got = out.to_numpy(np.float16, (B, Hh * s, Ww * s, c)).astype(np.float32)
+    want = oracle.conv_transpose2d_nhwc(x, w, b, s)
+    assert rel_err(got, want) < F16_TOL
+
+
+@pytest.mark.parametrize("cin,cout,stride,hw", [(64, 64, 1, (19, 23)), (48, 64, 1, (20, 12)), (32, 32, 1, (30, 17)), (128, 128, 2, (37, 37)),
+                                                 (96, 64, 1, (9, 9))])
+@pytest.mark.parametrize("mode", ["plain", "rcu1", "rcu2"])
+def test_conv3x3_implicit_gemm(cin, cout, stride, hw, mode):
+    """3x3 pad-1 NHWC conv (nn.cpp:72-100) and the fused residual-unit forms (depth-anything.cpp:15-30)."""
+    if mode != "plain" and (cin != cout or stride != 1):
+        pytest.skip("residual forms are same-shape convs")
+    rng = np.random.default_rng(cin + cout + stride)
+    B, (Hh, Ww) = 2, hw
+    x = _h(_rand(rng, B, Hh, Ww, cin))
+    w, b = _h(_rand(rng, cout, 3, 3, cin, scale=(9 * cin) ** -0.5)), _rand(rng, cout, scale=0.1)
+    OH, OW = (Hh + 2 - 3) // stride + 1, (Ww + 2 - 3) // stride + 1
+    out = empty(B * OH * OW * cout * 2)
+    kw = dict(conv_kh=3, conv_kw=3, conv_stride=stride, conv_pad=1, conv_H=Hh, conv_W=Ww, conv_Cin=cin, conv_OH=OH, conv_OW=OW,
+              n_valid=cout)
+    wp = pad_weight(w.reshape(cout, -1))
+    xin = x
+    if mode == "plain":
+        gemm(dev(x.astype(np.float16)), wp, pad_vec(b, wp.shape[0]), B * OH * OW, L.EPI_F16, out=out, ldo=cout, **kw)
+        want = oracle.conv2d_nhwc(x, w, b, stride, 1)
+    elif mode == "rcu1":  # relu on load, relu on store
+        gemm(dev(x.astype(np.float16)), wp, pad_vec(b, wp.shape[0]), B * OH * OW, L.EPI_F16_RELU, out=out, ldo=cout, a_relu=1, **kw)
+        want = np.maximum(oracle.conv2d_nhwc(np.maximum(xin, 0), w, b, 1, 1), 0)
+    else:  # conv + two residual addends
+        r1, r2 = _h(_rand(rng, B, OH, OW, cout)), _h(_rand(rng, B, OH, OW, cout))
+        gemm(dev(x.astype(np.float16)), wp, pad_vec(b, wp.shape[0]), B * OH * OW, L.EPI_F16_ADD, out=out, ldo=cout,
+             res1=dev(r1.astype(np.float16)), res2=dev(r2.astype(np.float16)), **kw)
+        want = oracle.conv2d_nhwc(x, w, b, 1, 1) + r1 + r2
+    got = out.to_numpy(np.float16, (B, OH, OW, cout)).astype(np.float32)
+    assert rel_err(got, want) < F16_TOL
+
+
+@pytest.mark.parametrize("B,H,T", [(1, 1, 64), (2, 2, 65), (1, 3, 50), (1, 2, 257), (2, 6, 1370)])
+def test_attention(B, H, T):
+    """fused MHSA, head_dim 64 (nn.cpp:210-244) vs the oracle's softmax(q k^T * scale) v."""
+    rng = np.random.default_rng(T)
+    Cc, Tp = H * 64, -(-T // 64) * 64
+    q, k, v = (_h(_rand(rng, B, T, Cc)) for _ in range(3))
+    scale = 0.125
+    qs = _h(q * scale)  # the QKV epilogue stores q pre-scaled (exact: power of two)
+    qd = dev(qs.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float16))
+    kd = dev(k.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float16))
+    vt = np.zeros((B, H, 64, Tp), np.float16)
+    vt[..., :T] = v.reshape(B, T, H, 64).transpose(0, 2, 3, 1)
+    out = empty(B * T * Cc * 2)
+    L.vx_check(api().vx_attention_f16(qd.ptr, kd.ptr, dev(vt).ptr, out.ptr, B, H, T, Tp, None))
+    sync()
+    got = out.to_numpy(np.float16, (B, T, Cc)).astype(np.float32)
+    want = np.stack([oracle.attention(q[i], k[i], v[i], H, scale) for i in range(B)])
+    # P is rounded to f16 before the PV product: 2^-11 relative per term
+    assert rel_err(got, want) < 5e-3
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Forces the running max to jump late (a spiked key in the last tile), so every earlier
+    tile's partial sums must be rescaled (guide rule 26: a data-dependent branch needs its own test)."""
+    rng = np.random.default_rng(3)
+    B, H, T = 1, 1, 300
+    q, k, v = (_h(_rand(rng, B, T, 64)) for _ in range(3))
+    k[0, 290] = q[0, 7] * 4.0  # key 290 dominates query 7 only
+    k = _h(k)
+    Tp = 320
+    vt = np.zeros((B, H, 64, Tp), np.float16)
+    vt[0, 0, :, :T] = v[0].T
+    out = empty(T * 64 * 2)
+    L.vx_check(api().vx_attention_f16(dev(_h(q * 0.125).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr, dev(vt).ptr, out.ptr,
+                                      B, H, T, Tp, None))
+    sync()
+    got = out.to_numpy(np.float16, (T, 64)).astype(np.float32)
+    want = oracle.attention(q[0], k[0], v[0], 1, 0.125)
+    assert rel_err(got, want) < 5e-3
+
+
+@pytest.mark.parametrize("M,Cc", [(1370, 384), (77, 128), (33, 768), (10, 96)])
+def test_layernorm(M, Cc):
+    rng = np.random.default_rng(Cc)
+    x = _rand(rng, M, Cc, scale=3.0) + 1.5
+    w, b = 1 + _rand(rng, Cc, scale=0.1), _rand(rng, Cc, scale=0.1)
+    y = empty(M * Cc * 2)
+    L.vx_check(api().vx_layernorm_f32_f16(dev(x).ptr, dev(w).ptr, dev(b).ptr, y.ptr, M, Cc, 1e-6, None))
+    sync()
+    got = y.to_numpy(np.float16, (M, Cc)).astype(np.float32)
+    want = oracle.layer_norm(x, w, b, 1e-6)
+    assert rel_err(got, want) < 1e-3  # f32 math, one f16 rounding of the output
+
+
+def test_preprocess_patches_and_f32():
+    rng = np.random.default_rng(1)
+    B, Hh, Ww, ps = 2, 28, 42, 14
+    img = rng.integers(0, 256, (B, Hh, Ww, 3), dtype=np.uint8)
+    mean = (C.c_float * 3)(0.485, 0.456, 0.406)
+    inv = (C.c_float * 3)(*[np.float32(1.0) / np.float32(s) for s in (0.229, 0.224, 0.225)])
+    Kp = 640
+    pat = empty(B * 2 * 3 * Kp * 2)
+    L.vx_check(api().vx_preprocess_patches(dev(img).ptr, pat.ptr, B, Hh, Ww, ps, Kp, mean, inv, None))
+    f32 = empty(B * Hh * Ww * 3 * 4)
+    L.vx_check(api().vx_preprocess_f32(dev(img).ptr, f32.ptr, B, Hh, Ww, mean, inv, None))
+    sync()
+    want = np.stack([oracle.image_u8_to_f32(img[i], oracle.RGB_U8, oracle.RGB_F32, (-0.485, -0.456, -0.406, 0),
+                                            (1 / 0.229, 1 / 0.224, 1 / 0.225, 1)) for i in range(B)])
+    got32 = f32.to_numpy(np.float32, (B, Hh, Ww, 3))
+    np.testing.assert_allclose(got32, want, rtol=0, atol=1e-6)
+    gp = pat.to_numpy(np.float16, (B, 2, 3, Kp)).astype(np.float32)
+    wp = want.reshape(B, 2, ps, 3, ps, 3).transpose(0, 1, 3, 2, 4, 5).reshape(B, 2, 3, ps * ps * 3)  # k = (ky, kx, c)
+    assert rel_err(gp[..., :588], wp) < 1e-3
+    assert not gp[..., 588:].any()
+
+
+@pytest.mark.parametrize("shape,target", [((2, 19, 19, 64), (37, 37)), ((1, 37, 23, 64), (74, 46)), ((2, 40, 40, 32), (70, 70)), ((1, 5, 7, 8), (9, 3))])
+def test_bilinear_align_corners(shape, target):
+    rng = np.random.default_rng(shape[1])
+    x = _h(_rand(rng, *shape))
+    B, Hh, Ww, Cc = shape
+    y = empty(B * target[0] * target[1] * Cc * 2)
+    L.vx_check(api().vx_bilinear_ac_f16(dev(x.astype(np.float16)).ptr, y.ptr, B, Hh, Ww, Cc, target[0], target[1], None))
+    sync()
+    got = y.to_numpy(np.float16, (B, *target, Cc)).astype(np.float32)
+    want = oracle.interpolate_nhwc(x, target, "bilinear", True)
+    assert rel_err(got, want) < 1e-3
+
+
+def test_head_out_and_minmax_normalize():
+    rng = np.random.default_rng(2)
+    B, n, Cc = 3, 518 * 37, 32
+    x = np.maximum(_h(_rand(rng, B * n, Cc)), 0)
+    w, bias = np.abs(_rand(rng, Cc, scale=0.2)), 0.1
+    depth, out, mm = empty(B * n * 4), empty(B * n * 4), empty(B * 8)
+    L.vx_check(api().vx_head_out_f32(dev(x.astype(np.float16)).ptr, dev(w).ptr, bias, 1.0, depth.ptr, B * n, Cc, None))
+    L.vx_check(api().vx_minmax_normalize(depth.ptr, out.ptr, mm.ptr, B, n, None))
+    sync()
+    d = depth.to_numpy(np.float32, (B, n))
+    want_d = np.maximum(x @ w + bias, 0).reshape(B, n)
+    assert rel_err(d, want_d) < 1e-5
+    got = out.to_numpy(np.float32, (B, n))
+    want = np.stack([oracle.image_normalize(d[i].reshape(1, n)).ravel() for i in range(B)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    assert got.min() == 0.0 and abs(got.max() - 1.0) < 1e-6
+    u8 = empty(B * n)
+    L.vx_check(api().vx_f32_to_u8(out.ptr, u8.ptr, B * n, None))
+    sync()
+    np.testing.assert_array_equal(u8.to_numpy(np.uint8, (B, n)), oracle.image_f32_to_u8(got.reshape(B, n, 1), oracle.ALPHA_F32, oracle.ALPHA_U8).reshape(B, n))
+
+
+def test_constant_image_normalizes_to_zero():
+    """delta < 1e-5 => scale 1 (image.cpp:560-563): a constant depth map maps to 0, not NaN."""
+    d = np.full((1, 1000), 3.25, np.float32)
+    out, mm = empty(4000), empty(8)
+    L.vx_check(api().vx_minmax_normalize(dev(d).ptr, out.ptr, mm.ptr, 1, 1000, None))
+    sync()
+    assert not out.to_numpy(np.float32, (1000,)).any()

@@ -1,0 +1,181 @@
+"""ctypes declarations of the C ABI in lib/libvisioncpp.so.
+
+Mirror of the reference's bindings/python/visioncpp/_lib.py (:36-171): same structures, same
+11 `visp_*` prototypes, plus the batched extension (include/visp_c_api.h part 2) and the
+kernel-level `vx_*` launchers (include/visp_hip_kernels.h) that the parity tests drive.
+There is no fallback: if the library is missing or a symbol cannot be resolved this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
+from pathlib import Path
+
+
+class Error(Exception):
+    pass
+
+
+class ImageView(ctypes.Structure):  # == visp_image_view
+    _fields_ = [("width", c_int32), ("height", c_int32), ("stride", c_int32), ("format", c_int32), ("data", c_void_p)]
+
+
+class DepthAnyInfo(ctypes.Structure):
+    _fields_ = [("patch_size", c_int32), ("embed_dim", c_int32), ("n_layers", c_int32), ("n_heads", c_int32),
+                ("image_size", c_int32), ("image_multiple", c_int32), ("feature_layers", c_int32 * 4),
+                ("max_depth", c_float)]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32), ("ms", c_float), ("launches", c_int32), ("flops", c_double), ("bytes", c_double)]
+
+
+class GemmArgs(ctypes.Structure):  # == vx_gemm_args
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64), ("a_group", c_int), ("a_group_stride", c_int), ("a_row_off", c_int),
+        ("conv_kh", c_int), ("conv_kw", c_int), ("conv_stride", c_int), ("conv_pad", c_int),
+        ("conv_H", c_int), ("conv_W", c_int), ("conv_Cin", c_int), ("conv_OH", c_int), ("conv_OW", c_int),
+        ("a_relu", c_int),
+        ("W", c_void_p), ("bias", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int),
+        ("epi", c_int), ("out", c_void_p), ("ldo", c_int64), ("relu", c_int),
+        ("lambda_", c_void_p), ("pos", c_void_p), ("tokens_P", c_int),
+        ("q", c_void_p), ("k", c_void_p), ("vt", c_void_p), ("qkv_T", c_int), ("qkv_Tp", c_int), ("qkv_H", c_int),
+        ("q_scale", c_float),
+        ("ps_s", c_int), ("ps_Cout", c_int), ("ps_H", c_int), ("ps_W", c_int),
+        ("res1", c_void_p), ("res2", c_void_p), ("n_valid", c_int),
+    ]
+
+
+EPI_F16, EPI_F16_GELU, EPI_F16_RELU, EPI_RESID_F32, EPI_TOKENS, EPI_QKV, EPI_PIXSHUF, EPI_F16_ADD = range(8)
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvisioncpp.so"
+
+# every symbol include/visp_c_api.h and include/visp_hip_kernels.h declare
+C_API_SYMBOLS = [
+    "visp_get_last_error", "visp_image_destroy", "visp_backend_load_all", "visp_device_init", "visp_device_destroy",
+    "visp_device_type", "visp_device_name", "visp_device_description", "visp_model_detect_family", "visp_model_load",
+    "visp_model_destroy", "visp_model_compute",
+    "visp_hip_device_init", "visp_model_load_ex", "visp_depthany_weights_arena", "visp_depthany_weights_ready",
+    "visp_depthany_get_info", "visp_depthany_image_extent", "visp_depthany_reserve",
+    "visp_depthany_compute_batch_device", "visp_depthany_compute_batch_host", "visp_depthany_use_graph",
+    "visp_depthany_enable_captures", "visp_depthany_read_capture", "visp_depthany_enable_timing",
+    "visp_depthany_read_timing",
+]
+KERNEL_SYMBOLS = [
+    "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
+    "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
+    "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_graph_begin_capture",
+    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_attention_f16",
+    "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
+    "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
+]
+
+
+def init() -> ctypes.CDLL:
+    if not LIB_PATH.exists():
+        raise OSError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"(make -C vision.cpp_amd/csrc). There is no CPU fallback.")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for sym in C_API_SYMBOLS + KERNEL_SYMBOLS:
+        getattr(lib, sym)  # AttributeError if the build dropped a declared symbol
+
+    lib.visp_get_last_error.restype = c_char_p
+    lib.visp_backend_load_all.argtypes = [c_char_p]
+    lib.visp_backend_load_all.restype = c_int32
+    lib.visp_image_destroy.argtypes = [c_void_p]
+    lib.visp_image_destroy.restype = None
+    lib.visp_device_init.argtypes = [c_int32, POINTER(c_void_p)]
+    lib.visp_device_init.restype = c_int32
+    lib.visp_hip_device_init.argtypes = [c_int32, POINTER(c_void_p)]
+    lib.visp_hip_device_init.restype = c_int32
+    lib.visp_device_destroy.argtypes = [c_void_p]
+    lib.visp_device_destroy.restype = None
+    lib.visp_device_type.argtypes = [c_void_p]
+    lib.visp_device_type.restype = c_int32
+    lib.visp_device_name.argtypes = [c_void_p]
+    lib.visp_device_name.restype = c_char_p
+    lib.visp_device_description.argtypes = [c_void_p]
+    lib.visp_device_description.restype = c_char_p
+    lib.visp_model_detect_family.argtypes = [c_char_p, POINTER(c_int32)]
+    lib.visp_model_detect_family.restype = c_int32
+    lib.visp_model_load.argtypes = [c_char_p, c_void_p, c_int32, POINTER(c_void_p)]
+    lib.visp_model_load.restype = c_int32
+    lib.visp_model_load_ex.argtypes = [c_char_p, c_void_p, c_int32, c_int32, POINTER(c_void_p)]
+    lib.visp_model_load_ex.restype = c_int32
+    lib.visp_model_destroy.argtypes = [c_void_p, c_int32]
+    lib.visp_model_destroy.restype = None
+    lib.visp_model_compute.argtypes = [c_void_p, c_int32, POINTER(ImageView), c_int32, POINTER(c_int32), c_int32,
+                                       POINTER(ImageView), POINTER(c_void_p)]
+    lib.visp_model_compute.restype = c_int32
+
+    lib.visp_depthany_weights_arena.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]
+    lib.visp_depthany_weights_ready.argtypes = [c_void_p]
+    lib.visp_depthany_get_info.argtypes = [c_void_p, POINTER(DepthAnyInfo)]
+    lib.visp_depthany_image_extent.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]
+    lib.visp_depthany_reserve.argtypes = [c_void_p, c_int32, c_int32, c_int32]
+    lib.visp_depthany_compute_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.visp_depthany_compute_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.visp_depthany_use_graph.argtypes = [c_void_p, c_int32]
+    lib.visp_depthany_enable_captures.argtypes = [c_void_p, c_int32]
+    lib.visp_depthany_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
+    lib.visp_depthany_enable_timing.argtypes = [c_void_p, c_int32]
+    lib.visp_depthany_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
+    for name in C_API_SYMBOLS[15:]:
+        getattr(lib, name).restype = c_int32
+
+    lib.vx_last_error.restype = c_char_p
+    lib.vx_device_info.argtypes = [c_int, c_char_p, c_int, c_char_p, c_int, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_int)]
+    lib.vx_malloc.argtypes = [POINTER(c_void_p), c_size_t]
+    lib.vx_free.argtypes = [c_void_p]
+    lib.vx_memset.argtypes = [c_void_p, c_int, c_size_t, c_void_p]
+    lib.vx_memcpy_h2d.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.vx_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.vx_memcpy_d2d.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.vx_stream_create.argtypes = [POINTER(c_void_p)]
+    lib.vx_stream_destroy.argtypes = [c_void_p]
+    lib.vx_stream_sync.argtypes = [c_void_p]
+    lib.vx_event_create.argtypes = [POINTER(c_void_p)]
+    lib.vx_event_destroy.argtypes = [c_void_p]
+    lib.vx_event_record.argtypes = [c_void_p, c_void_p]
+    lib.vx_event_elapsed_ms.argtypes = [c_void_p, c_void_p, POINTER(c_float)]
+    lib.vx_graph_begin_capture.argtypes = [c_void_p]
+    lib.vx_graph_end_capture.argtypes = [c_void_p, POINTER(c_void_p)]
+    lib.vx_graph_launch.argtypes = [c_void_p, c_void_p]
+    lib.vx_graph_destroy.argtypes = [c_void_p]
+    lib.vx_gemm_f16.argtypes = [POINTER(GemmArgs), c_void_p]
+    lib.vx_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.vx_layernorm_f32_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
+    lib.vx_preprocess_patches.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]
+    lib.vx_preprocess_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]
+    lib.vx_write_cls_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.vx_bilinear_ac_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.vx_head_out_f32.argtypes = [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_int, c_void_p]
+    lib.vx_minmax_normalize.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
+    lib.vx_f32_to_u8.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    for name in KERNEL_SYMBOLS[1:]:
+        getattr(lib, name).restype = c_int
+    return lib
+
+
+_lib: ctypes.CDLL | None = None
+
+
+def get_lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = init()
+    return _lib
+
+
+def check(return_value: int):
+    if return_value == 0:
+        raise Error(get_lib().visp_get_last_error().decode())
+
+
+def vx_check(return_value: int):
+    if return_value == 0:
+        raise Error(get_lib().vx_last_error().decode())
+
+
+def path_to_char_p(p) -> bytes:
+    return str(p).encode()

@@ -1,0 +1,264 @@
+// The drop-in C ABI (include/visp_c_api.h). Part 1 restates the reference's
+// src/visp/c-api.cpp:145-253 symbol for symbol on top of this backend; part 2 is the batched
+// extension. Error convention: return 1 on success, 0 on error + thread-local message
+// (reference c-api.cpp:6-21).
+#include "../../include/visp_c_api.h"
+
+#include <cstring>
+#include <exception>
+#include <memory>
+
+#include "../../include/visp_hip_kernels.h"
+#include "depthany.h"
+#include "visp_util.h"
+
+using namespace visp;
+
+struct visp_image_data : image_data {};
+struct visp_device : backend_device {};
+// visp_model stays opaque: handles are depthany_model* (any_model in the reference, c-api.cpp:193)
+
+namespace {
+
+thread_local char g_error[512] = {0};
+
+void set_error(const char* msg) { snprintf(g_error, sizeof g_error, "%s", msg); }
+
+template <typename F>
+int32_t handle_errors(F&& f) {
+    try {
+        f();
+    } catch (std::exception const& e) {
+        set_error(e.what());
+        return 0;
+    } catch (...) {
+        set_error("unknown error");
+        return 0;
+    }
+    return 1;
+}
+
+depthany_model& as_depthany(visp_model* m) {
+    if (!m) throw except("model handle is null");
+    return *reinterpret_cast<depthany_model*>(m);
+}
+depthany_model const& as_depthany(visp_model const* m) {
+    if (!m) throw except("model handle is null");
+    return *reinterpret_cast<depthany_model const*>(m);
+}
+
+int32_t detect_family(model_file const& file) { // reference vision.cpp:7-21
+    std::string_view arch = file.arch();
+    if (arch == "mobile-sam") return VISP_SAM;
+    if (arch == "birefnet") return VISP_BIREFNET;
+    if (arch == "depthanything") return VISP_DEPTH_ANYTHING;
+    if (arch == "migan") return VISP_MIGAN;
+    if (arch == "esrgan") return VISP_ESRGAN;
+    return VISP_FAMILY_COUNT;
+}
+
+void require_depth_anything(int32_t family) {
+    if (family < 0 || family >= VISP_FAMILY_COUNT) throw except("Unsupported model family");
+    if (family != VISP_DEPTH_ANYTHING)
+        throw except("Model family %d is not built in this backend (MI355X backend implements depth_anything)", family);
+}
+
+} // namespace
+
+extern "C" {
+
+char const* visp_get_last_error(void) { return g_error; }
+
+void visp_image_destroy(visp_image_data* img) { delete img; }
+
+int32_t visp_backend_load_all(char const*) { return 1; } // single built-in backend, nothing to load
+
+int32_t visp_device_init(int32_t type, visp_device** out_device) {
+    return handle_errors([&]() {
+        if (type == VISP_BACKEND_CPU)
+            throw except("Failed to initialize backend, no suitable device available (this build has no CPU backend)");
+        if (type != VISP_BACKEND_AUTO && type != VISP_BACKEND_GPU)
+            throw except("Failed to initialize backend, backend type %d is not available in this build", type);
+        *out_device = static_cast<visp_device*>(backend_init(0));
+    });
+}
+
+int32_t visp_hip_device_init(int32_t device_index, visp_device** out_device) {
+    return handle_errors([&]() { *out_device = static_cast<visp_device*>(backend_init(device_index)); });
+}
+
+void visp_device_destroy(visp_device* d) { delete static_cast<backend_device*>(d); }
+
+int32_t visp_device_type(visp_device const* d) { return int32_t(d->type()); }
+char const* visp_device_name(visp_device const* d) { return d->name.c_str(); }
+char const* visp_device_description(visp_device const* d) { return d->description.c_str(); }
+
+int32_t visp_model_detect_family(char const* filepath, int32_t* out_family) {
+    return handle_errors([&]() {
+        model_file file = model_load(filepath, /*header_only=*/true);
+        *out_family = detect_family(file);
+    });
+}
+
+int32_t visp_model_load_ex(char const* filepath, visp_device const* dev, int32_t arch, int32_t flags, visp_model** out) {
+    return handle_errors([&]() {
+        if (!dev) throw except("device handle is null");
+        int32_t family = arch;
+        if (family == VISP_FAMILY_COUNT) {
+            model_file file = model_load(filepath, true);
+            family = detect_family(file);
+        }
+        require_depth_anything(family);
+        *out = reinterpret_cast<visp_model*>(depthany_load_model(filepath, *dev, flags));
+    });
+}
+
+int32_t visp_model_load(char const* filepath, visp_device const* dev, int32_t arch, visp_model** out) {
+    return visp_model_load_ex(filepath, dev, arch, VISP_LOAD_DEFAULT, out);
+}
+
+void visp_model_destroy(visp_model* model, int32_t arch) {
+    if (arch == VISP_DEPTH_ANYTHING) delete reinterpret_cast<depthany_model*>(model);
+}
+
+int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* inputs, int32_t n_inputs, int32_t*, int32_t,
+                           visp_image_view* out_image, visp_image_data** out_data) {
+    return handle_errors([&]() {
+        require_depth_anything(family);
+        if (n_inputs != 1) throw except("Expected %d input images, but got %d.", 1, n_inputs);
+        image_view in;
+        in.extent = {{inputs[0].width, inputs[0].height}};
+        in.stride = inputs[0].stride;
+        in.format = image_format(inputs[0].format);
+        in.data = inputs[0].data;
+        // model_funcs<depth_anything>::compute (reference c-api.cpp:72-77)
+        image_data result_f32 = depthany_compute(as_depthany(model), in);
+        image_data normalized = image_normalize(view_of(result_f32));
+        image_data u8 = image_f32_to_u8(view_of(normalized), image_format::alpha_u8);
+        auto* owned = new visp_image_data;
+        static_cast<image_data&>(*owned) = std::move(u8);
+        *out_data = owned;
+        out_image->width = owned->extent[0];
+        out_image->height = owned->extent[1];
+        out_image->stride = owned->extent[0] * n_bytes(owned->format);
+        out_image->format = int32_t(owned->format);
+        out_image->data = owned->data.get();
+    });
+}
+
+// ---- extension ---------------------------------------------------------------------------
+
+int32_t visp_depthany_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes) {
+    return handle_errors([&]() {
+        depthany_model& dm = as_depthany(m);
+        *device_ptr = dm.weight_arena.ptr;
+        *n_bytes = dm.weight_arena.bytes;
+    });
+}
+
+int32_t visp_depthany_weights_ready(visp_model* m) {
+    return handle_errors([&]() { depthany_weights_ready(as_depthany(m)); });
+}
+
+int32_t visp_depthany_get_info(visp_model const* m, visp_depthany_info* out) {
+    return handle_errors([&]() {
+        depthany_params const& p = as_depthany(m).params;
+        out->patch_size = p.dino.patch_size;
+        out->embed_dim = p.dino.embed_dim;
+        out->n_layers = p.dino.n_layers;
+        out->n_heads = p.dino.n_heads;
+        out->image_size = p.image_size;
+        out->image_multiple = p.image_multiple;
+        for (int i = 0; i < 4; ++i) out->feature_layers[i] = p.feature_layers[i];
+        out->max_depth = p.max_depth;
+    });
+}
+
+int32_t visp_depthany_image_extent(visp_model const* m, int32_t w, int32_t h, int32_t* out_w, int32_t* out_h) {
+    return handle_errors([&]() {
+        if (w <= 0 || h <= 0) throw except("invalid extent %dx%d", w, h);
+        i32x2 e = depthany_image_extent(i32x2{{w, h}}, as_depthany(m).params);
+        *out_w = e[0];
+        *out_h = e[1];
+    });
+}
+
+int32_t visp_depthany_reserve(visp_model* m, int32_t batch, int32_t w, int32_t h) {
+    return handle_errors([&]() { depthany_reserve(as_depthany(m), batch, w, h); });
+}
+
+int32_t visp_depthany_compute_batch_device(visp_model* m, void const* rgb, int32_t batch, int32_t w, int32_t h, void* out,
+                                           void* raw_out, void* stream) {
+    return handle_errors([&]() {
+        if (!rgb || !out) throw except("depthany: null input/output pointer");
+        depthany_compute_batch_device(as_depthany(m), rgb, batch, w, h, out, raw_out, stream);
+    });
+}
+
+int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb, int32_t batch, int32_t w, int32_t h, float* out,
+                                         float* raw_out) {
+    return handle_errors([&]() {
+        if (!rgb || !out) throw except("depthany: null input/output pointer");
+        depthany_compute_batch_host(as_depthany(m), rgb, batch, w, h, out, raw_out);
+    });
+}
+
+int32_t visp_depthany_use_graph(visp_model* m, int32_t enable) {
+    return handle_errors([&]() {
+        depthany_model& dm = as_depthany(m);
+        dm.use_graph = enable != 0;
+        if (!enable && dm.ws.graph_exec) {
+            vx_graph_destroy(dm.ws.graph_exec);
+            dm.ws.graph_exec = nullptr;
+        }
+    });
+}
+
+int32_t visp_depthany_enable_captures(visp_model* m, int32_t enable) {
+    return handle_errors([&]() { as_depthany(m).captures = enable != 0; });
+}
+
+int32_t visp_depthany_read_capture(visp_model* m, char const* name, float* host_out, int64_t capacity, int64_t* n_written,
+                                   int64_t shape[4]) {
+    return handle_errors([&]() {
+        depthany_model& dm = as_depthany(m);
+        auto it = dm.capture_bufs.find(name);
+        if (it == dm.capture_bufs.end()) throw except("capture '%s' not available (enable captures before compute)", name);
+        capture_entry const& c = it->second;
+        int64_t n = c.shape[0] * c.shape[1] * c.shape[2] * c.shape[3];
+        *n_written = n;
+        if (shape) memcpy(shape, c.shape, sizeof(int64_t) * 4);
+        if (n > capacity) return; // caller learns the size and retries
+        if (!vx_set_device(dm.backend->index)) throw except("%s", vx_last_error());
+        if (c.f16) {
+            std::unique_ptr<uint16_t[]> tmp(new uint16_t[(size_t)n]);
+            if (!vx_memcpy_d2h(tmp.get(), c.dev, (size_t)n * 2, dm.backend->stream)) throw except("%s", vx_last_error());
+            for (int64_t i = 0; i < n; ++i) host_out[i] = f16_to_f32(tmp[(size_t)i]);
+        } else {
+            if (!vx_memcpy_d2h(host_out, c.dev, (size_t)n * 4, dm.backend->stream)) throw except("%s", vx_last_error());
+        }
+    });
+}
+
+int32_t visp_depthany_enable_timing(visp_model* m, int32_t enable) {
+    return handle_errors([&]() { as_depthany(m).timing = enable != 0; });
+}
+
+int32_t visp_depthany_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n) {
+    return handle_errors([&]() {
+        depthany_model& dm = as_depthany(m);
+        int32_t count = 0;
+        for (timing_entry const& t : dm.last_timing) {
+            if (count >= cap) break;
+            snprintf(out[count].name, sizeof out[count].name, "%s", t.name.c_str());
+            out[count].ms = t.ms;
+            out[count].launches = t.launches;
+            out[count].flops = t.flops;
+            out[count].bytes = t.bytes;
+            ++count;
+        }
+        *n = count;
+    });
+}
+
+} // extern "C"

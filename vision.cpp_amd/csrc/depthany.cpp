@@ -1,0 +1,842 @@
+#include "depthany.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/visp_hip_kernels.h"
+#include "visp_util.h"
+
+namespace visp {
+
+#define VX(call)                                        \
+    do {                                                \
+        if (!(call)) throw except("%s", vx_last_error()); \
+    } while (0)
+
+namespace {
+template <typename T>
+T round_up(T x, T m) { return (x + m - 1) / m * m; }
+} // namespace
+
+//
+// backend (reference src/visp/ml.cpp:59-95)
+
+backend_device* backend_init(int device_index) {
+    int n = vx_device_count();
+    if (n <= 0) throw except("Failed to initialize backend, no suitable device available");
+    if (device_index < 0 || device_index >= n) throw except("Failed to initialize backend, device index %d out of range (%d devices)", device_index, n);
+    VX(vx_set_device(device_index));
+    char name[256] = {0}, arch[128] = {0};
+    size_t total = 0;
+    int n_cu = 0;
+    VX(vx_device_info(device_index, name, sizeof name, arch, sizeof arch, &total, nullptr, &n_cu));
+    if (strncmp(arch, "gfx950", 6) != 0)
+        throw except("Failed to initialize backend: device %d is %s, this backend is built for gfx950 (MI355X) only", device_index, arch);
+    auto* d = new backend_device;
+    d->index = device_index;
+    d->name = std::string("HIP") + std::to_string(device_index);
+    d->description = std::string(name) + " (" + arch + ")";
+    d->total_mem = total;
+    d->n_cu = n_cu;
+    VX(vx_stream_create(&d->stream));
+    return d;
+}
+backend_device::~backend_device() {
+    if (stream) vx_stream_destroy(stream);
+}
+
+//
+// params (reference dino.cpp:119-126, depth-anything.cpp:112-128)
+
+dino_params dino_detect_params(model_file const& file) {
+    dino_params p{};
+    p.patch_size = file.get_int("dino.patch_size");
+    p.embed_dim = file.get_int("dino.embed_dim");
+    p.n_heads = file.get_int("dino.n_heads");
+    p.n_layers = file.get_int("dino.n_layers");
+    return p;
+}
+depthany_params depthany_detect_params(model_file const& file) {
+    depthany_params p;
+    p.dino = dino_detect_params(file);
+    p.image_size = file.get_int("depthanything.image_size");
+    file.get_array("depthanything.feature_layers", p.feature_layers.data(), 4);
+    return p;
+}
+i32x2 depthany_image_extent(i32x2 extent, depthany_params const& p) {
+    int min_side = std::min(extent[0], extent[1]);
+    int tgt_side = std::max(p.image_size, next_multiple(min_side, p.image_multiple));
+    i32x2 target = {{extent[0] * tgt_side / min_side, extent[1] * tgt_side / min_side}};
+    return i32x2{{next_multiple(target[0], p.image_multiple), next_multiple(target[1], p.image_multiple)}};
+}
+
+//
+// weight packing: the counterpart of model_transfer (reference src/visp/ml.cpp:449-516).
+// The reference converts f16->f32 and WHCN->CWHN for its CPU backend; this backend keeps f16
+// (the file's type) for matrix operands, converts small vectors to f32, and lays every matrix
+// out as [N][K] row-major with k = (ky, kx, cin) -- i.e. CWHN kernels flattened.
+
+namespace {
+
+struct arena_builder {
+    std::vector<uint8_t> data;
+    size_t alloc(size_t bytes) {
+        size_t off = round_up<size_t>(data.size(), 256);
+        data.resize(off + bytes, 0);
+        return off;
+    }
+};
+
+std::vector<float> to_f32(gguf_tensor const& t) {
+    std::vector<float> out((size_t)t.n_elements());
+    if (!t.data) throw except("tensor %s has no data (header-only load)", t.name.c_str());
+    if (t.type == GGML_F32) memcpy(out.data(), t.data, out.size() * 4);
+    else if (t.type == GGML_F16) {
+        const uint16_t* s = reinterpret_cast<const uint16_t*>(t.data);
+        for (size_t i = 0; i < out.size(); ++i) out[i] = f16_to_f32(s[i]);
+    } else throw except("tensor %s: unsupported type %d", t.name.c_str(), t.type);
+    return out;
+}
+
+struct packer {
+    model_file const& file;
+    arena_builder& ab;
+    bool with_data;
+    bool file_whcn;
+    std::vector<int32_t> conv2d;
+
+    packer(model_file const& f, arena_builder& a, bool data)
+        : file(f), ab(a), with_data(data), file_whcn(f.tensor_layout() == layout_whcn), conv2d(f.conv2d_weights()) {}
+
+    bool is_listed_conv2d(std::string_view name) const {
+        auto it = file.index.find(name);
+        return it != file.index.end() && std::binary_search(conv2d.begin(), conv2d.end(), it->second);
+    }
+
+    packed_vec vec(std::string const& name) {
+        gguf_tensor const& t = file.tensor(name);
+        packed_vec v;
+        v.n = (int)t.n_elements();
+        v.off = ab.alloc((size_t)v.n * 4);
+        if (with_data) {
+            std::vector<float> f = to_f32(t);
+            memcpy(ab.data.data() + v.off, f.data(), f.size() * 4);
+        }
+        return v;
+    }
+
+    // rows[n_real][k_real] f32 -> f16 [N][K] zero padded; bias f32 [N] zero padded
+    packed_gemm matrix(const float* rows, int n_real, int k_real, const float* bias, int n_bias, int n_align) {
+        packed_gemm g;
+        g.n_real = n_real;
+        g.k_real = k_real;
+        g.N = round_up(n_real, n_align);
+        g.K = round_up(k_real, 64);
+        g.w = ab.alloc((size_t)g.N * g.K * 2);
+        if (with_data && rows) {
+            uint16_t* w = reinterpret_cast<uint16_t*>(ab.data.data() + g.w);
+            for (int n = 0; n < n_real; ++n)
+                for (int k = 0; k < k_real; ++k) w[(size_t)n * g.K + k] = f32_to_f16(rows[(size_t)n * k_real + k]);
+        }
+        if (n_bias > 0) {
+            g.b = ab.alloc((size_t)g.N * 4);
+            if (with_data && bias) memcpy(ab.data.data() + g.b, bias, (size_t)n_bias * 4);
+        }
+        return g;
+    }
+
+    // linear(): weight ggml ne [K, N] == torch [N][K] (reference nn.cpp:6-12)
+    packed_gemm linear(std::string const& prefix, int n_align = 32) {
+        gguf_tensor const& w = file.tensor(prefix + ".weight");
+        gguf_tensor const* b = file.find(prefix + ".bias");
+        int K = (int)w.ne[0], N = (int)w.ne[1];
+        std::vector<float> wf, bf;
+        if (with_data) {
+            wf = to_f32(w);
+            if (b) bf = to_f32(*b);
+        }
+        return matrix(with_data ? wf.data() : nullptr, N, K, b && with_data ? bf.data() : nullptr, b ? N : 0, n_align);
+    }
+
+    // three linears concatenated along N (fused QKV projection)
+    packed_gemm linear3(std::string const& a, std::string const& b, std::string const& c) {
+        gguf_tensor const& wa = file.tensor(a + ".weight");
+        int K = (int)wa.ne[0], N = (int)wa.ne[1];
+        std::vector<float> rows, bias;
+        if (with_data) {
+            for (std::string const* p : {&a, &b, &c}) {
+                gguf_tensor const& w = file.tensor(*p + ".weight");
+                if (w.ne[0] != K || w.ne[1] != N) throw except("qkv weights of %s differ in shape", p->c_str());
+                std::vector<float> wf = to_f32(w), bf = to_f32(file.tensor(*p + ".bias"));
+                rows.insert(rows.end(), wf.begin(), wf.end());
+                bias.insert(bias.end(), bf.begin(), bf.end());
+            }
+        }
+        return matrix(with_data ? rows.data() : nullptr, 3 * N, K, with_data ? bias.data() : nullptr, 3 * N, 32);
+    }
+
+    // conv kernel as [Cout][kh][kw][Cin] f32. A tensor listed in <arch>.conv2d_weights of a WHCN
+    // file is stored [kw,kh,Cin,Cout] (torch OIHW) and permuted here, exactly the tensors
+    // model_transfer permutes (ml.cpp:462-502); anything else is already CWHN [Cin,kw,kh,Cout].
+    std::vector<float> conv_ohwi(std::string const& name, int& cout, int& kh, int& kw, int& cin) {
+        gguf_tensor const& t = file.tensor(name);
+        bool permute = file_whcn && is_listed_conv2d(name);
+        if (permute) { kw = (int)t.ne[0]; kh = (int)t.ne[1]; cin = (int)t.ne[2]; cout = (int)t.ne[3]; }
+        else { cin = (int)t.ne[0]; kw = (int)t.ne[1]; kh = (int)t.ne[2]; cout = (int)t.ne[3]; }
+        if (!with_data) return {};
+        std::vector<float> src = to_f32(t);
+        if (!permute) return src;
+        std::vector<float> dst(src.size());
+        for (int o = 0; o < cout; ++o)
+            for (int c = 0; c < cin; ++c)
+                for (int y = 0; y < kh; ++y)
+                    for (int x = 0; x < kw; ++x)
+                        dst[(((size_t)o * kh + y) * kw + x) * cin + c] = src[(((size_t)o * cin + c) * kh + y) * kw + x];
+        return dst;
+    }
+
+    packed_gemm conv(std::string const& prefix, int n_align = 32, int* out_k = nullptr, int* out_cin = nullptr) {
+        int cout, kh, kw, cin;
+        std::vector<float> w = conv_ohwi(prefix + ".weight", cout, kh, kw, cin);
+        gguf_tensor const* b = file.find(prefix + ".bias");
+        std::vector<float> bf;
+        if (b && with_data) bf = to_f32(*b);
+        if (out_k) *out_k = kh;
+        if (out_cin) *out_cin = cin;
+        return matrix(with_data ? w.data() : nullptr, cout, kh * kw * cin, b && with_data ? bf.data() : nullptr, b ? cout : 0, n_align);
+    }
+
+    // conv_transpose_2d with kernel == stride (reference nn.cpp:117-129, weight ne [kw,kh,Cout,Cin] ==
+    // torch [Cin][Cout][kh][kw], never permuted: convert.py:466-467). Row n = (dy*s+dx)*Cout + co.
+    packed_gemm conv_transpose(std::string const& prefix, int stride, int k_pad_to) {
+        gguf_tensor const& t = file.tensor(prefix + ".weight");
+        int kw = (int)t.ne[0], kh = (int)t.ne[1], cout = (int)t.ne[2], cin = (int)t.ne[3];
+        if (kw != stride || kh != stride) throw except("%s: conv_transpose kernel %dx%d != stride %d is not supported", prefix.c_str(), kw, kh, stride);
+        gguf_tensor const* b = file.find(prefix + ".bias");
+        int n_real = stride * stride * cout;
+        std::vector<float> rows, bias;
+        if (with_data) {
+            std::vector<float> src = to_f32(t);
+            rows.assign((size_t)n_real * k_pad_to, 0.0f);
+            for (int ci = 0; ci < cin; ++ci)
+                for (int co = 0; co < cout; ++co)
+                    for (int dy = 0; dy < kh; ++dy)
+                        for (int dx = 0; dx < kw; ++dx)
+                            rows[((size_t)(dy * stride + dx) * cout + co) * k_pad_to + ci] = src[(((size_t)ci * cout + co) * kh + dy) * kw + dx];
+            if (b) {
+                std::vector<float> bf = to_f32(*b);
+                bias.resize(n_real);
+                for (int n = 0; n < n_real; ++n) bias[n] = bf[n % cout];
+            }
+        }
+        return matrix(with_data ? rows.data() : nullptr, n_real, k_pad_to, b && with_data ? bias.data() : nullptr, b ? n_real : 0, 32);
+    }
+};
+
+} // namespace
+
+depthany_model* depthany_load_model(char const* filepath, backend_device const& dev, int flags) {
+    const bool with_data = !(flags & load_no_upload);
+    model_file file = model_load(filepath, /*header_only=*/!with_data);
+    if (file.arch() != "depthanything")
+        throw except("Model %s has architecture '%.*s', expected 'depthanything'", filepath, (int)file.arch().size(), file.arch().data());
+
+    auto model = std::make_unique<depthany_model>();
+    model->backend = &dev;
+    model->params = depthany_detect_params(file);
+    depthany_params const& P = model->params;
+    const int D = P.dino.embed_dim;
+    if (D % P.dino.n_heads != 0 || D / P.dino.n_heads != 64)
+        throw except("Unsupported DINO head dim %d (this backend implements head_dim 64)", P.dino.n_heads ? D / P.dino.n_heads : 0);
+    if (D % 128 != 0) throw except("Unsupported embed dim %d (must be a multiple of 128)", D);
+
+    arena_builder ab;
+    packer pk(file, ab, with_data);
+    depthany_weights& Wt = model->weights;
+
+    const std::string e = "backbone.embeddings";
+    {
+        // patch embed: stored NHWC [Cout][ps][ps][3] (convert.py:463-465), flattened k = (ky,kx,c)
+        int k, cin;
+        Wt.patch = pk.conv(e + ".patch_embeddings.projection", 128, &k, &cin);
+        if (k != P.dino.patch_size || cin != 3) throw except("patch embedding kernel %dx%dx%d does not match patch size %d", k, k, cin, P.dino.patch_size);
+        Wt.cls = pk.vec(e + ".cls_token");
+        Wt.pos = pk.vec(e + ".position_embeddings");
+        Wt.pos_tokens = (int)file.tensor(e + ".position_embeddings").ne[1];
+    }
+    Wt.layers.resize(P.dino.n_layers);
+    for (int i = 0; i < P.dino.n_layers; ++i) {
+        std::string p = "backbone.encoder.layer." + std::to_string(i);
+        dino_layer_weights& L = Wt.layers[i];
+        L.ln1_w = pk.vec(p + ".norm1.weight");
+        L.ln1_b = pk.vec(p + ".norm1.bias");
+        L.qkv = pk.linear3(p + ".attention.attention.query", p + ".attention.attention.key", p + ".attention.attention.value");
+        L.out = pk.linear(p + ".attention.output.dense");
+        L.lambda1 = pk.vec(p + ".layer_scale1.lambda1");
+        L.ln2_w = pk.vec(p + ".norm2.weight");
+        L.ln2_b = pk.vec(p + ".norm2.bias");
+        L.fc1 = pk.linear(p + ".mlp.fc1");
+        L.fc2 = pk.linear(p + ".mlp.fc2");
+        L.lambda2 = pk.vec(p + ".layer_scale2.lambda1");
+    }
+    Wt.final_ln_w = pk.vec("backbone.layernorm.weight");
+    Wt.final_ln_b = pk.vec("backbone.layernorm.bias");
+
+    const std::string r = "neck.reassemble_stage.layers.";
+    for (int i = 0; i < 4; ++i) {
+        Wt.re_proj[i] = pk.conv(r + std::to_string(i) + ".projection", 64);
+        Wt.neck_c[i] = Wt.re_proj[i].n_real;
+    }
+    Wt.re_up0 = pk.conv_transpose(r + "0.resize", 4, Wt.re_proj[0].N);
+    Wt.re_up1 = pk.conv_transpose(r + "1.resize", 2, Wt.re_proj[1].N);
+    Wt.re_down3 = pk.conv(r + "3.resize");
+    if (Wt.neck_c[0] % 8 || Wt.neck_c[1] % 8 || Wt.neck_c[2] % 64 || Wt.neck_c[3] % 64)
+        throw except("Unsupported neck channel counts %d/%d/%d/%d", Wt.neck_c[0], Wt.neck_c[1], Wt.neck_c[2], Wt.neck_c[3]);
+    for (int i = 0; i < 4; ++i) Wt.neck_conv[i] = pk.conv("neck.convs." + std::to_string(i));
+    Wt.fusion_c = Wt.neck_conv[0].n_real;
+    for (int i = 0; i < 4; ++i) {
+        std::string p = "neck.fusion_stage.layers." + std::to_string(i);
+        fusion_weights& F = Wt.fusion[i];
+        F.proj = pk.conv(p + ".projection");
+        // residual_layer1 of fusion layer 0 exists in the file but is never executed
+        // (reference depth-anything.cpp:27-30, 74); it is packed anyway to keep the arena layout uniform
+        F.rl1_c1 = pk.conv(p + ".residual_layer1.convolution1");
+        F.rl1_c2 = pk.conv(p + ".residual_layer1.convolution2");
+        F.rl2_c1 = pk.conv(p + ".residual_layer2.convolution1");
+        F.rl2_c2 = pk.conv(p + ".residual_layer2.convolution2");
+    }
+    if (Wt.fusion_c % 32) throw except("Unsupported fusion width %d", Wt.fusion_c);
+    Wt.head1 = pk.conv("head.conv1");
+    Wt.head2 = pk.conv("head.conv2");
+    Wt.head_c = Wt.head1.n_real;
+    if (Wt.head_c != 8 && Wt.head_c != 16 && Wt.head_c != 32 && Wt.head_c != 64) throw except("Unsupported head width %d", Wt.head_c);
+    Wt.head3_w = pk.vec("head.conv3.weight");
+    // the scalar bias of the final 1x1 conv lives in the arena too, so that an arena received by
+    // RCCL broadcast is self-contained (depthany_weights_ready reads it back)
+    Wt.head3_b_off = ab.alloc(16);
+    if (with_data) {
+        Wt.head3_b = to_f32(file.tensor("head.conv3.bias"))[0];
+        memcpy(ab.data.data() + Wt.head3_b_off, &Wt.head3_b, 4);
+    }
+
+    VX(vx_set_device(dev.index));
+    model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256);
+    VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
+    if (with_data) {
+        VX(vx_memcpy_h2d(model->weight_arena.ptr, ab.data.data(), ab.data.size(), dev.stream));
+        VX(vx_stream_sync(dev.stream));
+        model->weights_uploaded = true;
+    }
+    return model.release();
+}
+
+void depthany_weights_ready(depthany_model& m) {
+    VX(vx_set_device(m.backend->index));
+    VX(vx_memcpy_d2h(&m.weights.head3_b, static_cast<const uint8_t*>(m.weight_arena.ptr) + m.weights.head3_b_off, 4, m.backend->stream));
+    m.weights_uploaded = true;
+}
+
+depthany_model::~depthany_model() {
+    if (ws.graph_exec) vx_graph_destroy(ws.graph_exec);
+    for (auto& c : capture_bufs) vx_free(c.second.dev);
+    vx_free(ws.arena.ptr);
+    vx_free(weight_arena.ptr);
+}
+
+//
+// workspace
+
+namespace {
+
+struct ws_layout {
+    size_t total = 0;
+    std::vector<std::pair<std::string, std::pair<size_t, size_t>>> items;
+    void add(std::string name, size_t bytes) {
+        size_t off = round_up<size_t>(total, 256);
+        items.push_back({std::move(name), {off, bytes}});
+        total = off + bytes;
+    }
+};
+
+// bicubic (a = -0.75, half-pixel centres, clamped taps) resize of the patch position embeddings,
+// the host-side counterpart of dino::interpolate_pos_encoding (reference dino.cpp:10-30)
+void interpolate_pos(const float* pos /*[1+n, D]*/, int n_side, int D, int th, int tw, float* out /*[1+th*tw, D]*/) {
+    memcpy(out, pos, (size_t)D * 4);
+    const float* src = pos + D;
+    auto coeffs = [](float t, float c[4]) {
+        const float a = -0.75f;
+        float x;
+        x = t + 1.0f; c[0] = ((a * x - 5.0f * a) * x + 8.0f * a) * x - 4.0f * a;
+        x = t;        c[1] = ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+        x = 1.0f - t; c[2] = ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+        x = 2.0f - t; c[3] = ((a * x - 5.0f * a) * x + 8.0f * a) * x - 4.0f * a;
+    };
+    float sfy = (float)th / (float)n_side, sfx = (float)tw / (float)n_side;
+    for (int oy = 0; oy < th; ++oy) {
+        float sy = ((float)oy + 0.5f) / sfy - 0.5f;
+        int iy = (int)std::floor(sy);
+        float cy[4];
+        coeffs(sy - (float)iy, cy);
+        for (int ox = 0; ox < tw; ++ox) {
+            float sx = ((float)ox + 0.5f) / sfx - 0.5f;
+            int ix = (int)std::floor(sx);
+            float cx[4];
+            coeffs(sx - (float)ix, cx);
+            float* o = out + ((size_t)1 + (size_t)oy * tw + ox) * D;
+            for (int d = 0; d < D; ++d) o[d] = 0.0f;
+            for (int j = 0; j < 4; ++j) {
+                int yy = std::clamp(iy - 1 + j, 0, n_side - 1);
+                for (int i = 0; i < 4; ++i) {
+                    int xx = std::clamp(ix - 1 + i, 0, n_side - 1);
+                    float wgt = cy[j] * cx[i];
+                    const float* s = src + ((size_t)yy * n_side + xx) * D;
+                    for (int d = 0; d < D; ++d) o[d] += wgt * s[d];
+                }
+            }
+        }
+    }
+}
+
+} // namespace
+
+void depthany_reserve(depthany_model& m, int B, int W, int H) {
+    depthany_params const& P = m.params;
+    depthany_weights const& Wt = m.weights;
+    const int ps = P.dino.patch_size;
+    if (B <= 0 || W <= 0 || H <= 0) throw except("depthany: invalid batch/extent %d x %dx%d", B, W, H);
+    if (W % ps || H % ps) throw except("depthany: extent %dx%d is not a multiple of the patch size %d", W, H, ps);
+    if (m.ws.B == B && m.ws.W == W && m.ws.H == H && m.ws.arena.ptr) return;
+
+    const int pw = W / ps, ph = H / ps, Pn = pw * ph, T = Pn + 1, D = P.dino.embed_dim, Hh = P.dino.n_heads;
+    const long M = (long)B * T;
+    const int Tp = round_up(T, 64);
+    const int F = Wt.fusion_c, HC = Wt.head_c;
+    const int h3 = (ph + 2 - 3) / 2 + 1, w3 = (pw + 2 - 3) / 2 + 1;
+
+    ws_layout L;
+    L.add("rgb", (size_t)B * H * W * 3);
+    L.add("patches", (size_t)B * Pn * Wt.patch.K * 2);
+    L.add("pos", (size_t)T * D * 4);
+    L.add("x", (size_t)M * D * 4);
+    L.add("ln", (size_t)M * D * 2);
+    L.add("q", (size_t)M * D * 2);
+    L.add("k", (size_t)M * D * 2);
+    L.add("vt", (size_t)B * Hh * 64 * Tp * 2);
+    L.add("att", (size_t)M * D * 2);
+    L.add("hidden", (size_t)M * Wt.layers[0].fc1.N * 2);
+    for (int j = 0; j < 4; ++j) L.add("feat" + std::to_string(j), (size_t)M * D * 2);
+    for (int j = 0; j < 4; ++j) L.add("r" + std::to_string(j), (size_t)B * Pn * Wt.re_proj[j].N * 2);
+    L.add("l0", (size_t)B * 16 * Pn * Wt.neck_c[0] * 2);
+    L.add("l1", (size_t)B * 4 * Pn * Wt.neck_c[1] * 2);
+    L.add("l3", (size_t)B * h3 * w3 * Wt.neck_c[3] * 2);
+    L.add("c0", (size_t)B * 16 * Pn * F * 2);
+    L.add("c1", (size_t)B * 4 * Pn * F * 2);
+    L.add("c2", (size_t)B * Pn * F * 2);
+    L.add("c3", (size_t)B * h3 * w3 * F * 2);
+    for (const char* n : {"t1", "t2", "t3"}) L.add(n, (size_t)B * 16 * Pn * F * 2);
+    L.add("up", (size_t)B * 64 * Pn * F * 2);
+    L.add("fused", (size_t)B * 64 * Pn * F * 2);
+    L.add("h1", (size_t)B * 64 * Pn * HC * 2);
+    L.add("hup", (size_t)B * H * W * HC * 2);
+    L.add("h2", (size_t)B * H * W * HC * 2);
+    L.add("depth", (size_t)B * H * W * 4);
+    L.add("out", (size_t)B * H * W * 4);
+    L.add("minmax", (size_t)B * 2 * 4);
+
+    VX(vx_set_device(m.backend->index));
+    if (m.ws.graph_exec) { vx_graph_destroy(m.ws.graph_exec); m.ws.graph_exec = nullptr; }
+    if (m.ws.arena.bytes < L.total) {
+        VX(vx_free(m.ws.arena.ptr));
+        m.ws.arena = {};
+        VX(vx_malloc(&m.ws.arena.ptr, L.total));
+        m.ws.arena.bytes = L.total;
+    }
+    m.ws.buf.clear();
+    for (auto& it : L.items) m.ws.buf[it.first] = static_cast<uint8_t*>(m.ws.arena.ptr) + it.second.first;
+    m.ws.B = B; m.ws.W = W; m.ws.H = H;
+    void* s = m.backend->stream;
+    // v^T pad columns must stay finite: zero once (the QKV epilogue never writes them)
+    VX(vx_memset(m.ws.buf["vt"], 0, (size_t)B * Hh * 64 * Tp * 2, s));
+
+    // position embeddings for this grid (dino.cpp:10-30): as stored, or bicubic-resized on the host
+    const uint8_t* wa = static_cast<const uint8_t*>(m.weight_arena.ptr);
+    if (T == Wt.pos_tokens && W == H) {
+        VX(vx_memcpy_d2d(m.ws.buf["pos"], wa + Wt.pos.off, (size_t)T * D * 4, s));
+    } else {
+        int n = Wt.pos_tokens - 1;
+        int n_side = (int)(std::sqrt((float)n) + 0.01f);
+        std::vector<float> stored((size_t)Wt.pos_tokens * D), resized((size_t)T * D);
+        VX(vx_memcpy_d2h(stored.data(), wa + Wt.pos.off, stored.size() * 4, s));
+        interpolate_pos(stored.data(), n_side, D, ph, pw, resized.data());
+        VX(vx_memcpy_h2d(m.ws.buf["pos"], resized.data(), resized.size() * 4, s));
+    }
+    VX(vx_stream_sync(s));
+}
+
+//
+// executor
+
+namespace {
+
+struct exec_ctx {
+    depthany_model& m;
+    void* stream;
+    const uint8_t* wa;
+    std::vector<std::pair<std::string, void*>> marks; // timing
+    std::vector<timing_entry> acc;
+
+    const void* wptr(size_t off) const { return wa + off; }
+    const float* fptr(packed_vec const& v) const { return reinterpret_cast<const float*>(wa + v.off); }
+    void* buf(const char* name) { return m.ws.buf.at(name); }
+
+    void mark(const char* name, int launches, double flops, double bytes) {
+        if (!m.timing) return;
+        void* ev = nullptr;
+        VX(vx_event_create(&ev));
+        VX(vx_event_record(ev, stream));
+        marks.push_back({name, ev});
+        acc.push_back({name, 0, launches, flops, bytes});
+    }
+    void finish_timing() {
+        if (!m.timing) return;
+        void* ev = nullptr;
+        VX(vx_event_create(&ev));
+        VX(vx_event_record(ev, stream));
+        marks.push_back({"end", ev});
+        std::map<std::string, timing_entry> by;
+        std::vector<std::string> order;
+        for (size_t i = 0; i + 1 < marks.size(); ++i) {
+            float ms = 0;
+            VX(vx_event_elapsed_ms(marks[i].second, marks[i + 1].second, &ms));
+            auto it = by.find(marks[i].first);
+            if (it == by.end()) { order.push_back(marks[i].first); it = by.emplace(marks[i].first, timing_entry{marks[i].first, 0, 0, 0, 0}).first; }
+            it->second.ms += ms;
+            it->second.launches += acc[i].launches;
+            it->second.flops += acc[i].flops;
+            it->second.bytes += acc[i].bytes;
+        }
+        m.last_timing.clear();
+        for (auto& n : order) m.last_timing.push_back(by[n]);
+        for (auto& mk : marks) vx_event_destroy(mk.second);
+        marks.clear();
+    }
+
+    void capture(const char* name, const void* dev, std::array<int64_t, 4> shape, bool f16) {
+        if (!m.captures) return;
+        size_t n = (size_t)(shape[0] * shape[1] * shape[2] * shape[3]);
+        size_t bytes = n * (f16 ? 2 : 4);
+        capture_entry& c = m.capture_bufs[name];
+        if (c.dev) vx_free(c.dev);
+        VX(vx_malloc(&c.dev, bytes));
+        VX(vx_memcpy_d2d(c.dev, dev, bytes, stream));
+        for (int i = 0; i < 4; ++i) c.shape[i] = shape[i];
+        c.f16 = f16;
+    }
+
+    vx_gemm_args base(packed_gemm const& g, long M) {
+        vx_gemm_args a;
+        memset(&a, 0, sizeof a);
+        a.W = wptr(g.w);
+        a.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b);
+        a.M = (int)M;
+        a.N = g.N;
+        a.K = g.K;
+        a.n_valid = g.n_real;
+        return a;
+    }
+    void gemm(vx_gemm_args const& a) { VX(vx_gemm_f16(&a, stream)); }
+
+    // NHWC 3x3 (or kxk) convolution as implicit GEMM
+    void conv(packed_gemm const& g, const void* x, int B, int H, int W, int Cin, int k, int stride, int pad, void* y, int ldo,
+              int epi, bool a_relu, bool relu, const void* res1, const void* res2, const char* group) {
+        int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+        long M = (long)B * OH * OW;
+        vx_gemm_args a = base(g, M);
+        a.A = x;
+        a.conv_kh = a.conv_kw = k;
+        a.conv_stride = stride;
+        a.conv_pad = pad;
+        a.conv_H = H; a.conv_W = W; a.conv_Cin = Cin; a.conv_OH = OH; a.conv_OW = OW;
+        a.a_relu = a_relu;
+        a.epi = epi;
+        a.relu = relu;
+        a.out = y;
+        a.ldo = ldo;
+        a.res1 = res1; a.res2 = res2;
+        mark(group, 1, 2.0 * M * g.n_real * g.k_real, (double)B * H * W * Cin * 2 + (double)M * g.n_real * 2 + (double)g.N * g.K * 2);
+        gemm(a);
+    }
+};
+
+} // namespace
+
+static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void* raw_out_dev, void* stream) {
+    depthany_params const& P = m.params;
+    depthany_weights const& Wt = m.weights;
+    const int B = m.ws.B, W = m.ws.W, H = m.ws.H;
+    const int ps = P.dino.patch_size, pw = W / ps, ph = H / ps, Pn = pw * ph, T = Pn + 1, D = P.dino.embed_dim, NH = P.dino.n_heads;
+    const long M = (long)B * T, MP = (long)B * Pn;
+    const int Tp = round_up(T, 64);
+    const int F = Wt.fusion_c, HC = Wt.head_c;
+    exec_ctx c{m, stream, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
+
+    float* x = static_cast<float*>(c.buf("x"));
+    void* ln = c.buf("ln");
+    const float* pos = static_cast<const float*>(c.buf("pos"));
+
+    // ---- depthany_process_input (depth-anything.cpp:130-140) fused with the patch im2col
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float inv_std[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
+    c.mark("preprocess", 2, 0, (double)B * H * W * 3 + (double)MP * Wt.patch.K * 2);
+    VX(vx_preprocess_patches(static_cast<const uint8_t*>(rgb), c.buf("patches"), B, H, W, ps, Wt.patch.K, mean, inv_std, stream));
+    VX(vx_write_cls_rows(x, c.fptr(Wt.cls), pos, B, T, D, stream));
+
+    // ---- dino::prepare_tokens (dino.cpp:32-46): patch GEMM, epilogue adds bias + pos-embed, writes token rows
+    {
+        vx_gemm_args a = c.base(Wt.patch, MP);
+        a.A = c.buf("patches");
+        a.lda = Wt.patch.K;
+        a.epi = VX_EPI_TOKENS;
+        a.out = x;
+        a.ldo = D;
+        a.pos = pos;
+        a.tokens_P = Pn;
+        c.mark("patch_embed", 1, 2.0 * MP * D * Wt.patch.k_real, (double)MP * Wt.patch.K * 2 + (double)M * D * 4);
+        c.gemm(a);
+    }
+    c.capture("tokens", x, {B, T, D, 1}, false);
+
+    // ---- dino::layer x n_layers (dino.cpp:76-90)
+    const float q_scale = 1.0f / std::sqrt((float)D / (float)NH);
+    int tap = 0;
+    for (int i = 0; i < P.dino.n_layers; ++i) {
+        dino_layer_weights const& L = Wt.layers[i];
+        c.mark("layernorm", 1, 0, (double)M * D * 6);
+        VX(vx_layernorm_f32_f16(x, c.fptr(L.ln1_w), c.fptr(L.ln1_b), ln, (int)M, D, 1e-6f, stream));
+        {
+            vx_gemm_args a = c.base(L.qkv, M);
+            a.A = ln; a.lda = D;
+            a.epi = VX_EPI_QKV;
+            a.q = c.buf("q"); a.k = c.buf("k"); a.vt = c.buf("vt");
+            a.qkv_T = T; a.qkv_Tp = Tp; a.qkv_H = NH;
+            a.q_scale = q_scale;
+            c.mark("gemm_qkv", 1, 2.0 * M * 3 * D * D, (double)M * D * 2 * 4 + 3.0 * D * D * 2);
+            c.gemm(a);
+        }
+        c.mark("attention", 1, 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
+        VX(vx_attention_f16(c.buf("q"), c.buf("k"), c.buf("vt"), c.buf("att"), B, NH, T, Tp, stream));
+        {
+            vx_gemm_args a = c.base(L.out, M);
+            a.A = c.buf("att"); a.lda = D;
+            a.epi = VX_EPI_RESID_F32;
+            a.out = x; a.ldo = D;
+            a.lambda = c.fptr(L.lambda1);
+            c.mark("gemm_out", 1, 2.0 * M * D * D, (double)M * D * (2 + 8) + (double)D * D * 2);
+            c.gemm(a);
+        }
+        c.mark("layernorm", 1, 0, (double)M * D * 6);
+        VX(vx_layernorm_f32_f16(x, c.fptr(L.ln2_w), c.fptr(L.ln2_b), ln, (int)M, D, 1e-6f, stream));
+        {
+            vx_gemm_args a = c.base(L.fc1, M);
+            a.A = ln; a.lda = D;
+            a.epi = VX_EPI_F16_GELU;
+            a.out = c.buf("hidden"); a.ldo = L.fc1.N;
+            c.mark("gemm_fc1", 1, 2.0 * M * L.fc1.n_real * D, (double)M * (D + L.fc1.N) * 2 + (double)L.fc1.N * D * 2);
+            c.gemm(a);
+        }
+        {
+            vx_gemm_args a = c.base(L.fc2, M);
+            a.A = c.buf("hidden"); a.lda = L.fc1.N;
+            a.epi = VX_EPI_RESID_F32;
+            a.out = x; a.ldo = D;
+            a.lambda = c.fptr(L.lambda2);
+            c.mark("gemm_fc2", 1, 2.0 * M * D * L.fc2.k_real, (double)M * (L.fc1.N * 2 + D * 8) + (double)L.fc2.K * D * 2);
+            c.gemm(a);
+        }
+        if (m.captures) { std::string nm = "layer_" + std::to_string(i); c.capture(nm.c_str(), x, {B, T, D, 1}, false); }
+        // get_intermediate_layers (dino.cpp:100-107): shared final layernorm on the tapped layers
+        for (int f = 0; f < 4; ++f)
+            if (P.feature_layers[f] == i && tap < 4) {
+                std::string fb = "feat" + std::to_string(tap);
+                c.mark("layernorm", 1, 0, (double)M * D * 6);
+                VX(vx_layernorm_f32_f16(x, c.fptr(Wt.final_ln_w), c.fptr(Wt.final_ln_b), c.buf(fb.c_str()), (int)M, D, 1e-6f, stream));
+                if (m.captures) { std::string nm = "dino_layer_" + std::to_string(i); c.capture(nm.c_str(), c.buf(fb.c_str()), {B, T, D, 1}, true); }
+                ++tap;
+            }
+    }
+    if (tap != 4) throw except("depthany: expected 4 feature layers, found %d", tap);
+
+    // ---- dpt::neck reassemble (depth-anything.cpp:44-64)
+    const int lh[4] = {4 * ph, 2 * ph, ph, (ph + 2 - 3) / 2 + 1};
+    const int lw[4] = {4 * pw, 2 * pw, pw, (pw + 2 - 3) / 2 + 1};
+    const void* lay[4];
+    for (int j = 0; j < 4; ++j) {
+        std::string fb = "feat" + std::to_string(j), rb = "r" + std::to_string(j);
+        vx_gemm_args a = c.base(Wt.re_proj[j], MP);
+        a.A = c.buf(fb.c_str()); a.lda = D;
+        a.a_group = Pn; a.a_group_stride = T; a.a_row_off = 1; // slice off the cls token (depth-anything.cpp:50)
+        a.epi = VX_EPI_F16;
+        a.out = c.buf(rb.c_str()); a.ldo = Wt.re_proj[j].N;
+        a.n_valid = Wt.re_proj[j].N; // pad columns are exact zeros and feed the next GEMM's padded K
+        c.mark("neck_proj", 1, 2.0 * MP * Wt.neck_c[j] * D, (double)MP * (D + Wt.re_proj[j].N) * 2);
+        c.gemm(a);
+    }
+    {
+        vx_gemm_args a = c.base(Wt.re_up0, MP); // conv_transpose k4 s4 as GEMM + pixel shuffle
+        a.A = c.buf("r0"); a.lda = Wt.re_proj[0].N;
+        a.epi = VX_EPI_PIXSHUF;
+        a.out = c.buf("l0"); a.ldo = Wt.neck_c[0];
+        a.ps_s = 4; a.ps_Cout = Wt.neck_c[0]; a.ps_H = ph; a.ps_W = pw;
+        c.mark("neck_convT", 1, 2.0 * MP * Wt.re_up0.n_real * Wt.neck_c[0], (double)MP * Wt.re_up0.n_real * 2);
+        c.gemm(a);
+        lay[0] = c.buf("l0");
+    }
+    {
+        vx_gemm_args a = c.base(Wt.re_up1, MP);
+        a.A = c.buf("r1"); a.lda = Wt.re_proj[1].N;
+        a.epi = VX_EPI_PIXSHUF;
+        a.out = c.buf("l1"); a.ldo = Wt.neck_c[1];
+        a.ps_s = 2; a.ps_Cout = Wt.neck_c[1]; a.ps_H = ph; a.ps_W = pw;
+        c.mark("neck_convT", 1, 2.0 * MP * Wt.re_up1.n_real * Wt.neck_c[1], (double)MP * Wt.re_up1.n_real * 2);
+        c.gemm(a);
+        lay[1] = c.buf("l1");
+    }
+    lay[2] = c.buf("r2");
+    c.conv(Wt.re_down3, c.buf("r3"), B, ph, pw, Wt.neck_c[3], 3, 2, 1, c.buf("l3"), Wt.neck_c[3], VX_EPI_F16, false, false, nullptr, nullptr, "neck_conv_s2");
+    lay[3] = c.buf("l3");
+    for (int j = 0; j < 4; ++j)
+        if (m.captures) { std::string nm = "reassemble_" + std::to_string(j); c.capture(nm.c_str(), lay[j], {B, lh[j], lw[j], Wt.neck_c[j]}, true); }
+
+    // ---- neck.convs (depth-anything.cpp:66-69): 3x3, no bias, -> F channels
+    void* cb[4] = {c.buf("c0"), c.buf("c1"), c.buf("c2"), c.buf("c3")};
+    for (int j = 0; j < 4; ++j) {
+        c.conv(Wt.neck_conv[j], lay[j], B, lh[j], lw[j], Wt.neck_c[j], 3, 1, 1, cb[j], F, VX_EPI_F16, false, false, nullptr, nullptr, "neck_convs");
+        if (m.captures) { std::string nm = "neck_conv_" + std::to_string(j); c.capture(nm.c_str(), cb[j], {B, lh[j], lw[j], F}, true); }
+    }
+
+    // ---- fusion stage (depth-anything.cpp:25-42, 71-77)
+    void *t1 = c.buf("t1"), *t2 = c.buf("t2"), *t3 = c.buf("t3"), *up = c.buf("up"), *fused = c.buf("fused");
+    const void* prev = nullptr; // output of the previous fusion layer (lives in `fused`)
+    for (int i = 0; i < 4; ++i) {
+        fusion_weights const& FW = Wt.fusion[i];
+        const int j = 3 - i; // feature consumed at this stage
+        const int h = lh[j], w = lw[j];
+        const void* xin;
+        if (i == 0) {
+            xin = cb[3];
+        } else {
+            // x = x0 + residual_layer1(x1) with x0 = prev, x1 = c_j:  t2 = conv2(relu(conv1(relu(x1)))) + x1 + x0
+            c.conv(FW.rl1_c1, cb[j], B, h, w, F, 3, 1, 1, t1, F, VX_EPI_F16_RELU, true, false, nullptr, nullptr, "fusion_rcu");
+            c.conv(FW.rl1_c2, t1, B, h, w, F, 3, 1, 1, t2, F, VX_EPI_F16_ADD, false, false, cb[j], prev, "fusion_rcu");
+            xin = t2;
+        }
+        // residual_layer2: t3 = conv2(relu(conv1(relu(x)))) + x
+        c.conv(FW.rl2_c1, xin, B, h, w, F, 3, 1, 1, t1, F, VX_EPI_F16_RELU, true, false, nullptr, nullptr, "fusion_rcu");
+        c.conv(FW.rl2_c2, t1, B, h, w, F, 3, 1, 1, t3, F, VX_EPI_F16_ADD, false, false, xin, nullptr, "fusion_rcu");
+        // bilinear (align_corners) to the next feature's size, or x2 for the last stage
+        const int oh = i < 3 ? lh[j - 1] : 2 * h, ow = i < 3 ? lw[j - 1] : 2 * w;
+        c.mark("bilinear", 1, 0, (double)B * (h * w + oh * ow) * F * 2);
+        VX(vx_bilinear_ac_f16(t3, up, B, h, w, F, oh, ow, stream));
+        {
+            vx_gemm_args a = c.base(FW.proj, (long)B * oh * ow); // 1x1 projection (nn.cpp:76-81)
+            a.A = up; a.lda = F;
+            a.epi = VX_EPI_F16;
+            a.out = fused; a.ldo = F;
+            c.mark("fusion_proj", 1, 2.0 * B * oh * ow * F * F, (double)B * oh * ow * F * 4);
+            c.gemm(a);
+        }
+        prev = fused;
+        if (m.captures) { std::string nm = "fusion_" + std::to_string(i); c.capture(nm.c_str(), fused, {B, oh, ow, F}, true); }
+    }
+
+    // ---- dpt::head (depth-anything.cpp:81-96)
+    const int fh = 8 * ph, fw = 8 * pw;
+    c.conv(Wt.head1, fused, B, fh, fw, F, 3, 1, 1, c.buf("h1"), HC, VX_EPI_F16, false, false, nullptr, nullptr, "head_conv1");
+    c.capture("head_conv1", c.buf("h1"), {B, fh, fw, HC}, true);
+    c.mark("bilinear", 1, 0, (double)B * ((double)fh * fw + (double)H * W) * HC * 2);
+    VX(vx_bilinear_ac_f16(c.buf("h1"), c.buf("hup"), B, fh, fw, HC, H, W, stream));
+    c.conv(Wt.head2, c.buf("hup"), B, H, W, HC, 3, 1, 1, c.buf("h2"), HC, VX_EPI_F16_RELU, false, false, nullptr, nullptr, "head_conv2");
+    float* depth = raw_out_dev ? static_cast<float*>(raw_out_dev) : static_cast<float*>(c.buf("depth"));
+    c.mark("head_out", 1, 2.0 * B * H * W * HC, (double)B * H * W * (HC * 2 + 4));
+    VX(vx_head_out_f32(c.buf("h2"), c.fptr(Wt.head3_w), Wt.head3_b, P.max_depth, depth, (int64_t)B * H * W, HC, stream));
+    c.capture("depth", depth, {B, H, W, 1}, false);
+
+    // ---- depthany_process_output (depth-anything.cpp:142-149): per-image min-max to [0,1]
+    c.mark("normalize", 3, 0, (double)B * H * W * 12);
+    VX(vx_minmax_normalize(depth, static_cast<float*>(out_dev), static_cast<float*>(c.buf("minmax")), B, (int64_t)H * W, stream));
+    c.finish_timing();
+}
+
+void depthany_compute_batch_device(depthany_model& m, void const* rgb_dev, int batch, int w, int h, void* out_dev,
+                                   void* raw_out_dev, void* stream) {
+    if (!m.weights_uploaded) throw except("depthany: weights were not uploaded (load_no_upload) and no arena broadcast was marked complete");
+    VX(vx_set_device(m.backend->index));
+    depthany_reserve(m, batch, w, h);
+    bool own_stream = stream == nullptr;
+    void* s = own_stream ? m.backend->stream : stream;
+    if (m.use_graph && !m.captures && !m.timing) {
+        // the captured launch sequence bakes pointers in: stage through workspace-owned buffers
+        size_t in_bytes = (size_t)batch * h * w * 3, out_bytes = (size_t)batch * h * w * 4;
+        VX(vx_memcpy_d2d(m.ws.buf["rgb"], rgb_dev, in_bytes, s));
+        if (!m.ws.graph_exec) {
+            VX(vx_graph_begin_capture(s));
+            try {
+                run_forward(m, m.ws.buf["rgb"], m.ws.buf["out"], m.ws.buf["depth"], s);
+            } catch (...) {
+                void* g = nullptr;
+                vx_graph_end_capture(s, &g);
+                if (g) vx_graph_destroy(g);
+                throw;
+            }
+            VX(vx_graph_end_capture(s, &m.ws.graph_exec));
+        }
+        VX(vx_graph_launch(m.ws.graph_exec, s));
+        VX(vx_memcpy_d2d(out_dev, m.ws.buf["out"], out_bytes, s));
+        if (raw_out_dev) VX(vx_memcpy_d2d(raw_out_dev, m.ws.buf["depth"], out_bytes, s));
+    } else {
+        run_forward(m, rgb_dev, out_dev, raw_out_dev, s);
+    }
+    if (own_stream) VX(vx_stream_sync(s));
+}
+
+void depthany_compute_batch_host(depthany_model& m, uint8_t const* rgb, int batch, int w, int h, float* out, float* raw_out) {
+    VX(vx_set_device(m.backend->index));
+    depthany_reserve(m, batch, w, h);
+    void* s = m.backend->stream;
+    size_t in_bytes = (size_t)batch * h * w * 3, out_bytes = (size_t)batch * h * w * 4;
+    VX(vx_memcpy_h2d(m.ws.buf["rgb"], rgb, in_bytes, s));
+    bool g = m.use_graph;
+    m.use_graph = false; // direct launches already use workspace buffers
+    try {
+        depthany_compute_batch_device(m, m.ws.buf["rgb"], batch, w, h, m.ws.buf["out"], m.ws.buf["depth"], s);
+    } catch (...) {
+        m.use_graph = g;
+        throw;
+    }
+    m.use_graph = g;
+    VX(vx_memcpy_d2h(out, m.ws.buf["out"], out_bytes, s));
+    if (raw_out) VX(vx_memcpy_d2h(raw_out, m.ws.buf["depth"], out_bytes, s));
+}
+
+// reference src/visp/vision.cpp:147-167
+image_data depthany_compute(depthany_model& m, image_view image) {
+    if (is_float(image.format) || n_channels(image.format) < 3)
+        throw except("depthany: unsupported input image format [%d], expected an 8-bit colour image", int(image.format));
+    i32x2 res = depthany_image_extent(image.extent, m.params);
+    m.params.image_extent = res;
+    image_data rgb = image_to_rgb_u8(image);
+    image_view rgb_view = view_of(rgb);
+    image_data resized;
+    if (image.extent != res) { // depthany_process_input: image_scale to the model extent
+        resized = image_scale(rgb_view, res);
+        rgb_view = view_of(resized);
+    }
+    image_data out = image_alloc(res, image_format::alpha_f32);
+    depthany_compute_batch_host(m, static_cast<const uint8_t*>(rgb_view.data), 1, res[0], res[1],
+                                reinterpret_cast<float*>(out.data.get()), nullptr);
+    if (res != image.extent) return image_scale(view_of(out), image.extent); // depthany_process_output
+    return out;
+}
+
+} // namespace visp

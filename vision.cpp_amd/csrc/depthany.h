@@ -1,0 +1,121 @@
+// Depth-Anything-V2 on the MI355X backend: model load (GGUF -> packed f16 weight arena in HBM),
+// static per-shape schedule and the batched executor. Host C++ only; all device work goes
+// through the vx_* C ABI (include/visp_hip_kernels.h).
+//
+// Mirrors the reference's high-level API for this family (include/visp/vision.h:224-252,
+// 339-347; src/visp/vision.cpp:137-167; src/visp/arch/depth-anything.cpp; src/visp/arch/dino.cpp).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gguf.h"
+#include "image.h"
+
+namespace visp {
+
+enum class backend_type : int32_t { cpu = 1, gpu = 2, vulkan = 2 | 1 << 8 }; // include/visp/ml.h:32-36
+
+struct backend_device { // include/visp/ml.h:44-55, here: one HIP device + its compute stream
+    int index = 0;
+    std::string name, description;
+    void* stream = nullptr;
+    size_t total_mem = 0;
+    int n_cu = 0;
+    backend_type type() const { return backend_type::gpu; }
+    ~backend_device();
+};
+backend_device* backend_init(int device_index); // throws visp::exception if no gfx950 device
+
+struct dino_params { // vision.h:124-129
+    int patch_size = 16, embed_dim = 768, n_layers = 12, n_heads = 12;
+};
+struct depthany_params { // vision.h:236-243
+    int image_size = 518, image_multiple = 14;
+    i32x2 image_extent = {{518, 518}};
+    float max_depth = 1;
+    std::array<int, 4> feature_layers = {2, 5, 8, 11};
+    dino_params dino;
+};
+
+dino_params dino_detect_params(model_file const&);                        // dino.cpp:119-126
+depthany_params depthany_detect_params(model_file const&);                // depth-anything.cpp:119-128
+i32x2 depthany_image_extent(i32x2 extent, depthany_params const&);        // depth-anything.cpp:112-117
+
+// One GEMM-shaped weight in the packed arena: f16 [N][K] (both padded for the kernel's tiles,
+// pads are zero) + optional f32 bias [N].
+struct packed_gemm {
+    size_t w = 0, b = SIZE_MAX; // byte offsets into the arena
+    int N = 0, K = 0;           // padded
+    int n_real = 0, k_real = 0; // for FLOP accounting and n_valid
+};
+struct packed_vec { size_t off = SIZE_MAX; int n = 0; }; // f32 vector
+
+struct dino_layer_weights {
+    packed_vec ln1_w, ln1_b, ln2_w, ln2_b, lambda1, lambda2;
+    packed_gemm qkv, out, fc1, fc2;
+};
+struct fusion_weights {
+    packed_gemm proj, rl1_c1, rl1_c2, rl2_c1, rl2_c2;
+};
+struct depthany_weights {
+    packed_gemm patch;
+    packed_vec cls, pos; // f32 [D], [T0, D]
+    int pos_tokens = 0;
+    std::vector<dino_layer_weights> layers;
+    packed_vec final_ln_w, final_ln_b;
+    std::array<packed_gemm, 4> re_proj;
+    packed_gemm re_up0, re_up1, re_down3; // convT k4s4, convT k2s2, conv3x3 s2
+    std::array<int, 4> neck_c{};          // real channel counts of the reassembled maps
+    std::array<packed_gemm, 4> neck_conv;
+    std::array<fusion_weights, 4> fusion;
+    int fusion_c = 0, head_c = 0;
+    packed_gemm head1, head2;
+    packed_vec head3_w;
+    float head3_b = 0;
+    size_t head3_b_off = 0;
+};
+
+struct device_buffer { void* ptr = nullptr; size_t bytes = 0; };
+
+struct capture_entry { void* dev = nullptr; int64_t shape[4] = {1, 1, 1, 1}; bool f16 = true; };
+
+struct timing_entry { std::string name; float ms = 0; int launches = 0; double flops = 0, bytes = 0; };
+
+struct depthany_workspace {
+    int B = 0, W = 0, H = 0;
+    device_buffer arena;
+    // named sub-buffers (device pointers into arena)
+    std::map<std::string, void*> buf;
+    void* graph_exec = nullptr;
+};
+
+struct depthany_model { // vision.h:339-347 counterpart
+    backend_device const* backend = nullptr;
+    depthany_params params;
+    depthany_weights weights;
+    device_buffer weight_arena;
+    bool weights_uploaded = false;
+    depthany_workspace ws;
+    bool use_graph = false, captures = false, timing = false;
+    std::map<std::string, capture_entry> capture_bufs;
+    std::vector<timing_entry> last_timing;
+    ~depthany_model();
+};
+
+enum load_flags { load_default = 0, load_no_upload = 1 };
+depthany_model* depthany_load_model(char const* filepath, backend_device const& dev, int flags = load_default);
+// after a load_no_upload model's arena has been filled (RCCL broadcast from the rank that read the file)
+void depthany_weights_ready(depthany_model&);
+
+void depthany_reserve(depthany_model&, int batch, int w, int h);
+// rgb_u8 [B,h,w,3] on the device -> out f32 [B,h,w] normalised (+ raw depth if raw_out != null)
+void depthany_compute_batch_device(depthany_model&, void const* rgb_dev, int batch, int w, int h, void* out_dev,
+                                   void* raw_out_dev, void* stream);
+void depthany_compute_batch_host(depthany_model&, uint8_t const* rgb, int batch, int w, int h, float* out, float* raw_out);
+// reference API: any extent, any u8 colour format, batch 1 (vision.cpp:147-167) -> alpha_f32 at the input extent
+image_data depthany_compute(depthany_model&, image_view image);
+
+} // namespace visp

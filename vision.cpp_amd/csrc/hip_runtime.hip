@@ -1,0 +1,133 @@
+// Device/stream/memory plumbing behind the vx_* C ABI (include/visp_hip_kernels.h).
+// Replaces what the reference gets from ggml_backend_* (src/visp/ml.cpp:59-95, 479-502, 708-741).
+#include "vx_common.h"
+
+#include <cstring>
+
+static thread_local char g_vx_error[512];
+
+void vx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_vx_error, sizeof g_vx_error, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* vx_last_error(void) { return g_vx_error; }
+
+int vx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vx_set_device(int index) {
+    VX_CHECK(hipSetDevice(index));
+    return 1;
+}
+
+int vx_device_info(int index, char* name, int name_cap, char* arch, int arch_cap, size_t* total_mem,
+                   size_t* free_mem, int* n_cu) {
+    hipDeviceProp_t prop;
+    VX_CHECK(hipGetDeviceProperties(&prop, index));
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", prop.name);
+    if (arch && arch_cap > 0) snprintf(arch, arch_cap, "%s", prop.gcnArchName);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (total_mem) *total_mem = prop.totalGlobalMem;
+    if (free_mem) {
+        size_t f = 0, t = 0;
+        int cur = 0;
+        VX_CHECK(hipGetDevice(&cur));
+        VX_CHECK(hipSetDevice(index));
+        VX_CHECK(hipMemGetInfo(&f, &t));
+        VX_CHECK(hipSetDevice(cur));
+        *free_mem = f;
+    }
+    return 1;
+}
+
+int vx_malloc(void** ptr, size_t bytes) {
+    VX_CHECK(hipMalloc(ptr, bytes ? bytes : 16));
+    return 1;
+}
+int vx_free(void* ptr) {
+    if (ptr) VX_CHECK(hipFree(ptr));
+    return 1;
+}
+int vx_memset(void* ptr, int value, size_t bytes, void* stream) {
+    VX_CHECK(hipMemsetAsync(ptr, value, bytes, as_stream(stream)));
+    return 1;
+}
+int vx_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    VX_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return 1;
+}
+int vx_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    VX_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    VX_CHECK(hipStreamSynchronize(as_stream(stream)));
+    return 1;
+}
+int vx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    VX_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return 1;
+}
+int vx_stream_create(void** stream) {
+    hipStream_t s;
+    VX_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return 1;
+}
+int vx_stream_destroy(void* stream) {
+    if (stream) VX_CHECK(hipStreamDestroy(as_stream(stream)));
+    return 1;
+}
+int vx_stream_sync(void* stream) {
+    VX_CHECK(hipStreamSynchronize(as_stream(stream)));
+    return 1;
+}
+int vx_event_create(void** ev) {
+    hipEvent_t e;
+    VX_CHECK(hipEventCreate(&e));
+    *ev = e;
+    return 1;
+}
+int vx_event_destroy(void* ev) {
+    if (ev) VX_CHECK(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)));
+    return 1;
+}
+int vx_event_record(void* ev, void* stream) {
+    VX_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), as_stream(stream)));
+    return 1;
+}
+int vx_event_elapsed_ms(void* start, void* stop, float* ms) {
+    VX_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+    VX_CHECK(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+    return 1;
+}
+
+int vx_graph_begin_capture(void* stream) {
+    VX_CHECK(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+    return 1;
+}
+int vx_graph_end_capture(void* stream, void** graph_exec) {
+    hipGraph_t graph = nullptr;
+    VX_CHECK(hipStreamEndCapture(as_stream(stream), &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    VX_CHECK(e);
+    *graph_exec = exec;
+    return 1;
+}
+int vx_graph_launch(void* graph_exec, void* stream) {
+    VX_CHECK(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), as_stream(stream)));
+    return 1;
+}
+int vx_graph_destroy(void* graph_exec) {
+    if (graph_exec) VX_CHECK(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)));
+    return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,301 @@
+// HBM-bound kernels of the Depth-Anything path on gfx950: LayerNorm, pre/post-processing,
+// bilinear resize, head output. Each is a coalesced streaming kernel (16-byte lane accesses
+// where the layout allows) with wave64 shuffle reductions.
+#include "vx_common.h"
+
+namespace {
+
+// ---- LayerNorm: one wave per row (reference src/visp/nn.cpp:14-19 = ggml_norm * w + b)
+// x f32 [M, C] -> y f16 [M, C]; biased variance, eps inside the sqrt; two-pass in registers.
+template <int VPL> // float2 vectors per lane: C == 64 * 2 * VPL
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, f16* __restrict__ y, int M,
+                                                             int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float2* xr = reinterpret_cast<const float2*>(x + (long)row * C);
+    float2 v[VPL];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = xr[lane + 64 * i];
+        sum += v[i].x + v[i].y;
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i].x -= mean; v[i].y -= mean;
+        sq += v[i].x * v[i].x + v[i].y * v[i].y;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    const float2* wr = reinterpret_cast<const float2*>(w);
+    const float2* br = reinterpret_cast<const float2*>(b);
+    f16x2* yr = reinterpret_cast<f16x2*>(y + (long)row * C);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float2 ww = wr[lane + 64 * i], bb = br[lane + 64 * i];
+        f16x2 o = {(f16)(v[i].x * rstd * ww.x + bb.x), (f16)(v[i].y * rstd * ww.y + bb.y)};
+        yr[lane + 64 * i] = o;
+    }
+}
+
+// generic fallback: any C, one wave per row, three strided passes
+__global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, f16* __restrict__ y,
+                                                                 int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long)row * C;
+    float sum = 0.0f;
+    for (int c = lane; c < C; c += 64) sum += xr[c];
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+    for (int c = lane; c < C; c += 64) { float d = xr[c] - mean; sq += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    for (int c = lane; c < C; c += 64) y[(long)row * C + c] = (f16)((xr[c] - mean) * rstd * w[c] + b[c]);
+}
+
+// ---- pre-processing + patch im2col (reference depth-anything.cpp:130-140, image.cpp:215-226,
+// image-impl.h:23-27, nn.cpp:166-180). One thread writes 8 consecutive k of one patch row.
+__global__ __launch_bounds__(256) void preprocess_patches_kernel(const uint8_t* __restrict__ rgb, f16* __restrict__ patches,
+                                                                  int B, int H, int W, int ps, int Kp, float m0, float m1,
+                                                                  float m2, float s0, float s1, float s2) {
+    const int chunks = Kp >> 3;
+    const long total = (long)B * (H / ps) * (W / ps) * chunks;
+    const int pw = W / ps, ph = H / ps;
+    const int kreal = ps * ps * 3;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int ch = (int)(idx % chunks);
+        long prow = idx / chunks;
+        int px = (int)(prow % pw);
+        int py = (int)((prow / pw) % ph);
+        int b = (int)(prow / ((long)pw * ph));
+        f16x8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int k = ch * 8 + j;
+            float v = 0.0f;
+            if (k < kreal) {
+                int c = k % 3, kk = k / 3;
+                int kx = kk % ps, ky = kk / ps;
+                float u = (float)rgb[(((long)b * H + py * ps + ky) * W + px * ps + kx) * 3 + c];
+                float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+                float inv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                v = (u / 255.0f - mean) * inv;
+            }
+            out[j] = (f16)v;
+        }
+        *reinterpret_cast<f16x8*>(patches + prow * Kp + ch * 8) = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void preprocess_f32_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ out, long n,
+                                                              float m0, float m1, float m2, float s0, float s1, float s2) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % 3);
+        float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+        float inv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        out[i] = ((float)rgb[i] / 255.0f + (-mean)) * inv;
+    }
+}
+
+__global__ void write_cls_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int T, int C) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) x[(long)b * T * C + c] = cls[c] + pos[c];
+}
+
+// ---- bilinear, align_corners (ggml_interpolate BILINEAR|ALIGN_CORNERS; reference ml.cpp:782-788).
+// NHWC f16, one thread = 8 channels of one output pixel; source coords as ggml computes them:
+// sf = (out-1)/(in-1), src = i / sf.
+__global__ __launch_bounds__(256) void bilinear_ac_kernel(const f16* __restrict__ x, f16* __restrict__ y, int B, int H, int W,
+                                                           int C, int OH, int OW, float sfy, float sfx) {
+    const int c8n = C >> 3;
+    const long total = (long)B * OH * OW * c8n;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c8 = (int)(idx % c8n);
+        long pix = idx / c8n;
+        int ox = (int)(pix % OW);
+        int oy = (int)((pix / OW) % OH);
+        int b = (int)(pix / ((long)OW * OH));
+        float sy = (float)oy / sfy, sx = (float)ox / sfx;
+        int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+        int y1 = y0 + 1, x1 = x0 + 1;
+        y0 = max(0, min(y0, H - 1)); y1 = max(0, min(y1, H - 1));
+        x0 = max(0, min(x0, W - 1)); x1 = max(0, min(x1, W - 1));
+        float dy = fminf(fmaxf(sy - (float)y0, 0.0f), 1.0f), dx = fminf(fmaxf(sx - (float)x0, 0.0f), 1.0f);
+        const f16* base = x + (long)b * H * W * C + c8 * 8;
+        f16x8 a = *reinterpret_cast<const f16x8*>(base + ((long)y0 * W + x0) * C);
+        f16x8 bb = *reinterpret_cast<const f16x8*>(base + ((long)y0 * W + x1) * C);
+        f16x8 c = *reinterpret_cast<const f16x8*>(base + ((long)y1 * W + x0) * C);
+        f16x8 d = *reinterpret_cast<const f16x8*>(base + ((long)y1 * W + x1) * C);
+        float w00 = (1 - dx) * (1 - dy), w01 = dx * (1 - dy), w10 = (1 - dx) * dy, w11 = dx * dy;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = (f16)((float)a[j] * w00 + (float)bb[j] * w01 + (float)c[j] * w10 + (float)d[j] * w11);
+        *reinterpret_cast<f16x8*>(y + pix * C + c8 * 8) = o;
+    }
+}
+
+// ---- head output: 1x1 conv C -> 1, ReLU, * max_depth (reference depth-anything.cpp:89-94)
+template <int C>
+__global__ __launch_bounds__(256) void head_out_kernel(const f16* __restrict__ x, const float* __restrict__ w, float bias,
+                                                        float max_depth, float* __restrict__ depth, long n) {
+    float wr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) wr[c] = w[c];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const f16x8* px = reinterpret_cast<const f16x8*>(x + i * C);
+        float acc = 0.0f;
+#pragma unroll
+        for (int c8 = 0; c8 < C / 8; ++c8) {
+            f16x8 v = px[c8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)v[j] * wr[c8 * 8 + j];
+        }
+        depth[i] = fmaxf(acc + bias, 0.0f) * max_depth;
+    }
+}
+
+// ---- post-processing (reference image.cpp:537-576): per-image min/max, then v*scale + offset
+__device__ __forceinline__ unsigned f2ord(float f) { // order-preserving float -> uint
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__global__ void minmax_init_kernel(unsigned* mm, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { mm[2 * i] = 0xffffffffu; mm[2 * i + 1] = 0u; }
+}
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ depth, unsigned* __restrict__ mm, long n) {
+    const int b = blockIdx.y;
+    const float* d = depth + (long)b * n;
+    float mn = INFINITY, mx = -INFINITY;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = d[i];
+        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[2 * b], f2ord(mn));
+        atomicMax(&mm[2 * b + 1], f2ord(mx));
+    }
+}
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ depth, float* __restrict__ out,
+                                                         const unsigned* __restrict__ mm, long n) {
+    const int b = blockIdx.y;
+    const float mn = ord2f(mm[2 * b]), mx = ord2f(mm[2 * b + 1]);
+    float delta = mx - mn;
+    delta = delta < 1e-5f ? 1.0f : delta;
+    const float scale = 1.0f / delta;          // (max - min) / delta with max=1, min=0
+    const float offset = -mn * scale + 0.0f;
+    const float* d = depth + (long)b * n;
+    float* o = out + (long)b * n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        o[i] = d[i] * scale + offset;
+}
+__global__ __launch_bounds__(256) void f32_to_u8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = fminf(fmaxf(src[i], 0.0f), 1.0f);
+        dst[i] = (uint8_t)(v * 255.0f);
+    }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+    long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+} // namespace
+
+extern "C" {
+
+int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y, int M, int C, float eps, void* stream) {
+    VX_REQUIRE(M > 0 && C > 0, "vx_layernorm: empty problem");
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = as_stream(stream);
+    f16* yy = reinterpret_cast<f16*>(y);
+    if (C == 384) hipLaunchKernelGGL(layernorm_vec_kernel<3>, grid, block, 0, s, x, w, b, yy, M, C, eps);
+    else if (C == 128) hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, s, x, w, b, yy, M, C, eps);
+    else if (C == 768) hipLaunchKernelGGL(layernorm_vec_kernel<6>, grid, block, 0, s, x, w, b, yy, M, C, eps);
+    else if (C == 1024) hipLaunchKernelGGL(layernorm_vec_kernel<8>, grid, block, 0, s, x, w, b, yy, M, C, eps);
+    else hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, w, b, yy, M, C, eps);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_preprocess_patches(const uint8_t* rgb, void* patches, int B, int H, int W, int ps, int Kp, const float mean[3],
+                          const float inv_std[3], void* stream) {
+    VX_REQUIRE(H % ps == 0 && W % ps == 0, "vx_preprocess_patches: %dx%d not a multiple of patch size %d", W, H, ps);
+    VX_REQUIRE(Kp % 8 == 0 && Kp >= ps * ps * 3, "vx_preprocess_patches: bad Kp=%d", Kp);
+    long total = (long)B * (H / ps) * (W / ps) * (Kp / 8);
+    hipLaunchKernelGGL(preprocess_patches_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), rgb,
+                       reinterpret_cast<f16*>(patches), B, H, W, ps, Kp, mean[0], mean[1], mean[2], inv_std[0], inv_std[1],
+                       inv_std[2]);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_preprocess_f32(const uint8_t* rgb, float* out, int B, int H, int W, const float mean[3], const float inv_std[3],
+                      void* stream) {
+    long n = (long)B * H * W * 3;
+    hipLaunchKernelGGL(preprocess_f32_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), rgb, out, n, mean[0],
+                       mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_write_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int C, void* stream) {
+    hipLaunchKernelGGL(write_cls_kernel, dim3(B), dim3(128), 0, as_stream(stream), x, cls, pos, T, C);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_bilinear_ac_f16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, void* stream) {
+    VX_REQUIRE(C % 8 == 0, "vx_bilinear_ac_f16: C=%d must be a multiple of 8", C);
+    float sfy = (OH > 1 && H > 1) ? (float)(OH - 1) / (float)(H - 1) : (float)OH / (float)H;
+    float sfx = (OW > 1 && W > 1) ? (float)(OW - 1) / (float)(W - 1) : (float)OW / (float)W;
+    long total = (long)B * OH * OW * (C / 8);
+    hipLaunchKernelGGL(bilinear_ac_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const f16*>(x), reinterpret_cast<f16*>(y), B, H, W, C, OH, OW, sfy, sfx);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_head_out_f32(const void* x, const float* w, float bias, float max_depth, float* depth, int64_t n_pixels, int C,
+                    void* stream) {
+    hipStream_t s = as_stream(stream);
+    const f16* xx = reinterpret_cast<const f16*>(x);
+    dim3 grid(grid_for(n_pixels)), block(256);
+    if (C == 32) hipLaunchKernelGGL(head_out_kernel<32>, grid, block, 0, s, xx, w, bias, max_depth, depth, (long)n_pixels);
+    else if (C == 64) hipLaunchKernelGGL(head_out_kernel<64>, grid, block, 0, s, xx, w, bias, max_depth, depth, (long)n_pixels);
+    else if (C == 8) hipLaunchKernelGGL(head_out_kernel<8>, grid, block, 0, s, xx, w, bias, max_depth, depth, (long)n_pixels);
+    else if (C == 16) hipLaunchKernelGGL(head_out_kernel<16>, grid, block, 0, s, xx, w, bias, max_depth, depth, (long)n_pixels);
+    else { vx_set_error("vx_head_out_f32: unsupported C=%d", C); return 0; }
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_minmax_normalize(const float* depth, float* out, float* minmax, int B, int64_t n, void* stream) {
+    hipStream_t s = as_stream(stream);
+    unsigned* mm = reinterpret_cast<unsigned*>(minmax);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, mm, B);
+    int gx = grid_for(n, 256, 64);
+    hipLaunchKernelGGL(minmax_kernel, dim3(gx, B), dim3(256), 0, s, depth, mm, (long)n);
+    hipLaunchKernelGGL(normalize_kernel, dim3(gx, B), dim3(256), 0, s, depth, out, mm, (long)n);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_f32_to_u8(const float* src, uint8_t* dst, int64_t n, void* stream) {
+    hipLaunchKernelGGL(f32_to_u8_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), src, dst, (long)n);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,212 @@
+"""Python face of the backend: the reference's bindings/python/visioncpp/vision.py classes
+(Backend, Device, Arch, Model.load/compute) on top of the same C symbols, plus the batched
+extension (`Model.compute_batch`, device-resident `compute_batch_device`)."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_int32, c_int64, c_size_t, c_void_p
+from enum import Enum
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib as lib
+from ._lib import check, get_lib, vx_check
+
+
+class ImageFormat(Enum):
+    rgba_u8 = 0
+    bgra_u8 = 1
+    argb_u8 = 2
+    rgb_u8 = 3
+    alpha_u8 = 4
+    rgba_f32 = 5
+    rgb_f32 = 6
+    alpha_f32 = 7
+
+
+class Backend(Enum):
+    auto = 0
+    cpu = 1
+    gpu = 2
+    vulkan = gpu | 1 << 8
+
+
+class Arch(Enum):
+    sam = 0
+    birefnet = 1
+    depth_anything = 2
+    migan = 3
+    esrgan = 4
+    unknown = 5
+
+
+class Device:
+    @staticmethod
+    def init(backend: Backend = Backend.auto, index: int | None = None):
+        api = get_lib()
+        handle = c_void_p()
+        if index is None:
+            check(api.visp_device_init(backend.value, byref(handle)))
+        else:
+            check(api.visp_hip_device_init(index, byref(handle)))
+        return Device(api, handle)
+
+    def __init__(self, api, handle):
+        self._api, self._handle = api, handle
+
+    @property
+    def type(self) -> Backend:
+        return Backend(self._api.visp_device_type(self._handle))
+
+    @property
+    def name(self) -> str:
+        return self._api.visp_device_name(self._handle).decode()
+
+    @property
+    def description(self) -> str:
+        return self._api.visp_device_description(self._handle).decode()
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            self._api.visp_device_destroy(self._handle)
+            self._handle = None
+
+
+_CHANNELS = {0: 4, 1: 4, 2: 4, 3: 3, 4: 1}
+
+
+class Model:
+    @classmethod
+    def load(cls, path, device: Device, arch: Arch = Arch.unknown, no_upload: bool = False):
+        api = get_lib()
+        handle = c_void_p()
+        p = lib.path_to_char_p(path)
+        if arch is Arch.unknown:
+            v = c_int32()
+            check(api.visp_model_detect_family(p, byref(v)))
+            arch = Arch(v.value)
+        check(api.visp_model_load_ex(p, device._handle, arch.value, 1 if no_upload else 0, byref(handle)))
+        return cls(api, handle, arch, device)
+
+    def __init__(self, api, handle, arch: Arch, device: Device):
+        self.arch, self._api, self._handle, self._device = arch, api, handle, device
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            self._api.visp_model_destroy(self._handle, self.arch.value)
+            self._handle = None
+
+    # ---- reference API: one image of any size/format -> u8 depth map (c-api.cpp:230-251)
+    def compute(self, image: np.ndarray, format: ImageFormat = ImageFormat.rgb_u8) -> np.ndarray:
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = img.shape[:2]
+        view = lib.ImageView(w, h, w * _CHANNELS[format.value], format.value, img.ctypes.data)
+        views = (lib.ImageView * 1)(view)
+        out_view, out_data = lib.ImageView(), c_void_p()
+        check(self._api.visp_model_compute(self._handle, self.arch.value, views, 1, (c_int32 * 1)(), 0, byref(out_view), byref(out_data)))
+        try:
+            n = out_view.height * out_view.stride
+            buf = (ctypes.c_uint8 * n).from_address(out_view.data)
+            res = np.frombuffer(buf, np.uint8).reshape(out_view.height, out_view.width).copy()
+        finally:
+            self._api.visp_image_destroy(out_data)
+        return res
+
+    # ---- batched extension
+    @property
+    def info(self) -> lib.DepthAnyInfo:
+        i = lib.DepthAnyInfo()
+        check(self._api.visp_depthany_get_info(self._handle, byref(i)))
+        return i
+
+    def image_extent(self, w: int, h: int):
+        ow, oh = c_int32(), c_int32()
+        check(self._api.visp_depthany_image_extent(self._handle, w, h, byref(ow), byref(oh)))
+        return ow.value, oh.value
+
+    def weights_arena(self):
+        p, n = c_void_p(), c_size_t()
+        check(self._api.visp_depthany_weights_arena(self._handle, byref(p), byref(n)))
+        return p.value, n.value
+
+    def weights_ready(self):
+        check(self._api.visp_depthany_weights_ready(self._handle))
+
+    def reserve(self, batch: int, w: int, h: int):
+        check(self._api.visp_depthany_reserve(self._handle, batch, w, h))
+
+    def use_graph(self, enable: bool = True):
+        check(self._api.visp_depthany_use_graph(self._handle, int(enable)))
+
+    def compute_batch(self, images: np.ndarray, return_raw: bool = False):
+        """images: uint8 [B, h, w, 3] on the host -> float32 [B, h, w] in [0, 1]."""
+        imgs = np.ascontiguousarray(images, dtype=np.uint8)
+        b, h, w, c = imgs.shape
+        assert c == 3
+        out = np.empty((b, h, w), np.float32)
+        raw = np.empty((b, h, w), np.float32) if return_raw else None
+        check(self._api.visp_depthany_compute_batch_host(self._handle, imgs.ctypes.data, b, w, h, out.ctypes.data,
+                                                         raw.ctypes.data if return_raw else None))
+        return (out, raw) if return_raw else out
+
+    def compute_batch_device(self, rgb_dev: int, batch: int, w: int, h: int, out_dev: int, raw_dev: int | None = None,
+                             stream: int | None = None):
+        check(self._api.visp_depthany_compute_batch_device(self._handle, rgb_dev, batch, w, h, out_dev, raw_dev, stream))
+
+    def enable_captures(self, enable: bool = True):
+        check(self._api.visp_depthany_enable_captures(self._handle, int(enable)))
+
+    def read_capture(self, name: str) -> np.ndarray:
+        n, shape = c_int64(), (c_int64 * 4)()
+        check(self._api.visp_depthany_read_capture(self._handle, name.encode(), None, 0, byref(n), shape))
+        out = np.empty(n.value, np.float32)
+        check(self._api.visp_depthany_read_capture(self._handle, name.encode(), out.ctypes.data, n.value, byref(n), shape))
+        dims = [int(d) for d in shape]
+        while len(dims) > 1 and dims[-1] == 1:
+            dims.pop()
+        return out.reshape(dims)
+
+    def enable_timing(self, enable: bool = True):
+        check(self._api.visp_depthany_enable_timing(self._handle, int(enable)))
+
+    def read_timing(self):
+        arr, n = (lib.Timing * 64)(), c_int32()
+        check(self._api.visp_depthany_read_timing(self._handle, arr, 64, byref(n)))
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches, flops=arr[i].flops, bytes=arr[i].bytes)
+                for i in range(n.value)]
+
+
+class DeviceBuffer:
+    """Raw device allocation through the vx_* runtime ABI (tests and bench use it so the hot path
+    never depends on torch tensors)."""
+
+    def __init__(self, nbytes: int):
+        self._api = get_lib()
+        self.nbytes = nbytes
+        p = c_void_p()
+        vx_check(self._api.vx_malloc(byref(p), nbytes))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        vx_check(b._api.vx_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes, None))
+        vx_check(b._api.vx_stream_sync(None))
+        return b
+
+    def to_numpy(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        vx_check(self._api.vx_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None))
+        return out
+
+    def zero(self):
+        vx_check(self._api.vx_memset(self.ptr, 0, self.nbytes, None))
+        vx_check(self._api.vx_stream_sync(None))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._api.vx_free(self.ptr)
+            self.ptr = None
