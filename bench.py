@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Depth-Anything-V2-Small f16, 518x518, images/sec (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU. A step = one pass of the hot path (depthany_compute semantics per image:
+pre-process, DINOv2-S encoder, DPT neck/head, min-max normalise) over one batch of 32 synthetic
+518x518x3 uint8 images that are already resident in HBM. Images are independent units, so the
+batch is sharded across ranks with no data-path collective (weak scaling: 32 images per GPU);
+RCCL is used once, at load, to broadcast the packed weight arena from rank 0.
+
+Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events on the compute stream
+(per kernel group, non-graph pass); `cpu_baseline` times the CPU oracle (oracle/, a port of the
+reference's ggml CPU path) on a bounded sample on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from visioncpp_amd import _lib as L  # noqa: E402
+from visioncpp_amd import synth, vision  # noqa: E402
+
+GFLOP_PER_IMAGE = 115.27  # BASELINE.md section 2 (2 x MACs of matmuls/convs)
+PEAK_MFMA_F16 = 2.5e15    # dense f16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--profile-groups", action="store_true", help="print the per-kernel-group table to stderr")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B, W, H = args.batch, 518, 518
+    cfg = synth.SMALL
+    api = L.get_lib()
+
+    # ---- load: rank 0 reads the GGUF and uploads; other ranks allocate and receive the arena over RCCL
+    tmp = Path(tempfile.gettempdir()) / "visp_bench_da_v2_small_f16.gguf"
+    if rank == 0:
+        synth.write_gguf(tmp, cfg, seed=0)
+    barrier()
+    dev = vision.Device.init(index=local_rank)
+    model = vision.Model.load(tmp, dev, vision.Arch.depth_anything, no_upload=(rank != 0))
+    if world > 1:
+        ptr, nbytes = model.weights_arena()
+        staging = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            L.vx_check(api.vx_memcpy_d2d(staging.data_ptr(), ptr, nbytes, None))
+            L.vx_check(api.vx_stream_sync(None))
+        dist.broadcast(staging, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            L.vx_check(api.vx_memcpy_d2d(ptr, staging.data_ptr(), nbytes, None))
+            L.vx_check(api.vx_stream_sync(None))
+            model.weights_ready()
+        del staging
+
+    # ---- inputs resident in HBM before the timed region
+    imgs = synth.images(min(B, 8), W, H, seed=1234 + 100 * rank)
+    imgs = np.concatenate([imgs] * ((B + len(imgs) - 1) // len(imgs)))[:B]
+    rgb = torch.from_numpy(imgs).cuda()
+    out = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+    compute_stream = torch.cuda.Stream()  # a real (non-null) stream: required for hipGraph capture
+    stream = compute_stream.cuda_stream
+    model.reserve(B, W, H)
+
+    def step():
+        model.compute_batch_device(rgb.data_ptr(), B, W, H, out.data_ptr(), None, stream)
+
+    # ---- per-kernel-group timing (direct launches, HIP events on the compute stream), untimed
+    groups = []
+    if rank == 0:
+        step()
+        torch.cuda.synchronize()
+        model.enable_timing(True)
+        acc: dict[str, dict] = {}
+        reps = 3
+        for _ in range(reps):
+            step()
+            torch.cuda.synchronize()
+            for t in model.read_timing():
+                a = acc.setdefault(t["name"], dict(name=t["name"], ms=0.0, launches=0, flops=0.0, bytes=0.0))
+                a["ms"] += t["ms"] / reps
+                a["launches"] = t["launches"]
+                a["flops"] = t["flops"]
+                a["bytes"] = t["bytes"]
+        model.enable_timing(False)
+        groups = sorted(acc.values(), key=lambda g: -g["ms"])
+        if args.profile_groups:
+            tot = sum(g["ms"] for g in groups)
+            print(f"{'group':16s} {'ms':>8s} {'%':>6s} {'launch':>6s} {'TFLOP/s':>9s} {'GB/s':>9s}", file=sys.stderr)
+            for g in groups:
+                print(f"{g['name']:16s} {g['ms']:8.3f} {100 * g['ms'] / tot:6.1f} {g['launches']:6d} "
+                      f"{g['flops'] / g['ms'] / 1e9:9.1f} {g['bytes'] / g['ms'] / 1e6:9.1f}", file=sys.stderr)
+            print(f"{'total':16s} {tot:8.3f}", file=sys.stderr)
+
+    if not args.no_graph:
+        model.use_graph(True)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    model.use_graph(False)
+
+    # sanity: the timed output is a valid normalised depth batch
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all() and o.min() >= 0 and o.max() <= 1 + 1e-6, "invalid output"
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        res = {
+            "metric": "images/sec, Depth-Anything-V2-Small 518x518 f16",
+            "value": round(value, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "Depth-Anything-V2-Small f16 (DINOv2-S ViT) 518x518 batch=32 per MI355X (BASELINE.json configs[1])",
+                       "images_per_gpu_per_step": B, "global_batch": world * B, "weights": "random-init synthetic GGUF (seed 0)",
+                       "parallelism": f"dp{world} (image shards, no data-path collective)", "hip_graph": not args.no_graph},
+            "model_tflops": round(value * GFLOP_PER_IMAGE / 1e3, 2),
+            "mfma_frac_whole_model": round(value * GFLOP_PER_IMAGE * 1e9 / (world * PEAK_MFMA_F16), 4),
+        }
+        if groups:
+            dom = groups[0]
+            per_launch_ms = dom["ms"] / max(dom["launches"], 1)
+            if dom["flops"] > 0 and dom["flops"] / max(dom["bytes"], 1) > PEAK_MFMA_F16 / PEAK_HBM / 4:
+                ach = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+                res["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F16 / 1e12,
+                                   "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_MFMA_F16, 4), "traffic": None,
+                                   "avg_launch_ms": round(per_launch_ms, 4), "launches_per_step": dom["launches"]}
+            else:
+                ach = dom["bytes"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e9
+                res["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM / 1e9,
+                                   "unit": "GB/s", "frac": round(ach * 1e9 / PEAK_HBM, 4), "traffic": None,
+                                   "avg_launch_ms": round(per_launch_ms, 4), "launches_per_step": dom["launches"]}
+            res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, imgs, o, args.cpu_images)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, imgs, gpu_out, n_images):
+    """Times the CPU oracle (a port of the reference's ggml CPU path: f32 math, f16-rounded weights,
+    batch-1 sequential like vision.cpp:155) on a bounded sample and reports the parity of the timed
+    GPU output against it."""
+    from oracle import oracle
+
+    sd = synth.state_dict(cfg, 0)
+    tensors, conv2d = synth.gguf_tensors(sd)
+    om = oracle.Model(tensors, conv2d, "whcn")
+    params = oracle.make_params(cfg.patch_size, cfg.embed_dim, cfg.n_layers, cfg.n_heads, cfg.image_size, 14, cfg.feature_layers)
+    cores = oracle.num_threads()
+    om.compute(params, imgs[0])  # warm-up (page-in, LUT init)
+    t0 = time.perf_counter()
+    maes = []
+    for i in range(n_images):
+        want, _ = om.compute(params, imgs[i])
+        maes.append(float(np.abs(gpu_out[i] - want).mean()))
+    dt = time.perf_counter() - t0
+    return {"value": round(n_images / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n_images} images 518x518, batch-1 sequential, OpenMP {cores} threads, oracle/libvisp_oracle.so",
+            "mae_gpu_vs_cpu": round(max(maes), 6)}
+
+
+if __name__ == "__main__":
+    main()

@@ -266,7 +266,10 @@ int vo_transfer_tensor(const vo_tensor* t, int whcn_to_cwhn, void* dst, int64_t 
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* GEMM core: y[M][N] (+)= x[M][K] * wt[K][N]; k summed in ascending order per output */
+/* GEMM core: y[M][N] (+)= x[M][K] * wt[K][N]; k summed in ascending order per output.
+ * The library is built with -ffp-contract=off (the reference's scalar image code is compiled
+ * without FMA contraction); the matmul inner loops use explicit fused multiply-adds, as ggml's
+ * AVX2 vec_dot / vec_mad kernels do. */
 
 static void gemm_nn(const float* x, int64_t ldx, const float* wt, int64_t ldw, float* y, int64_t ldy,
                     int64_t M, int64_t K, int64_t N, const float* bias) {
@@ -286,14 +289,14 @@ static void gemm_nn(const float* x, int64_t ldx, const float* wt, int64_t ldw, f
                     float xs[MB];
                     for (int r = 0; r < MB; ++r) xs[r] = x[(m0 + r) * ldx + k];
                     for (int r = 0; r < MB; ++r)
-                        for (int j = 0; j < NB; ++j) acc[r][j] += xs[r] * wrow[j];
+                        for (int j = 0; j < NB; ++j) acc[r][j] = __builtin_fmaf(xs[r], wrow[j], acc[r][j]);
                 }
             } else {
                 for (int64_t k = 0; k < K; ++k) {
                     const float* wrow = wt + k * ldw + n0;
                     for (int r = 0; r < mr; ++r) {
                         float xv = x[(m0 + r) * ldx + k];
-                        for (int j = 0; j < nr; ++j) acc[r][j] += xv * wrow[j];
+                        for (int j = 0; j < nr; ++j) acc[r][j] = __builtin_fmaf(xv, wrow[j], acc[r][j]);
                     }
                 }
             }
@@ -407,7 +410,7 @@ void vo_attention(const float* q, const float* k, const float* v, int64_t N, int
                     for (int d = 0; d < hd; ++d) {
                         float qv = qr_[d];
                         const float* krow = kt + (int64_t)d * N;
-                        for (int64_t j = 0; j < N; ++j) sr[j] += qv * krow[j];
+                        for (int64_t j = 0; j < N; ++j) sr[j] = __builtin_fmaf(qv, krow[j], sr[j]);
                     }
                     /* ggml_soft_max_ext: x*scale, max, expf(x-max), sum (double), /sum */
                     float mx = -INFINITY;
@@ -422,7 +425,7 @@ void vo_attention(const float* q, const float* k, const float* v, int64_t N, int
                     for (int64_t j = 0; j < N; ++j) {
                         float p = sr[j];
                         const float* vrow = vh + j * hd;
-                        for (int d = 0; d < hd; ++d) acc[d] += p * vrow[d];
+                        for (int d = 0; d < hd; ++d) acc[d] = __builtin_fmaf(p, vrow[d], acc[d]);
                     }
                     for (int d = 0; d < hd; ++d) o[d] = acc[d];
                 }
@@ -504,7 +507,7 @@ void vo_conv_transpose2d_nhwc(const float* x, int B, int H, int W, int Cin, cons
                         for (int ci = 0; ci < Cin; ++ci) {
                             float xv = xp[ci];
                             const float* wrow = wk + (int64_t)ci * Cout;
-                            for (int co = 0; co < Cout; ++co) yp[co] += xv * wrow[co];
+                            for (int co = 0; co < Cout; ++co) yp[co] = __builtin_fmaf(xv, wrow[co], yp[co]);
                         }
                     }
             }

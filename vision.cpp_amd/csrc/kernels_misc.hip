@@ -188,16 +188,21 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ d
 }
 __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ depth, float* __restrict__ out,
                                                          const unsigned* __restrict__ mm, long n) {
+#pragma clang fp contract(off)
     const int b = blockIdx.y;
     const float mn = ord2f(mm[2 * b]), mx = ord2f(mm[2 * b + 1]);
     float delta = mx - mn;
     delta = delta < 1e-5f ? 1.0f : delta;
+    // the reference's scalar loop rounds the product and the sum separately (image.cpp:565-575),
+    // so the minimum maps to exactly 0: keep the compiler from contracting them into an FMA
     const float scale = 1.0f / delta;          // (max - min) / delta with max=1, min=0
-    const float offset = -mn * scale + 0.0f;
+    const float offset = -mn * scale;
     const float* d = depth + (long)b * n;
     float* o = out + (long)b * n;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        o[i] = d[i] * scale + offset;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float prod = d[i] * scale;
+        o[i] = prod + offset;
+    }
 }
 __global__ __launch_bounds__(256) void f32_to_u8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
