@@ -58,7 +58,7 @@ enum vx_epilogue {
     VX_EPI_RESID_F32 = 3, /* x f32 [M, ldo] += lambda[n] * (acc + bias)   (dino.cpp:48-50,80-87) */
     VX_EPI_TOKENS = 4,    /* patch embed: x f32 [(m/P)*(P+1) + 1 + m%P, n] = acc + bias + pos[1 + m%P, n]
                              (dino.cpp:32-46, pos-embed add fused)                              */
-    VX_EPI_QKV = 5,       /* scatter into q,k [B,H,T,64] and v^T [B,H,64,Tp] f16; q scaled      */
+    VX_EPI_QKV = 5,       /* scatter into head-major q, k, v f16 [B,H,T,64]; q scaled             */
     VX_EPI_PIXSHUF = 6,   /* conv-transpose k==s: n = (dy*s+dx)*Cout + co ->
                              out f16 [b, y*s+dy, x*s+dx, co]  (nn.cpp:117-129)                  */
     VX_EPI_F16_ADD = 7,   /* out f16 = [relu](acc + bias) + res1 + res2 (nullable), conv residual units
@@ -90,7 +90,7 @@ typedef struct {
     int tokens_P;       /* VX_EPI_TOKENS: patches per image                                     */
     /* VX_EPI_QKV */
     void* q; void* k; void* vt;
-    int qkv_T, qkv_Tp, qkv_H; /* tokens per image, padded tokens (v^T row length), heads        */
+    int qkv_T, qkv_Tp, qkv_H; /* tokens per image, (unused), heads; vt receives v as [B,H,T,64]    */
     float q_scale;
     /* VX_EPI_PIXSHUF */
     int ps_s, ps_Cout, ps_H, ps_W; /* stride, real Cout, input H, W; ldo = output channel stride */
@@ -102,10 +102,10 @@ typedef struct {
 VX_API int vx_gemm_f16(const vx_gemm_args* args, void* stream);
 
 /* ---- fused multi-head attention, head_dim 64 (nn.cpp:210-244, dino.cpp:59-74) ------------
- * q,k: f16 [B,H,T,64] (q pre-scaled by 1/sqrt(64)); vt: f16 [B,H,64,Tp] (pad columns finite);
- * out: f16 [B*T, H*64]. softmax in f32, S never leaves registers. */
-VX_API int vx_attention_f16(const void* q, const void* k, const void* vt, void* out, int B, int H, int T,
-                            int Tp, void* stream);
+ * q,k,v: f16 [B,H,T,64] (q pre-scaled by 1/sqrt(64)); out: f16 [B*T, H*64].
+ * softmax in f32, S never leaves registers; V is transposed on the fly by ds_read_b64_tr_b16. */
+VX_API int vx_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int T,
+                            void* stream);
 
 /* ---- LayerNorm (nn.cpp:14-19): x f32 [M,C] -> y f16 [M,C]; biased variance, eps in sqrt --- */
 VX_API int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y, int M, int C,

@@ -109,20 +109,16 @@ def test_gemm_tokens_epilogue():
 def test_gemm_qkv_scatter():
     rng = np.random.default_rng(9)
     B, T, H = 2, 70, 2
-    Cc, Tp = H * 64, 128
+    Cc = H * 64
     a = _h(_rand(rng, B * T, Cc))
     w, b = _h(_rand(rng, 3 * Cc, Cc, scale=Cc ** -0.5)), _rand(rng, 3 * Cc, scale=0.1)
-    q, k, vt = empty(B * H * T * 64 * 2), empty(B * H * T * 64 * 2), empty(B * H * 64 * Tp * 2)
-    gemm(dev(a.astype(np.float16)), pad_weight(w), b, B * T, L.EPI_QKV, lda=Cc, q=q, k=k, vt=vt, qkv_T=T, qkv_Tp=Tp, qkv_H=H,
-         q_scale=0.125)
+    q, k, v = (empty(B * H * T * 64 * 2) for _ in range(3))
+    gemm(dev(a.astype(np.float16)), pad_weight(w), b, B * T, L.EPI_QKV, lda=Cc, q=q, k=k, vt=v, qkv_T=T, qkv_H=H, q_scale=0.125)
     y = oracle.linear(a, w, b).reshape(B, T, 3, H, 64)
-    gq = q.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32)
-    gk = k.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32)
-    gv = vt.to_numpy(np.float16, (B, H, 64, Tp)).astype(np.float32)
+    gq, gk, gv = (t.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32) for t in (q, k, v))
     assert rel_err(gq, y[:, :, 0].transpose(0, 2, 1, 3) * 0.125) < F16_TOL
     assert rel_err(gk, y[:, :, 1].transpose(0, 2, 1, 3)) < F16_TOL
-    assert rel_err(gv[..., :T], y[:, :, 2].transpose(0, 2, 3, 1)) < F16_TOL
-    assert not gv[..., T:].any()  # pad columns untouched
+    assert rel_err(gv, y[:, :, 2].transpose(0, 2, 1, 3)) < F16_TOL
 
 
 @pytest.mark.parametrize("s,c", [(4, 48), (2, 96)])
@@ -181,16 +177,15 @@ def test_conv3x3_implicit_gemm(cin, cout, stride, hw, mode):
 def test_attention(B, H, T):
     """fused MHSA, head_dim 64 (nn.cpp:210-244) vs the oracle's softmax(q k^T * scale) v."""
     rng = np.random.default_rng(T)
-    Cc, Tp = H * 64, -(-T // 64) * 64
+    Cc = H * 64
     q, k, v = (_h(_rand(rng, B, T, Cc)) for _ in range(3))
     scale = 0.125
     qs = _h(q * scale)  # the QKV epilogue stores q pre-scaled (exact: power of two)
     qd = dev(qs.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float16))
     kd = dev(k.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float16))
-    vt = np.zeros((B, H, 64, Tp), np.float16)
-    vt[..., :T] = v.reshape(B, T, H, 64).transpose(0, 2, 3, 1)
+    vd = dev(v.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float16))
     out = empty(B * T * Cc * 2)
-    L.vx_check(api().vx_attention_f16(qd.ptr, kd.ptr, dev(vt).ptr, out.ptr, B, H, T, Tp, None))
+    L.vx_check(api().vx_attention_f16(qd.ptr, kd.ptr, vd.ptr, out.ptr, B, H, T, None))
     sync()
     got = out.to_numpy(np.float16, (B, T, Cc)).astype(np.float32)
     want = np.stack([oracle.attention(q[i], k[i], v[i], H, scale) for i in range(B)])
@@ -206,12 +201,9 @@ def test_attention_online_softmax_rescale_branch():
     q, k, v = (_h(_rand(rng, B, T, 64)) for _ in range(3))
     k[0, 290] = q[0, 7] * 4.0  # key 290 dominates query 7 only
     k = _h(k)
-    Tp = 320
-    vt = np.zeros((B, H, 64, Tp), np.float16)
-    vt[0, 0, :, :T] = v[0].T
     out = empty(T * 64 * 2)
-    L.vx_check(api().vx_attention_f16(dev(_h(q * 0.125).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr, dev(vt).ptr, out.ptr,
-                                      B, H, T, Tp, None))
+    L.vx_check(api().vx_attention_f16(dev(_h(q * 0.125).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr,
+                                      dev(v.astype(np.float16)).ptr, out.ptr, B, H, T, None))
     sync()
     got = out.to_numpy(np.float16, (T, 64)).astype(np.float32)
     want = oracle.attention(q[0], k[0], v[0], 1, 0.125)

@@ -143,7 +143,7 @@ def init() -> ctypes.CDLL:
     lib.vx_graph_launch.argtypes = [c_void_p, c_void_p]
     lib.vx_graph_destroy.argtypes = [c_void_p]
     lib.vx_gemm_f16.argtypes = [POINTER(GemmArgs), c_void_p]
-    lib.vx_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.vx_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.vx_layernorm_f32_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
     lib.vx_preprocess_patches.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]
     lib.vx_preprocess_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]

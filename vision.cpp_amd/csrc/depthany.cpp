@@ -410,7 +410,6 @@ void depthany_reserve(depthany_model& m, int B, int W, int H) {
 
     const int pw = W / ps, ph = H / ps, Pn = pw * ph, T = Pn + 1, D = P.dino.embed_dim, Hh = P.dino.n_heads;
     const long M = (long)B * T;
-    const int Tp = round_up(T, 64);
     const int F = Wt.fusion_c, HC = Wt.head_c;
     const int h3 = (ph + 2 - 3) / 2 + 1, w3 = (pw + 2 - 3) / 2 + 1;
 
@@ -422,7 +421,7 @@ void depthany_reserve(depthany_model& m, int B, int W, int H) {
     L.add("ln", (size_t)M * D * 2);
     L.add("q", (size_t)M * D * 2);
     L.add("k", (size_t)M * D * 2);
-    L.add("vt", (size_t)B * Hh * 64 * Tp * 2);
+    L.add("vt", (size_t)M * D * 2);
     L.add("att", (size_t)M * D * 2);
     L.add("hidden", (size_t)M * Wt.layers[0].fc1.N * 2);
     for (int j = 0; j < 4; ++j) L.add("feat" + std::to_string(j), (size_t)M * D * 2);
@@ -456,8 +455,6 @@ void depthany_reserve(depthany_model& m, int B, int W, int H) {
     for (auto& it : L.items) m.ws.buf[it.first] = static_cast<uint8_t*>(m.ws.arena.ptr) + it.second.first;
     m.ws.B = B; m.ws.W = W; m.ws.H = H;
     void* s = m.backend->stream;
-    // v^T pad columns must stay finite: zero once (the QKV epilogue never writes them)
-    VX(vx_memset(m.ws.buf["vt"], 0, (size_t)B * Hh * 64 * Tp * 2, s));
 
     // position embeddings for this grid (dino.cpp:10-30): as stored, or bicubic-resized on the host
     const uint8_t* wa = static_cast<const uint8_t*>(m.weight_arena.ptr);
@@ -577,7 +574,6 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     const int B = m.ws.B, W = m.ws.W, H = m.ws.H;
     const int ps = P.dino.patch_size, pw = W / ps, ph = H / ps, Pn = pw * ph, T = Pn + 1, D = P.dino.embed_dim, NH = P.dino.n_heads;
     const long M = (long)B * T, MP = (long)B * Pn;
-    const int Tp = round_up(T, 64);
     const int F = Wt.fusion_c, HC = Wt.head_c;
     exec_ctx c{m, stream, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
 
@@ -619,13 +615,13 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
             a.A = ln; a.lda = D;
             a.epi = VX_EPI_QKV;
             a.q = c.buf("q"); a.k = c.buf("k"); a.vt = c.buf("vt");
-            a.qkv_T = T; a.qkv_Tp = Tp; a.qkv_H = NH;
+            a.qkv_T = T; a.qkv_Tp = 0; a.qkv_H = NH;
             a.q_scale = q_scale;
             c.mark("gemm_qkv", 1, 2.0 * M * 3 * D * D, (double)M * D * 2 * 4 + 3.0 * D * D * 2);
             c.gemm(a);
         }
         c.mark("attention", 1, 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
-        VX(vx_attention_f16(c.buf("q"), c.buf("k"), c.buf("vt"), c.buf("att"), B, NH, T, Tp, stream));
+        VX(vx_attention_f16(c.buf("q"), c.buf("k"), c.buf("vt"), c.buf("att"), B, NH, T, stream));
         {
             vx_gemm_args a = c.base(L.out, M);
             a.A = c.buf("att"); a.lda = D;

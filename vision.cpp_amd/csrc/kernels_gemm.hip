@@ -3,13 +3,20 @@
 // K1, K4, K6-K11, K14 (reference call sites: src/visp/nn.cpp:6-12, 72-100, 117-129;
 // src/visp/arch/dino.cpp:48-90; src/visp/arch/depth-anything.cpp:15-96).
 //
-// Tiling: 256 threads = 4 wave64; block tile BM x BN x 64, wave tile WM x WN built from
-// v_mfma_f32_32x32x16_f16 (A and B fragments both K-contiguous: lane l holds row l&31,
-// k = 8*(l>>5)..+7). Both operands are staged through LDS in 128-byte rows whose 16-byte
-// chunks are XOR-swizzled with (row>>1)&7 so that ds_read_b128 of 32 different rows at one
-// k-column is bank-conflict free. Global->LDS staging is register double-buffered: loads of
-// k-tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after
-// them (one barrier per k-tile).
+// Structure (256 threads = 4 wave64 per block, block tile BM x BN x 64):
+//  * both operands go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
+//    instruction = 8 tile rows of 128 B); no staging registers, so 3-4 blocks fit a CU and
+//    one block's load latency / epilogue hides under the others' MFMA phases (K is only
+//    384..1536 on this path, so prologue and epilogue are a large share of a tile's life);
+//  * the LDS image is lane-linear, the (row>>1)&7 XOR swizzle of the 16-byte chunks is applied
+//    to the per-lane SOURCE address and again on the ds_read_b128 fragment reads, which makes
+//    the reads of 32 different rows at one k-column bank-conflict free;
+//  * v_mfma_f32_32x32x16_f16, A and B fragments both K-contiguous (lane l: row l&31,
+//    k = 8*(l>>5)..+7); wave tile WM x WN;
+//  * f16-output epilogues run the MFMA with swapped operands (D = W-frag x A-frag, so a lane owns
+//    one output row and 4 consecutive columns per register group), stage the tile through LDS
+//    and write it with coalesced 16-byte stores; f32 read-modify-write epilogues keep the natural
+//    orientation (a wave instruction covers whole 128-byte rows of x).
 #include "vx_common.h"
 
 namespace {
@@ -17,126 +24,126 @@ namespace {
 constexpr int BK = 64;          // k elements per LDS tile row (128 bytes)
 constexpr int THREADS = 256;
 
-struct ConvRow {                // per staged A row of an implicit-GEMM conv
-    int base;                   // element offset of (b, 0, 0, 0) in the NHWC image, -1 if row >= M
-    int iy0, ix0;               // oy*stride - pad, ox*stride - pad
-};
+__device__ __attribute__((aligned(16))) unsigned char g_zero_page[64]; // source of padded conv taps
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-    // ggml_gelu: 0.5*x*(1+tanh(sqrt(2/pi)*x*(1+0.044715*x*x)))
+    // ggml_gelu: 0.5*x*(1+tanh(sqrt(2/pi)*x*(1+0.044715*x*x))); tanh(u) = 1 - 2/(exp(2u)+1)
     const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
     float u = k0 * x * (1.0f + k1 * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1); exp via exp2
     float e = __builtin_amdgcn_exp2f(u * 2.88539008177792681472f); // 2*log2(e)
-    float t = 1.0f - 2.0f / (e + 1.0f);
+    float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
     return 0.5f * x * (1.0f + t);
+}
+
+constexpr bool epi_is_f16_tile(int epi) {
+    return epi == VX_EPI_F16 || epi == VX_EPI_F16_GELU || epi == VX_EPI_F16_RELU || epi == VX_EPI_F16_ADD ||
+           epi == VX_EPI_QKV || epi == VX_EPI_PIXSHUF;
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool CONV>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_CHUNKS = BM * 8 / THREADS; // 16-byte chunks per thread per k-tile
-    constexpr int B_CHUNKS = BN * 8 / THREADS;
+    constexpr int A_INSTR = BM / 32; // global_load_lds instructions per wave per k-tile (8 rows each)
+    constexpr int B_INSTR = BN / 32;
+    constexpr bool SWAPPED = epi_is_f16_tile(EPI);
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
-    static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small");
-    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const sa = smem;
+    unsigned char* const sb = smem + BM * BK * 2;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int r = lane & 31, h = lane >> 5;
 
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give every XCD a contiguous
+    // run of logical tiles so that the n-tiles of one A row panel are fetched through one L2.
     const int n_tiles_n = p.N / BN;
-    const int tile_m = blockIdx.x / n_tiles_n, tile_n = blockIdx.x % n_tiles_n;
+    int tile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = b & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+    }
+    const int tile_m = tile / n_tiles_n, tile_n = tile - tile_m * n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = p.K / BK;
 
     const f16* __restrict__ Ag = reinterpret_cast<const f16*>(p.A);
     const f16* __restrict__ Wg = reinterpret_cast<const f16*>(p.W);
 
-    // ---- per-thread staging coordinates -------------------------------------------------
-    int a_row[A_CHUNKS], a_ch[A_CHUNKS];
-    long a_off[A_CHUNKS];           // plain mode: element offset of the row start
-    ConvRow a_conv[A_CHUNKS];
+    // ---- per-lane source coordinates: instruction i of this wave fills tile rows (wave*A_INSTR+i)*8 .. +7,
+    // lane l lands at row + l/8, physical chunk l%8, so it must fetch logical chunk (l%8) ^ swz(row)
+    const int l_row = lane >> 3, l_pos = lane & 7;
+    long a_off[A_INSTR];   // plain: element offset of the row start; conv: image base
+    int a_iy0[A_INSTR], a_ix0[A_INSTR], a_chunk[A_INSTR];
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) {
-        int idx = tid + i * THREADS;
-        a_row[i] = idx >> 3;
-        a_ch[i] = idx & 7;
-        int m = m0 + a_row[i];
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int row = (wave * A_INSTR + i) * 8 + l_row;
+        a_chunk[i] = swz_chunk(row, l_pos);
+        int m = m0 + row;
         if constexpr (CONV) {
             if (m < p.M) {
                 int ohw = p.conv_OH * p.conv_OW;
-                int b = m / ohw, rem = m - b * ohw;
-                int oy = rem / p.conv_OW, ox = rem - oy * p.conv_OW;
-                a_conv[i].base = b * p.conv_H * p.conv_W * p.conv_Cin;
-                a_conv[i].iy0 = oy * p.conv_stride - p.conv_pad;
-                a_conv[i].ix0 = ox * p.conv_stride - p.conv_pad;
+                int b = m / ohw, rm = m - b * ohw;
+                int oy = rm / p.conv_OW, ox = rm - oy * p.conv_OW;
+                a_off[i] = (long)b * p.conv_H * p.conv_W * p.conv_Cin;
+                a_iy0[i] = oy * p.conv_stride - p.conv_pad;
+                a_ix0[i] = ox * p.conv_stride - p.conv_pad;
             } else {
-                a_conv[i].base = -1;
-                a_conv[i].iy0 = a_conv[i].ix0 = 0;
+                a_off[i] = -1;
+                a_iy0[i] = a_ix0[i] = 0;
             }
-            a_off[i] = 0;
         } else {
-            if (m >= p.M) m = p.M - 1; // clamp: rows beyond M are computed but never stored
+            if (m >= p.M) m = p.M - 1; // rows beyond M are computed but never stored
             long arow = m;
             if (p.a_group > 0) arow = (long)(m / p.a_group) * p.a_group_stride + p.a_row_off + (m % p.a_group);
             a_off[i] = arow * p.lda;
+            a_iy0[i] = a_ix0[i] = 0;
         }
     }
-    int b_row[B_CHUNKS], b_ch[B_CHUNKS];
+    long b_off[B_INSTR];
+    int b_chunk[B_INSTR];
 #pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) {
-        int idx = tid + i * THREADS;
-        b_row[i] = idx >> 3;
-        b_ch[i] = idx & 7;
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int row = (wave * B_INSTR + i) * 8 + l_row;
+        b_chunk[i] = swz_chunk(row, l_pos);
+        b_off[i] = (long)(n0 + row) * p.K;
     }
-
-    f16x8 a_reg[A_CHUNKS], b_reg[B_CHUNKS];
     const int cin8 = CONV ? (p.conv_Cin >> 3) : 1;
     const int ntaps = CONV ? p.conv_kh * p.conv_kw : 1;
 
-    auto load_tile = [&](int kt) {
+    auto issue_loads = [&](int kt) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
+        for (int i = 0; i < A_INSTR; ++i) {
+            const f16* src;
             if constexpr (CONV) {
-                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                int kc = (k0 >> 3) + a_ch[i];
+                src = reinterpret_cast<const f16*>(g_zero_page);
+                int kc = (k0 >> 3) + a_chunk[i];
                 int tap = kc / cin8, c8 = kc - tap * cin8;
-                if (a_conv[i].base >= 0 && tap < ntaps) {
+                if (a_off[i] >= 0 && tap < ntaps) {
                     int ky = tap / p.conv_kw, kx = tap - ky * p.conv_kw;
-                    int iy = a_conv[i].iy0 + ky, ix = a_conv[i].ix0 + kx;
-                    if ((unsigned)iy < (unsigned)p.conv_H && (unsigned)ix < (unsigned)p.conv_W) {
-                        v = *reinterpret_cast<const f16x8*>(Ag + a_conv[i].base + ((long)iy * p.conv_W + ix) * p.conv_Cin + c8 * 8);
-                        if (p.a_relu) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = v[j] > (f16)0 ? v[j] : (f16)0;
-                        }
-                    }
+                    int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                    if ((unsigned)iy < (unsigned)p.conv_H && (unsigned)ix < (unsigned)p.conv_W)
+                        src = Ag + a_off[i] + ((long)iy * p.conv_W + ix) * p.conv_Cin + c8 * 8;
                 }
-                a_reg[i] = v;
             } else {
-                a_reg[i] = *reinterpret_cast<const f16x8*>(Ag + a_off[i] + k0 + a_ch[i] * 8);
+                src = Ag + a_off[i] + k0 + a_chunk[i] * 8;
             }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave * A_INSTR + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i)
-            b_reg[i] = *reinterpret_cast<const f16x8*>(Wg + (long)(n0 + b_row[i]) * p.K + k0 + b_ch[i] * 8);
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE_BYTES;
-        unsigned char* sb = sa + BM * BK * 2;
-#pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i)
-            *reinterpret_cast<f16x8*>(sa + a_row[i] * 128 + swz_chunk(a_row[i], a_ch[i]) * 16) = a_reg[i];
-#pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i)
-            *reinterpret_cast<f16x8*>(sb + b_row[i] * 128 + swz_chunk(b_row[i], b_ch[i]) * 16) = b_reg[i];
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Wg + b_off[i] + k0 + b_chunk[i] * 8),
+                                             (lptr_t)(sb + (wave * B_INSTR + i) * 1024), 16, 0, 0);
     };
 
     f32x16 acc[MI][NI];
@@ -147,15 +154,10 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
+    issue_loads(0);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const unsigned char* sa = smem + buf * STAGE_BYTES;
-        const unsigned char* sb = sa + BM * BK * 2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // k-tile kt has landed in LDS for every wave
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             f16x8 af[MI], bf[NI];
@@ -163,6 +165,12 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
             for (int mi = 0; mi < MI; ++mi) {
                 int row = wr * WM + mi * 32 + r;
                 af[mi] = *reinterpret_cast<const f16x8*>(sa + row * 128 + swz_chunk(row, ks * 2 + h) * 16);
+                if constexpr (CONV) {
+                    if (p.a_relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) af[mi][j] = af[mi][j] > (f16)0 ? af[mi][j] : (f16)0;
+                    }
+                }
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
@@ -172,66 +180,119 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (SWAPPED) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+                    else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+        __syncthreads(); // every wave is done reading this k-tile
+        if (kt + 1 < nk) issue_loads(kt + 1);
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------
     const int n_valid = p.n_valid > 0 ? p.n_valid : p.N;
+
+    if constexpr (!SWAPPED) {
+        // ---- natural orientation: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); f32 rows of x
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wc * WN + ni * 32 + r;
-            const float bias = p.bias ? p.bias[n] : 0.0f;
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = n0 + wc * WN + ni * 32 + r;
+                const float bias = p.bias ? p.bias[n] : 0.0f;
+                float lam = 0.0f;
+                if constexpr (EPI == VX_EPI_RESID_F32) lam = p.lambda[n];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wr * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = acc[mi][ni][e] + bias;
-                if constexpr (EPI == VX_EPI_F16 || EPI == VX_EPI_F16_GELU || EPI == VX_EPI_F16_RELU) {
-                    if constexpr (EPI == VX_EPI_F16_GELU) v = gelu_tanh(v);
-                    if constexpr (EPI == VX_EPI_F16_RELU) v = fmaxf(v, 0.0f);
-                    if (n < n_valid) reinterpret_cast<f16*>(p.out)[(long)m * p.ldo + n] = (f16)v;
-                } else if constexpr (EPI == VX_EPI_F16_ADD) {
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (n < n_valid) {
-                        long o = (long)m * p.ldo + n;
-                        if (p.res1) v += (float)reinterpret_cast<const f16*>(p.res1)[o];
-                        if (p.res2) v += (float)reinterpret_cast<const f16*>(p.res2)[o];
-                        reinterpret_cast<f16*>(p.out)[o] = (f16)v;
-                    }
-                } else if constexpr (EPI == VX_EPI_RESID_F32) {
-                    float* x = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n;
-                    *x = *x + v * p.lambda[n];
-                } else if constexpr (EPI == VX_EPI_TOKENS) {
-                    int b = m / p.tokens_P, t = m - b * p.tokens_P;
-                    long row = (long)b * (p.tokens_P + 1) + 1 + t;
-                    reinterpret_cast<float*>(p.out)[row * p.ldo + n] = v + p.pos[(long)(1 + t) * p.N + n];
-                } else if constexpr (EPI == VX_EPI_QKV) {
-                    const int C = p.qkv_H * 64;
-                    int which = n / C, cc = n - which * C;
-                    int hh = cc >> 6, d = cc & 63;
-                    int b = m / p.qkv_T, t = m - b * p.qkv_T;
-                    long bh = (long)b * p.qkv_H + hh;
-                    if (which == 0) reinterpret_cast<f16*>(p.q)[(bh * p.qkv_T + t) * 64 + d] = (f16)(v * p.q_scale);
-                    else if (which == 1) reinterpret_cast<f16*>(p.k)[(bh * p.qkv_T + t) * 64 + d] = (f16)v;
-                    else reinterpret_cast<f16*>(p.vt)[(bh * 64 + d) * p.qkv_Tp + t] = (f16)v;
-                } else if constexpr (EPI == VX_EPI_PIXSHUF) {
-                    if (n < n_valid) {
-                        int s = p.ps_s;
-                        int tap = n / p.ps_Cout, co = n - tap * p.ps_Cout;
-                        int dy = tap / s, dx = tap - dy * s;
-                        int hw = p.ps_H * p.ps_W;
-                        int b = m / hw, rem = m - b * hw;
-                        int y = rem / p.ps_W, x = rem - y * p.ps_W;
-                        long o = (((long)b * p.ps_H * s + (y * s + dy)) * (p.ps_W * s) + (x * s + dx)) * p.ldo + co;
-                        reinterpret_cast<f16*>(p.out)[o] = (f16)v;
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wr * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (m >= p.M) continue;
+                    float v = acc[mi][ni][e] + bias;
+                    if constexpr (EPI == VX_EPI_RESID_F32) {
+                        float* x = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n;
+                        *x = *x + v * lam;
+                    } else { // VX_EPI_TOKENS
+                        int b = m / p.tokens_P, t = m - b * p.tokens_P;
+                        long row = (long)b * (p.tokens_P + 1) + 1 + t;
+                        reinterpret_cast<float*>(p.out)[row * p.ldo + n] = v + p.pos[(long)(1 + t) * p.N + n];
                     }
                 }
+            }
+        }
+    } else {
+        // ---- swapped orientation: lane&31 = row m, registers = 4 consecutive columns per group.
+        // Phase 1: bias / activation, pack to f16, stage the BM x BN tile in LDS (16-byte chunks
+        // XOR-swizzled with the row so both the 8-byte writes and the 16-byte reads are conflict free).
+        constexpr int NCH16 = BN / 8;              // 16-byte chunks per staged row
+        constexpr int PITCH = BN * 2;
+        unsigned char* const st = smem;            // the operand stage is dead after the last barrier
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ml = wr * WM + mi * 32 + r;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wc * WN + ni * 32 + 8 * g + 4 * h; // first of 4 consecutive columns
+                    float4 bias = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
+                    float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
+                                  acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (EPI == VX_EPI_F16_GELU) v[j] = gelu_tanh(v[j]);
+                        if constexpr (EPI == VX_EPI_F16_RELU) v[j] = fmaxf(v[j], 0.0f);
+                        if constexpr (EPI == VX_EPI_F16_ADD) { if (p.relu) v[j] = fmaxf(v[j], 0.0f); }
+                        if constexpr (EPI == VX_EPI_QKV) { if (n0 + nl < p.qkv_H * 64) v[j] *= p.q_scale; }
+                    }
+                    f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    const int c8 = nl >> 2;
+                    const int phys16 = (c8 >> 1) ^ (ml & (NCH16 - 1));
+                    *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // Phase 2: coalesced 16-byte stores (consecutive lanes = consecutive chunks of one row)
+        constexpr int CHUNKS = BM * NCH16;
+#pragma unroll
+        for (int it = 0; it < CHUNKS / THREADS; ++it) {
+            const int id = tid + it * THREADS;
+            const int ml = id / NCH16, j = id % NCH16;
+            const int m = m0 + ml, n = n0 + j * 8;
+            if (m >= p.M || n >= n_valid) continue;
+            f16x8 v = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ (ml & (NCH16 - 1))) * 16);
+            if constexpr (EPI == VX_EPI_F16 || EPI == VX_EPI_F16_GELU || EPI == VX_EPI_F16_RELU) {
+                *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + (long)m * p.ldo + n) = v;
+            } else if constexpr (EPI == VX_EPI_F16_ADD) {
+                const long o = (long)m * p.ldo + n;
+                if (p.res1) {
+                    f16x8 a = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.res1) + o);
+                    if (p.res2) {
+                        f16x8 b = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.res2) + o);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = (f16)((float)v[q] + (float)a[q] + (float)b[q]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = (f16)((float)v[q] + (float)a[q]);
+                    }
+                }
+                *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + o) = v;
+            } else if constexpr (EPI == VX_EPI_QKV) {
+                // q, k, v all head-major [B, H, T, 64]; a 16-byte chunk is 8 consecutive d of one head
+                const int C = p.qkv_H * 64;
+                const int which = n / C, cc = n - which * C;
+                const int hh = cc >> 6, d = cc & 63;
+                const int b = m / p.qkv_T, t = m - b * p.qkv_T;
+                f16* dst = reinterpret_cast<f16*>(which == 0 ? p.q : (which == 1 ? p.k : p.vt));
+                *reinterpret_cast<f16x8*>(dst + (((long)b * p.qkv_H + hh) * p.qkv_T + t) * 64 + d) = v;
+            } else if constexpr (EPI == VX_EPI_PIXSHUF) {
+                const int s = p.ps_s;
+                const int tap = n / p.ps_Cout, co = n - tap * p.ps_Cout;
+                const int dy = tap / s, dx = tap - dy * s;
+                const int hw = p.ps_H * p.ps_W;
+                const int b = m / hw, rem = m - b * hw;
+                const int y = rem / p.ps_W, x = rem - y * p.ps_W;
+                const long o = (((long)b * p.ps_H * s + (y * s + dy)) * (p.ps_W * s) + (x * s + dx)) * p.ldo + co;
+                *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + o) = v;
             }
         }
     }
@@ -239,13 +300,10 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
 
 template <int BM, int BN, int WM, int WN, int EPI, bool CONV>
 int launch(const vx_gemm_args& a, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * BK * 2;
+    constexpr int stage = (BM + BN) * BK * 2;
+    constexpr int out_stage = epi_is_f16_tile(EPI) ? BM * BN * 2 : 0;
+    constexpr int smem = stage > out_stage ? stage : out_stage;
     auto kern = gemm_kernel<BM, BN, WM, WN, EPI, CONV>;
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
-        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
     int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(THREADS), smem, s, a);
     VX_LAUNCH_CHECK();
@@ -289,11 +347,16 @@ extern "C" int vx_gemm_f16(const vx_gemm_args* args, void* stream) {
     VX_REQUIRE(a.K % BK == 0, "vx_gemm_f16: K=%d must be a multiple of %d (pad the weights)", a.K, BK);
     VX_REQUIRE(a.N % 32 == 0, "vx_gemm_f16: N=%d must be a multiple of 32", a.N);
     VX_REQUIRE(a.A && a.W, "vx_gemm_f16: null operand");
+    const int nv = a.n_valid > 0 ? a.n_valid : a.N;
+    if (epi_is_f16_tile(a.epi)) {
+        VX_REQUIRE(nv % 8 == 0, "vx_gemm_f16: n_valid=%d must be a multiple of 8 for f16 outputs", nv);
+        VX_REQUIRE(a.epi == VX_EPI_QKV || a.ldo % 8 == 0, "vx_gemm_f16: ldo=%ld must be a multiple of 8", (long)a.ldo);
+    }
+    if (a.epi == VX_EPI_PIXSHUF) VX_REQUIRE(a.ps_Cout % 8 == 0, "vx_gemm_f16: pixel-shuffle Cout=%d must be a multiple of 8", a.ps_Cout);
+    if (a.epi == VX_EPI_QKV) VX_REQUIRE(a.N == 3 * a.qkv_H * 64, "vx_gemm_f16: QKV epilogue needs N == 3*H*64");
     if (a.conv_kh > 0) {
         VX_REQUIRE(a.conv_Cin % 8 == 0, "vx_gemm_f16: conv Cin=%d must be a multiple of 8", a.conv_Cin);
         VX_REQUIRE(a.K >= a.conv_kh * a.conv_kw * a.conv_Cin, "vx_gemm_f16: conv K too small");
-        VX_REQUIRE((long)a.M * 1 <= 0x7fffffffL && (long)a.conv_H * a.conv_W * a.conv_Cin * ((a.M + a.conv_OH * a.conv_OW - 1) / (a.conv_OH * a.conv_OW)) < 0x7fffffffL,
-                   "vx_gemm_f16: conv image too large for 32-bit offsets");
         return dispatch_epi<true>(a, as_stream(stream));
     }
     VX_REQUIRE(a.lda % 8 == 0, "vx_gemm_f16: lda=%ld must be a multiple of 8", (long)a.lda);
