@@ -732,16 +732,20 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         c.conv(FW.rl2_c2, t1, B, h, w, F, 3, 1, 1, t3, F, VX_EPI_F16_ADD, false, false, xin, nullptr, "fusion_rcu");
         // bilinear (align_corners) to the next feature's size, or x2 for the last stage
         const int oh = i < 3 ? lh[j - 1] : 2 * h, ow = i < 3 ? lw[j - 1] : 2 * w;
-        c.mark("bilinear", 1, 0, (double)B * (h * w + oh * ow) * F * 2);
-        VX(vx_bilinear_ac_f16(t3, up, B, h, w, F, oh, ow, stream));
+        // The reference resizes and then applies the 1x1 projection (depth-anything.cpp:36-40). Both are
+        // linear and the bilinear weights sum to 1, so projection (with its bias) and resize commute:
+        // project at the low resolution (1/4 of the FLOPs, no full-resolution intermediate), then resize.
         {
-            vx_gemm_args a = c.base(FW.proj, (long)B * oh * ow); // 1x1 projection (nn.cpp:76-81)
-            a.A = up; a.lda = F;
+            vx_gemm_args a = c.base(FW.proj, (long)B * h * w); // 1x1 projection (nn.cpp:76-81)
+            a.A = t3; a.lda = F;
             a.epi = VX_EPI_F16;
-            a.out = fused; a.ldo = F;
-            c.mark("fusion_proj", 1, 2.0 * B * oh * ow * F * F, (double)B * oh * ow * F * 4);
+            a.out = t1; a.ldo = F;
+            c.mark("fusion_proj", 1, 2.0 * B * h * w * F * F, (double)B * h * w * F * 4);
             c.gemm(a);
         }
+        c.mark("bilinear", 1, 0, (double)B * (h * w + oh * ow) * F * 2);
+        VX(vx_bilinear_ac_f16(t1, fused, B, h, w, F, oh, ow, stream));
+        (void)up;
         prev = fused;
         if (m.captures) { std::string nm = "fusion_" + std::to_string(i); c.capture(nm.c_str(), fused, {B, oh, ow, F}, true); }
     }

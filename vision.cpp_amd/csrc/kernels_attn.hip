@@ -18,6 +18,8 @@
 // Softmax is online, f32, in the exp2 domain (log2(e) folded into one FMA per score).
 #include "vx_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int HD = 64;        // head dim
@@ -87,27 +89,36 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
     // transposed-read lane roles: 16-lane group g = lane>>4 covers d0 = 16*(g&1) .. +15 of key-half g>>1 (== h);
     // lane 4q+p of the group supplies the address of key row q, columns d0 + 4p .. +3
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_d0 = 16 * ((lane >> 4) & 1);
+    // loop-invariant LDS byte offsets (everything else is a compile-time immediate):
+    //  K fragment of d-step st, key block kb: k_off[st] + kb*4096   (swizzle term (r>>1)&7 is per lane)
+    //  V^T tr-read of d block db, key step ks, half a/b: v_off[db] + ks*2048 (+1024 for b)
+    int k_off[4], v_off[2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) k_off[st] = r * 128 + k_swz(r, st * 2 + h) * 16;
+    {
+        const int key = 4 * h + tr_q, dd = tr_d0 + 4 * tr_p;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) v_off[db] = key * 128 + v_swz(key, (db * 32 + dd) >> 3) * 16 + (dd & 7) * 2;
+    }
 
-    issue_loads(0, 0);
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
+    // one 64-key tile; BUF is a compile-time constant so every LDS offset folds into an immediate
+    auto tile_body = [&](int t, auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // tile t landed; every wave finished tile t-1, so the other stage is free
-        if (t + 1 < n_tiles) issue_loads(t + 1, buf ^ 1);
-        const unsigned char* sk = smem + buf * (2 * TILE_BYTES);
+        if (t + 1 < n_tiles) issue_loads(t + 1, BUF ^ 1);
+        const unsigned char* sk = smem + BUF * (2 * TILE_BYTES);
         const unsigned char* sv = sk + TILE_BYTES;
 
-        // ---- S^T = K Q^T : 2 key blocks x 4 d-steps
+        // ---- S^T = K Q^T : 2 key blocks x 4 d-steps (first step accumulates onto a constant zero)
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 s[2];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { s[0][e] = 0.0f; s[1][e] = 0.0f; }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                int row = kb * 32 + r;
-                f16x8 kf = *reinterpret_cast<const f16x8*>(sk + row * 128 + k_swz(row, st * 2 + h) * 16);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
+                f16x8 kf = *reinterpret_cast<const f16x8*>(sk + k_off[st] + kb * 4096);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], st == 0 ? zero : s[kb], 0, 0, 0);
             }
         }
         // ---- mask keys beyond T (last tile only), running max in the exp2 domain
@@ -128,20 +139,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
             for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, s[kb][e]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc * LOG2E);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        // rescale the running output only when some query of this wave saw a larger maximum
+        // (wave-uniform branch; after the first tiles the maxima rarely move)
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+            m_run = m_new;
+        }
         float psum = 0.0f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][e], LOG2E, -m_new));
+                float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][e], LOG2E, -m_run));
                 s[kb][e] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+        l_run += psum;
 
         // ---- O^T += V^T P^T : 4 key steps x 2 d blocks; V^T fragments by transposed LDS reads
 #pragma unroll
@@ -152,16 +168,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 // element j <-> key 16ks + 8(j>>2) + 4h + (j&3): two 4-key blocks, each one tr read
-                const int d = db * 32 + tr_d0 + 4 * tr_p;
-                const int key_a = 16 * ks + 4 * h + tr_q, key_b = key_a + 8;
                 hv4 va = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                    (__attribute__((address_space(3))) hv4*)(sv + key_a * 128 + v_swz(key_a, d >> 3) * 16 + (d & 7) * 2));
+                    (__attribute__((address_space(3))) hv4*)(sv + v_off[db] + ks * 2048));
                 hv4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                    (__attribute__((address_space(3))) hv4*)(sv + key_b * 128 + v_swz(key_b, d >> 3) * 16 + (d & 7) * 2));
+                    (__attribute__((address_space(3))) hv4*)(sv + v_off[db] + ks * 2048 + 1024));
                 f16x8 vf = {(f16)va[0], (f16)va[1], (f16)va[2], (f16)va[3], (f16)vb[0], (f16)vb[1], (f16)vb[2], (f16)vb[3]};
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[db], 0, 0, 0);
             }
         }
+    };
+
+    issue_loads(0, 0);
+    for (int t = 0; t < n_tiles; t += 2) {
+        tile_body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < n_tiles) tile_body(t + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- finalize: O[q, head*64 + d] = o / l

@@ -32,12 +32,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-    // ggml_gelu: 0.5*x*(1+tanh(sqrt(2/pi)*x*(1+0.044715*x*x))); tanh(u) = 1 - 2/(exp(2u)+1)
-    const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
-    float u = k0 * x * (1.0f + k1 * x * x);
-    float e = __builtin_amdgcn_exp2f(u * 2.88539008177792681472f); // 2*log2(e)
-    float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return 0.5f * x * (1.0f + t);
+    // ggml_gelu: 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*x*(1+0.044715*x*x). With tanh(u) = 2*sigmoid(2u) - 1
+    // this is x * sigmoid(2u) = x / (1 + exp(-2u)): 7 VALU ops, two of them transcendental.
+    const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f; // -2*sqrt(2/pi)*log2(e)
+    const float c3 = c1 * 0.044715f;
+    float w = fmaf(x * x, c3, c1);
+    float e = __builtin_amdgcn_exp2f(x * w);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 constexpr bool epi_is_f16_tile(int epi) {
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int A_INSTR = BM / 32; // global_load_lds instructions per wave per k-tile (8 rows each)
     constexpr int B_INSTR = BN / 32;
-    constexpr bool SWAPPED = epi_is_f16_tile(EPI);
+    constexpr bool SWAPPED = true; // every epilogue wants a lane to own an output row (see below)
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -191,28 +192,40 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
 
     const int n_valid = p.n_valid > 0 ? p.n_valid : p.N;
 
-    if constexpr (!SWAPPED) {
-        // ---- natural orientation: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); f32 rows of x
+    if constexpr (!epi_is_f16_tile(EPI)) {
+        // ---- f32 outputs (residual stream x): a lane owns row m and 4 consecutive columns per register
+        // group, so the read-modify-write runs on 16-byte accesses (16 + 16 per lane instead of 64 + 64)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wr * WM + mi * 32 + r;
+            if (m >= p.M) continue;
+            long row = m;
+            int t = 0;
+            if constexpr (EPI == VX_EPI_TOKENS) {
+                int b = m / p.tokens_P;
+                t = m - b * p.tokens_P;
+                row = (long)b * (p.tokens_P + 1) + 1 + t;
+            }
+            float* xrow = reinterpret_cast<float*>(p.out) + row * p.ldo;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int n = n0 + wc * WN + ni * 32 + r;
-                const float bias = p.bias ? p.bias[n] : 0.0f;
-                float lam = 0.0f;
-                if constexpr (EPI == VX_EPI_RESID_F32) lam = p.lambda[n];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wr * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (m >= p.M) continue;
-                    float v = acc[mi][ni][e] + bias;
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wc * WN + ni * 32 + 8 * g + 4 * h;
+                    float4 bias = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
+                    float4 v = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
+                                acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
+                    float4* xp = reinterpret_cast<float4*>(xrow + n);
                     if constexpr (EPI == VX_EPI_RESID_F32) {
-                        float* x = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n;
-                        *x = *x + v * lam;
+                        const float4 lam = *reinterpret_cast<const float4*>(p.lambda + n);
+                        float4 x = *xp;
+                        x.x += v.x * lam.x; x.y += v.y * lam.y; x.z += v.z * lam.z; x.w += v.w * lam.w;
+                        *xp = x;
                     } else { // VX_EPI_TOKENS
-                        int b = m / p.tokens_P, t = m - b * p.tokens_P;
-                        long row = (long)b * (p.tokens_P + 1) + 1 + t;
-                        reinterpret_cast<float*>(p.out)[row * p.ldo + n] = v + p.pos[(long)(1 + t) * p.N + n];
+                        const float4 pe = *reinterpret_cast<const float4*>(p.pos + (long)(1 + t) * p.N + n);
+                        v.x += pe.x; v.y += pe.y; v.z += pe.z; v.w += pe.w;
+                        *xp = v;
                     }
                 }
             }
