@@ -97,6 +97,8 @@ typedef struct {
     /* VX_EPI_F16_ADD */
     const void* res1; const void* res2; /* f16 [M, ldo] or NULL */
     int n_valid;        /* columns >= n_valid are not stored (N padded for tiling); 0 = N        */
+    int stages;         /* LDS ring depth of the k-loop: 0 = kernel default (tuning knob for benches) */
+    void* debug_stamps; /* diagnostics only: u64 [blocks][8] s_memtime stamps per phase, NULL in product */
 } vx_gemm_args;
 
 VX_API int vx_gemm_f16(const vx_gemm_args* args, void* stream);

@@ -46,21 +46,26 @@ constexpr bool epi_is_f16_tile(int epi) {
            epi == VX_EPI_QKV || epi == VX_EPI_PIXSHUF;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool CONV>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool CONV>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int A_INSTR = BM / 32; // global_load_lds instructions per wave per k-tile (8 rows each)
     constexpr int B_INSTR = BN / 32;
-    constexpr bool SWAPPED = true; // every epilogue wants a lane to own an output row (see below)
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
 
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int LOADS = A_INSTR + B_INSTR; // global_load_lds per wave per k-tile (vmcnt units)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const sa = smem;
-    unsigned char* const sb = smem + BM * BK * 2;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // optional phase stamps (diagnostic runs only: args.debug_stamps is null in the product path)
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(p.debug_stamps);
+    auto stamp = [&](int slot) {
+        if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int r = lane & 31, h = lane >> 5;
 
@@ -76,6 +81,16 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
     const int tile_m = tile / n_tiles_n, tile_n = tile - tile_m * n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = p.K / BK;
+
+    // per-column epilogue vectors (bias, LayerScale lambda) are fetched ONCE, now, into a small LDS side
+    // buffer behind the operand ring: their L2 latency hides under the k-loop instead of stalling the
+    // epilogue (16 dependent float4 loads per lane measured 10-30k cycles there)
+    float* const s_bias = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);
+    float* const s_lambda = s_bias + BN;
+    if (tid < BN) {
+        s_bias[tid] = p.bias ? p.bias[n0 + tid] : 0.0f;
+        if constexpr (EPI == VX_EPI_RESID_F32) s_lambda[tid] = p.lambda[n0 + tid];
+    }
 
     const f16* __restrict__ Ag = reinterpret_cast<const f16*>(p.A);
     const f16* __restrict__ Wg = reinterpret_cast<const f16*>(p.W);
@@ -121,7 +136,9 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
     const int cin8 = CONV ? (p.conv_Cin >> 3) : 1;
     const int ntaps = CONV ? p.conv_kh * p.conv_kw : 1;
 
-    auto issue_loads = [&](int kt) {
+    auto issue_loads = [&](int kt, int stage) {
+        unsigned char* const sa = smem + stage * STAGE_BYTES;
+        unsigned char* const sb = sa + BM * BK * 2;
         const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
@@ -155,17 +172,21 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
-    issue_loads(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // k-tile kt has landed in LDS for every wave
+    // fragment read offsets: the swizzle term (row>>1)&7 only depends on the lane (tile row offsets are
+    // multiples of 32), so 4 per-lane offsets cover every (mi / ni, k-step) through immediates
+    int f_off[BK / 16];
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) f_off[ks] = r * 128 + swz_chunk(r, ks * 2 + h) * 16;
+
+    auto compute = [&](int stage) {
+        const unsigned char* const sa = smem + stage * STAGE_BYTES + wr * WM * 128;
+        const unsigned char* const sb = smem + stage * STAGE_BYTES + BM * BK * 2 + wc * WN * 128;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             f16x8 af[MI], bf[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                int row = wr * WM + mi * 32 + r;
-                af[mi] = *reinterpret_cast<const f16x8*>(sa + row * 128 + swz_chunk(row, ks * 2 + h) * 16);
+                af[mi] = *reinterpret_cast<const f16x8*>(sa + f_off[ks] + mi * 32 * 128);
                 if constexpr (CONV) {
                     if (p.a_relu) {
 #pragma unroll
@@ -174,23 +195,54 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
                 }
             }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                int row = wc * WN + ni * 32 + r;
-                bf[ni] = *reinterpret_cast<const f16x8*>(sb + row * 128 + swz_chunk(row, ks * 2 + h) * 16);
-            }
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f16x8*>(sb + f_off[ks] + ni * 32 * 128);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    if constexpr (SWAPPED) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-                    else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-                }
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
         }
-        __syncthreads(); // every wave is done reading this k-tile
-        if (kt + 1 < nk) issue_loads(kt + 1);
+    };
+    // raw barrier: __syncthreads() would drain the LDS-DMA queue (vmcnt(0)) and serialise the ring
+    auto barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    stamp(1);
+    if constexpr (STAGES == 1) {
+        issue_loads(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            barrier(); // k-tile kt has landed in LDS for every wave
+            if (kt == 0) stamp(2);
+            compute(0);
+            barrier(); // every wave is done reading this k-tile
+            if (kt + 1 < nk) issue_loads(kt + 1, 0);
+        }
+    } else {
+        // ring of STAGES k-tiles, STAGES-1 of them in flight; one barrier per k-tile
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) issue_loads(s, s);
+        int stage = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = min(STAGES - 2, nk - 1 - kt); // tiles that may stay in flight behind tile kt
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            barrier(); // tile kt visible to all waves; all waves are done with tile kt-1, its stage is free
+            int next_stage = stage == 0 ? STAGES - 1 : stage - 1; // == (kt + STAGES - 1) % STAGES
+            if (kt + STAGES - 1 < nk) issue_loads(kt + STAGES - 1, next_stage);
+            compute(stage);
+            stage = stage + 1 == STAGES ? 0 : stage + 1;
+        }
+        barrier(); // the epilogue reuses the ring as its staging buffer
     }
 
     const int n_valid = p.n_valid > 0 ? p.n_valid : p.N;
+    stamp(3);
 
     if constexpr (!epi_is_f16_tile(EPI)) {
         // ---- f32 outputs (residual stream x): a lane owns row m and 4 consecutive columns per register
@@ -206,27 +258,33 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
                 t = m - b * p.tokens_P;
                 row = (long)b * (p.tokens_P + 1) + 1 + t;
             }
-            float* xrow = reinterpret_cast<float*>(p.out) + row * p.ldo;
+            float* xrow = reinterpret_cast<float*>(p.out) + row * p.ldo + n0;
+            const float* add_row = nullptr; // the tensor read-modify-written with the result
+            if constexpr (EPI == VX_EPI_RESID_F32) add_row = xrow;
+            else add_row = p.pos + (long)(1 + t) * p.N + n0;
+            // issue all NI*4 row loads first (one latency, not NI*4 dependent ones), then combine and store
+            float4 xin[NI][4];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    xin[ni][g] = *reinterpret_cast<const float4*>(add_row + wc * WN + ni * 32 + 8 * g + 4 * h);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wc * WN + ni * 32 + 8 * g + 4 * h;
-                    float4 bias = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
+                    const int nl = wc * WN + ni * 32 + 8 * g + 4 * h;
+                    const float4 bias = *reinterpret_cast<const float4*>(s_bias + nl);
                     float4 v = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
                                 acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
-                    float4* xp = reinterpret_cast<float4*>(xrow + n);
+                    float4 x = xin[ni][g];
                     if constexpr (EPI == VX_EPI_RESID_F32) {
-                        const float4 lam = *reinterpret_cast<const float4*>(p.lambda + n);
-                        float4 x = *xp;
+                        const float4 lam = *reinterpret_cast<const float4*>(s_lambda + nl);
                         x.x += v.x * lam.x; x.y += v.y * lam.y; x.z += v.z * lam.z; x.w += v.w * lam.w;
-                        *xp = x;
-                    } else { // VX_EPI_TOKENS
-                        const float4 pe = *reinterpret_cast<const float4*>(p.pos + (long)(1 + t) * p.N + n);
-                        v.x += pe.x; v.y += pe.y; v.z += pe.z; v.w += pe.w;
-                        *xp = v;
+                    } else { // VX_EPI_TOKENS: patch token + position embedding
+                        x.x += v.x; x.y += v.y; x.z += v.z; x.w += v.w;
                     }
+                    *reinterpret_cast<float4*>(xrow + nl) = x;
                 }
             }
         }
@@ -237,6 +295,9 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
         constexpr int NCH16 = BN / 8;              // 16-byte chunks per staged row
         constexpr int PITCH = BN * 2;
         unsigned char* const st = smem;            // the operand stage is dead after the last barrier
+        // QKV: a 128-column tile lies entirely inside q, k or v (C % 128 == 0), so the q scale is block uniform
+        float out_scale = 1.0f;
+        if constexpr (EPI == VX_EPI_QKV) out_scale = n0 < p.qkv_H * 64 ? p.q_scale : 1.0f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int ml = wr * WM + mi * 32 + r;
@@ -245,8 +306,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int nl = wc * WN + ni * 32 + 8 * g + 4 * h; // first of 4 consecutive columns
-                    float4 bias = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
+                    const float4 bias = *reinterpret_cast<const float4*>(s_bias + nl);
                     float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
                                   acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
 #pragma unroll
@@ -254,7 +314,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
                         if constexpr (EPI == VX_EPI_F16_GELU) v[j] = gelu_tanh(v[j]);
                         if constexpr (EPI == VX_EPI_F16_RELU) v[j] = fmaxf(v[j], 0.0f);
                         if constexpr (EPI == VX_EPI_F16_ADD) { if (p.relu) v[j] = fmaxf(v[j], 0.0f); }
-                        if constexpr (EPI == VX_EPI_QKV) { if (n0 + nl < p.qkv_H * 64) v[j] *= p.q_scale; }
+                        if constexpr (EPI == VX_EPI_QKV) v[j] *= out_scale;
                     }
                     f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                     const int c8 = nl >> 2;
@@ -264,6 +324,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
             }
         }
         __syncthreads();
+        stamp(4);
         // Phase 2: coalesced 16-byte stores (consecutive lanes = consecutive chunks of one row)
         constexpr int CHUNKS = BM * NCH16;
 #pragma unroll
@@ -291,10 +352,15 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
                 *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + o) = v;
             } else if constexpr (EPI == VX_EPI_QKV) {
                 // q, k, v all head-major [B, H, T, 64]; a 16-byte chunk is 8 consecutive d of one head
+                // block-uniform: which of q/k/v (tile inside one of them) and the first image of the tile;
+                // a 128-row tile spans at most two images when T >= 128 (else fall back to a division)
                 const int C = p.qkv_H * 64;
-                const int which = n / C, cc = n - which * C;
+                const int which = n0 / C, cc = n - which * C;
                 const int hh = cc >> 6, d = cc & 63;
-                const int b = m / p.qkv_T, t = m - b * p.qkv_T;
+                const int b0 = m0 / p.qkv_T;
+                int b = b0 + (m >= (b0 + 1) * p.qkv_T ? 1 : 0);
+                if (p.qkv_T < BM) b = m / p.qkv_T;
+                const int t = m - b * p.qkv_T;
                 f16* dst = reinterpret_cast<f16*>(which == 0 ? p.q : (which == 1 ? p.k : p.vt));
                 *reinterpret_cast<f16x8*>(dst + (((long)b * p.qkv_H + hh) * p.qkv_T + t) * 64 + d) = v;
             } else if constexpr (EPI == VX_EPI_PIXSHUF) {
@@ -309,14 +375,22 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
             }
         }
     }
+    stamp(5);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool CONV>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool CONV>
 int launch(const vx_gemm_args& a, hipStream_t s) {
-    constexpr int stage = (BM + BN) * BK * 2;
+    constexpr int ring = STAGES * (BM + BN) * BK * 2;
     constexpr int out_stage = epi_is_f16_tile(EPI) ? BM * BN * 2 : 0;
-    constexpr int smem = stage > out_stage ? stage : out_stage;
-    auto kern = gemm_kernel<BM, BN, WM, WN, EPI, CONV>;
+    constexpr int smem = (ring > out_stage ? ring : out_stage) + 2 * BN * 4; // + bias / lambda side buffer
+    auto kern = gemm_kernel<BM, BN, WM, WN, STAGES, EPI, CONV>;
+    if constexpr (smem > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+    }
     int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(THREADS), smem, s, a);
     VX_LAUNCH_CHECK();
@@ -325,9 +399,19 @@ int launch(const vx_gemm_args& a, hipStream_t s) {
 
 template <int EPI, bool CONV>
 int dispatch_tile(const vx_gemm_args& a, hipStream_t s) {
-    if (a.N % 128 == 0) return launch<128, 128, 64, 64, EPI, CONV>(a, s);
-    if (a.N % 64 == 0) return launch<128, 64, 64, 32, EPI, CONV>(a, s);
-    return launch<128, 32, 32, 32, EPI, CONV>(a, s);
+    if (a.N % 128 == 0) {
+        // stages: 0 = default = 1. Measured (tools/bench_kernels.py, M=43840): the single-stage form at
+        // 3 blocks/CU beats a 2-deep ring at 2 blocks/CU (587 vs 490 TF for K=384, equal for K=1536)
+        // and a 3-deep ring at 1 block/CU (320 TF): occupancy hides the load latency better here.
+        if constexpr (!CONV) {
+            if (a.stages == 2) return launch<128, 128, 64, 64, 2, EPI, CONV>(a, s);
+            return launch<128, 128, 64, 64, 1, EPI, CONV>(a, s);
+        } else {
+            return launch<128, 128, 64, 64, 1, EPI, CONV>(a, s);
+        }
+    }
+    if (a.N % 64 == 0) return launch<128, 64, 64, 32, 1, EPI, CONV>(a, s);
+    return launch<128, 32, 32, 32, 1, EPI, CONV>(a, s);
 }
 
 template <bool CONV>
