@@ -287,3 +287,19 @@ def test_constant_image_normalizes_to_zero():
     L.vx_check(api().vx_minmax_normalize(dev(d).ptr, out.ptr, mm.ptr, 1, 1000, None))
     sync()
     assert not out.to_numpy(np.float32, (1000,)).any()
+
+
+@pytest.mark.parametrize("stages", [2, 4, 8])
+def test_gemm_tuning_variants(stages):
+    """The LDS-ring depth / block-tile knob (vx_gemm_args.stages) must not change results."""
+    rng = np.random.default_rng(stages)
+    M, N, K = 1370 * 2 + 77, 384, 384
+    a, w, b = _h(_rand(rng, M, K)), _h(_rand(rng, N, K, scale=K ** -0.5)), _rand(rng, N, scale=0.1)
+    out = empty(M * N * 2)
+    gemm(dev(a.astype(np.float16)), pad_weight(w), b, M, L.EPI_F16_GELU, lda=K, out=out, ldo=N, stages=stages)
+    want = oracle.gelu(oracle.linear(a, w, b), oracle.GELU_TANH_F32)
+    assert rel_err(out.to_numpy(np.float16, (M, N)).astype(np.float32), want) < F16_TOL
+    lam, x = _rand(rng, N, scale=0.3), _rand(rng, M, N)
+    xd = dev(x)
+    gemm(dev(a.astype(np.float16)), pad_weight(w), b, M, L.EPI_RESID_F32, lda=K, out=xd, ldo=N, lambda_=dev(lam), stages=stages)
+    assert rel_err(xd.to_numpy(np.float32, (M, N)), x + oracle.linear(a, w, b) * lam) < 1e-3

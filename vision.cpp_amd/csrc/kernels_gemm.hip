@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int BK = 64;          // k elements per LDS tile row (128 bytes)
-constexpr int THREADS = 256;
+constexpr int WAVE = 64;
 
 __device__ __attribute__((aligned(16))) unsigned char g_zero_page[64]; // source of padded conv taps
 
@@ -47,12 +47,14 @@ constexpr bool epi_is_f16_tile(int epi) {
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool CONV>
-__global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const vx_gemm_args p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_INSTR = BM / 32; // global_load_lds instructions per wave per k-tile (8 rows each)
-    constexpr int B_INSTR = BN / 32;
-    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int NWAVES = (BM / WM) * WAVES_N;
+    constexpr int THREADS = WAVE * NWAVES;
+    constexpr int A_INSTR = BM / (8 * NWAVES); // global_load_lds instructions per wave per k-tile (8 rows each)
+    constexpr int B_INSTR = BN / (8 * NWAVES);
+    static_assert(A_INSTR >= 1 && B_INSTR >= 1 && (128 * (BN / 8)) % THREADS == 0, "tile / wave layout");
 
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int LOADS = A_INSTR + B_INSTR; // global_load_lds per wave per k-tile (vmcnt units)
@@ -181,26 +183,34 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
     auto compute = [&](int stage) {
         const unsigned char* const sa = smem + stage * STAGE_BYTES + wr * WM * 128;
         const unsigned char* const sb = smem + stage * STAGE_BYTES + BM * BK * 2 + wc * WN * 128;
+        // fragments are double-buffered in registers: the ds_reads of k-step ks+1 are in flight while the
+        // MFMAs of k-step ks issue (the compiler keeps one register set and serialises them otherwise)
+        f16x8 af[2][MI], bf[2][NI];
+        auto load_frags = [&](int ks, int set) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[set][mi] = *reinterpret_cast<const f16x8*>(sa + f_off[ks] + mi * 32 * 128);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bf[set][ni] = *reinterpret_cast<const f16x8*>(sb + f_off[ks] + ni * 32 * 128);
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            f16x8 af[MI], bf[NI];
+            const int set = ks & 1;
+            if (ks + 1 < BK / 16) load_frags(ks + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0); // keep the prefetch ahead of this step's MFMAs
+            if constexpr (CONV) {
+                if (p.a_relu) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                af[mi] = *reinterpret_cast<const f16x8*>(sa + f_off[ks] + mi * 32 * 128);
-                if constexpr (CONV) {
-                    if (p.a_relu) {
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) af[mi][j] = af[mi][j] > (f16)0 ? af[mi][j] : (f16)0;
-                    }
+                        for (int j = 0; j < 8; ++j) af[set][mi][j] = af[set][mi][j] > (f16)0 ? af[set][mi][j] : (f16)0;
                 }
             }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f16x8*>(sb + f_off[ks] + ni * 32 * 128);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[set][ni], af[set][mi], acc[mi][ni], 0, 0, 0);
         }
     };
     // raw barrier: __syncthreads() would drain the LDS-DMA queue (vmcnt(0)) and serialise the ring
@@ -298,9 +308,18 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
         // QKV: a 128-column tile lies entirely inside q, k or v (C % 128 == 0), so the q scale is block uniform
         float out_scale = 1.0f;
         if constexpr (EPI == VX_EPI_QKV) out_scale = n0 < p.qkv_H * 64 ? p.q_scale : 1.0f;
+        // The staging buffer holds 128 rows; taller block tiles are written in BM/128 passes, pass ps
+        // taking MI/PASSES of every wave's row blocks (staged row sl <-> tile row wr*WM + ps*WPP + sl%WPP).
+        constexpr int PASSES = BM / 128;
+        constexpr int MPP = MI / PASSES;            // row blocks per wave per pass
+        constexpr int WPP = WM / PASSES;            // rows per wave per pass
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int ml = wr * WM + mi * 32 + r;
+        for (int ps = 0; ps < PASSES; ++ps) {
+        if (ps > 0) __syncthreads();                // previous pass fully read out
+#pragma unroll
+        for (int mp = 0; mp < MPP; ++mp) {
+            const int mi = ps * MPP + mp;
+            const int ml = wr * WPP + mp * 32 + r;  // staged row
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -324,14 +343,14 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
             }
         }
         __syncthreads();
-        stamp(4);
+        if (ps == 0) stamp(4);
         // Phase 2: coalesced 16-byte stores (consecutive lanes = consecutive chunks of one row)
-        constexpr int CHUNKS = BM * NCH16;
+        constexpr int CHUNKS = 128 * NCH16;
 #pragma unroll
         for (int it = 0; it < CHUNKS / THREADS; ++it) {
             const int id = tid + it * THREADS;
             const int ml = id / NCH16, j = id % NCH16;
-            const int m = m0 + ml, n = n0 + j * 8;
+            const int m = m0 + (ml / WPP) * WM + ps * WPP + (ml % WPP), n = n0 + j * 8;
             if (m >= p.M || n >= n_valid) continue;
             f16x8 v = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ (ml & (NCH16 - 1))) * 16);
             if constexpr (EPI == VX_EPI_F16 || EPI == VX_EPI_F16_GELU || EPI == VX_EPI_F16_RELU) {
@@ -359,7 +378,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
                 const int hh = cc >> 6, d = cc & 63;
                 const int b0 = m0 / p.qkv_T;
                 int b = b0 + (m >= (b0 + 1) * p.qkv_T ? 1 : 0);
-                if (p.qkv_T < BM) b = m / p.qkv_T;
+                if (p.qkv_T < BM) b = m / p.qkv_T; // (more than two images per tile)
                 const int t = m - b * p.qkv_T;
                 f16* dst = reinterpret_cast<f16*>(which == 0 ? p.q : (which == 1 ? p.k : p.vt));
                 *reinterpret_cast<f16x8*>(dst + (((long)b * p.qkv_H + hh) * p.qkv_T + t) * 64 + d) = v;
@@ -374,6 +393,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
                 *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + o) = v;
             }
         }
+        } // passes
     }
     stamp(5);
 }
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const vx_gemm_args p) {
 template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool CONV>
 int launch(const vx_gemm_args& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * BK * 2;
-    constexpr int out_stage = epi_is_f16_tile(EPI) ? BM * BN * 2 : 0;
+    constexpr int out_stage = epi_is_f16_tile(EPI) ? 128 * BN * 2 : 0;
     constexpr int smem = (ring > out_stage ? ring : out_stage) + 2 * BN * 4; // + bias / lambda side buffer
     auto kern = gemm_kernel<BM, BN, WM, WN, STAGES, EPI, CONV>;
     if constexpr (smem > 48 * 1024) {
@@ -392,7 +412,7 @@ int launch(const vx_gemm_args& a, hipStream_t s) {
         }
     }
     int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(THREADS), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * (BM / WM) * (BN / WN)), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
 }
@@ -405,6 +425,9 @@ int dispatch_tile(const vx_gemm_args& a, hipStream_t s) {
         // and a 3-deep ring at 1 block/CU (320 TF): occupancy hides the load latency better here.
         if constexpr (!CONV) {
             if (a.stages == 2) return launch<128, 128, 64, 64, 2, EPI, CONV>(a, s);
+            if (a.stages == 4) return launch<256, 128, 128, 64, 1, EPI, CONV>(a, s); // 256x128 block tile, 4 waves
+            if (a.stages == 8) return launch<256, 128, 64, 64, 1, EPI, CONV>(a, s);  // 256x128 block tile, 8 waves
+            if (a.stages == 16) return launch<128, 64, 64, 32, 1, EPI, CONV>(a, s);  // 128x64 block tile
             return launch<128, 128, 64, 64, 1, EPI, CONV>(a, s);
         } else {
             return launch<128, 128, 64, 64, 1, EPI, CONV>(a, s);
