@@ -63,6 +63,8 @@ enum vx_epilogue {
                              out f16 [b, y*s+dy, x*s+dx, co]  (nn.cpp:117-129)                  */
     VX_EPI_F16_ADD = 7,   /* out f16 = [relu](acc + bias) + res1 + res2 (nullable), conv residual units
                              (depth-anything.cpp:15-30)                                          */
+    VX_EPI_HEAD_OUT = 8,  /* N == 32: out f32 [M] = head_scale * relu(sum_n relu(acc+bias)[n] * lambda[n] + head_bias):
+                             head.conv2 + ReLU + head.conv3 (1x1 -> 1) + ReLU fused (depth-anything.cpp:87-94) */
 };
 
 typedef struct {
@@ -98,6 +100,7 @@ typedef struct {
     const void* res1; const void* res2; /* f16 [M, ldo] or NULL */
     int n_valid;        /* columns >= n_valid are not stored (N padded for tiling); 0 = N        */
     int stages;         /* LDS ring depth of the k-loop: 0 = kernel default (tuning knob for benches) */
+    float head_bias, head_scale; /* VX_EPI_HEAD_OUT: conv3 bias, max_depth; lambda = conv3 weights f32 [N] */
     void* debug_stamps; /* diagnostics only: u64 [blocks][8] s_memtime stamps per phase, NULL in product */
 } vx_gemm_args;
 

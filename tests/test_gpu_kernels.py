@@ -303,3 +303,20 @@ def test_gemm_tuning_variants(stages):
     xd = dev(x)
     gemm(dev(a.astype(np.float16)), pad_weight(w), b, M, L.EPI_RESID_F32, lda=K, out=xd, ldo=N, lambda_=dev(lam), stages=stages)
     assert rel_err(xd.to_numpy(np.float32, (M, N)), x + oracle.linear(a, w, b) * lam) < 1e-3
+
+
+def test_conv3x3_fused_head_output():
+    """head.conv2 + ReLU + head.conv3 + ReLU in one kernel (depth-anything.cpp:87-94) vs oracle conv + 1x1."""
+    rng = np.random.default_rng(11)
+    B, Hh, Ww, Cc = 2, 29, 31, 32
+    x = _h(_rand(rng, B, Hh, Ww, Cc))
+    w, b = _h(_rand(rng, 32, 3, 3, Cc, scale=(9 * Cc) ** -0.5)), _rand(rng, 32, scale=0.1)
+    w3, b3 = np.abs(_rand(rng, 32, scale=0.3)), 0.05
+    out = empty(B * Hh * Ww * 4)
+    gemm(dev(x.astype(np.float16)), pad_weight(w.reshape(32, -1)), b, B * Hh * Ww, L.EPI_HEAD_OUT, out=out, ldo=1,
+         conv_kh=3, conv_kw=3, conv_stride=1, conv_pad=1, conv_H=Hh, conv_W=Ww, conv_Cin=Cc, conv_OH=Hh, conv_OW=Ww,
+         lambda_=dev(w3), head_bias=b3, head_scale=2.0)
+    got = out.to_numpy(np.float32, (B, Hh, Ww))
+    h2 = _h(np.maximum(oracle.conv2d_nhwc(x, w, b, 1, 1), 0))  # the fused kernel rounds conv2's output to f16 too
+    want = np.maximum(h2 @ w3 + b3, 0) * 2.0
+    assert rel_err(got, want) < 2e-3

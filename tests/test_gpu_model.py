@@ -156,7 +156,7 @@ def test_reference_c_api_compute(small):
     # same resized pixels is not possible bit-exactly (stb resize), so check shape/finite/range
     wide = synth.images(1, 640, 480, seed=10)[0]
     res = small.compute(wide)
-    assert res.shape == (480, 640) and res.min() == 0 and res.max() == 255
+    assert res.shape == (480, 640) and res.min() == 0 and res.max() >= 254  # uint8(0.99999994*255) truncates, as in the reference
 
 
 def test_non_square_extent_vs_oracle(small):

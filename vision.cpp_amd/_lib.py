@@ -42,11 +42,11 @@ class GemmArgs(ctypes.Structure):  # == vx_gemm_args
         ("q", c_void_p), ("k", c_void_p), ("vt", c_void_p), ("qkv_T", c_int), ("qkv_Tp", c_int), ("qkv_H", c_int),
         ("q_scale", c_float),
         ("ps_s", c_int), ("ps_Cout", c_int), ("ps_H", c_int), ("ps_W", c_int),
-        ("res1", c_void_p), ("res2", c_void_p), ("n_valid", c_int), ("stages", c_int), ("debug_stamps", c_void_p),
+        ("res1", c_void_p), ("res2", c_void_p), ("n_valid", c_int), ("stages", c_int), ("head_bias", c_float), ("head_scale", c_float), ("debug_stamps", c_void_p),
     ]
 
 
-EPI_F16, EPI_F16_GELU, EPI_F16_RELU, EPI_RESID_F32, EPI_TOKENS, EPI_QKV, EPI_PIXSHUF, EPI_F16_ADD = range(8)
+EPI_F16, EPI_F16_GELU, EPI_F16_RELU, EPI_RESID_F32, EPI_TOKENS, EPI_QKV, EPI_PIXSHUF, EPI_F16_ADD, EPI_HEAD_OUT = range(9)
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvisioncpp.so"
 

@@ -756,10 +756,26 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     c.capture("head_conv1", c.buf("h1"), {B, fh, fw, HC}, true);
     c.mark("bilinear", 1, 0, (double)B * ((double)fh * fw + (double)H * W) * HC * 2);
     VX(vx_bilinear_ac_f16(c.buf("h1"), c.buf("hup"), B, fh, fw, HC, H, W, stream));
-    c.conv(Wt.head2, c.buf("hup"), B, H, W, HC, 3, 1, 1, c.buf("h2"), HC, VX_EPI_F16_RELU, false, false, nullptr, nullptr, "head_conv2");
     float* depth = raw_out_dev ? static_cast<float*>(raw_out_dev) : static_cast<float*>(c.buf("depth"));
-    c.mark("head_out", 1, 2.0 * B * H * W * HC, (double)B * H * W * (HC * 2 + 4));
-    VX(vx_head_out_f32(c.buf("h2"), c.fptr(Wt.head3_w), Wt.head3_b, P.max_depth, depth, (int64_t)B * H * W, HC, stream));
+    if (Wt.head2.N == 32) {
+        // conv2 (3x3 -> 32) + ReLU + conv3 (1x1 -> 1) + ReLU [* max_depth] in one kernel: the 32-channel
+        // full-resolution tensor never reaches HBM
+        vx_gemm_args a = c.base(Wt.head2, (long)B * H * W);
+        a.A = c.buf("hup");
+        a.conv_kh = a.conv_kw = 3; a.conv_stride = 1; a.conv_pad = 1;
+        a.conv_H = H; a.conv_W = W; a.conv_Cin = HC; a.conv_OH = H; a.conv_OW = W;
+        a.epi = VX_EPI_HEAD_OUT;
+        a.out = depth;
+        a.lambda = c.fptr(Wt.head3_w);
+        a.head_bias = Wt.head3_b;
+        a.head_scale = P.max_depth;
+        c.mark("head_conv2+3", 1, 2.0 * B * H * W * 32 * (Wt.head2.k_real + 1), (double)B * H * W * (HC * 2 + 4));
+        c.gemm(a);
+    } else {
+        c.conv(Wt.head2, c.buf("hup"), B, H, W, HC, 3, 1, 1, c.buf("h2"), Wt.head2.N, VX_EPI_F16_RELU, false, false, nullptr, nullptr, "head_conv2");
+        c.mark("head_out", 1, 2.0 * B * H * W * Wt.head2.N, (double)B * H * W * (Wt.head2.N * 2 + 4));
+        VX(vx_head_out_f32(c.buf("h2"), c.fptr(Wt.head3_w), Wt.head3_b, P.max_depth, depth, (int64_t)B * H * W, Wt.head2.N, stream));
+    }
     c.capture("depth", depth, {B, H, W, 1}, false);
 
     // ---- depthany_process_output (depth-anything.cpp:142-149): per-image min-max to [0,1]

@@ -43,7 +43,7 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 
 constexpr bool epi_is_f16_tile(int epi) {
     return epi == VX_EPI_F16 || epi == VX_EPI_F16_GELU || epi == VX_EPI_F16_RELU || epi == VX_EPI_F16_ADD ||
-           epi == VX_EPI_QKV || epi == VX_EPI_PIXSHUF;
+           epi == VX_EPI_QKV || epi == VX_EPI_PIXSHUF || epi == VX_EPI_HEAD_OUT;
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool CONV>
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
     float* const s_lambda = s_bias + BN;
     if (tid < BN) {
         s_bias[tid] = p.bias ? p.bias[n0 + tid] : 0.0f;
-        if constexpr (EPI == VX_EPI_RESID_F32) s_lambda[tid] = p.lambda[n0 + tid];
+        if constexpr (EPI == VX_EPI_RESID_F32 || EPI == VX_EPI_HEAD_OUT) s_lambda[tid] = p.lambda[n0 + tid];
     }
 
     const f16* __restrict__ Ag = reinterpret_cast<const f16*>(p.A);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if constexpr (EPI == VX_EPI_F16_GELU) v[j] = gelu_tanh(v[j]);
-                        if constexpr (EPI == VX_EPI_F16_RELU) v[j] = fmaxf(v[j], 0.0f);
+                        if constexpr (EPI == VX_EPI_F16_RELU || EPI == VX_EPI_HEAD_OUT) v[j] = fmaxf(v[j], 0.0f);
                         if constexpr (EPI == VX_EPI_F16_ADD) { if (p.relu) v[j] = fmaxf(v[j], 0.0f); }
                         if constexpr (EPI == VX_EPI_QKV) v[j] *= out_scale;
                     }
@@ -353,7 +353,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
             const int m = m0 + (ml / WPP) * WM + ps * WPP + (ml % WPP), n = n0 + j * 8;
             if (m >= p.M || n >= n_valid) continue;
             f16x8 v = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ (ml & (NCH16 - 1))) * 16);
-            if constexpr (EPI == VX_EPI_F16 || EPI == VX_EPI_F16_GELU || EPI == VX_EPI_F16_RELU) {
+            if constexpr (EPI == VX_EPI_HEAD_OUT) {
+                // 1x1 conv to one channel: the NCH16 (= 4) consecutive lanes of a row each dot 8 channels
+                float part = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) part += (float)v[q] * s_lambda[j * 8 + q];
+                part += __shfl_xor(part, 1, 64);
+                part += __shfl_xor(part, 2, 64);
+                if (j == 0) reinterpret_cast<float*>(p.out)[m] = fmaxf(part + p.head_bias, 0.0f) * p.head_scale;
+            } else if constexpr (EPI == VX_EPI_F16 || EPI == VX_EPI_F16_GELU || EPI == VX_EPI_F16_RELU) {
                 *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + (long)m * p.ldo + n) = v;
             } else if constexpr (EPI == VX_EPI_F16_ADD) {
                 const long o = (long)m * p.ldo + n;
@@ -444,6 +452,7 @@ int dispatch_epi(const vx_gemm_args& a, hipStream_t s) {
         case VX_EPI_F16_GELU: return dispatch_tile<VX_EPI_F16_GELU, CONV>(a, s);
         case VX_EPI_F16_RELU: return dispatch_tile<VX_EPI_F16_RELU, CONV>(a, s);
         case VX_EPI_F16_ADD: return dispatch_tile<VX_EPI_F16_ADD, CONV>(a, s);
+        case VX_EPI_HEAD_OUT: return launch<128, 32, 32, 32, 1, VX_EPI_HEAD_OUT, CONV>(a, s); // N == 32 only
         default: break;
     }
     if constexpr (!CONV) {
@@ -470,10 +479,11 @@ extern "C" int vx_gemm_f16(const vx_gemm_args* args, void* stream) {
     const int nv = a.n_valid > 0 ? a.n_valid : a.N;
     if (epi_is_f16_tile(a.epi)) {
         VX_REQUIRE(nv % 8 == 0, "vx_gemm_f16: n_valid=%d must be a multiple of 8 for f16 outputs", nv);
-        VX_REQUIRE(a.epi == VX_EPI_QKV || a.ldo % 8 == 0, "vx_gemm_f16: ldo=%ld must be a multiple of 8", (long)a.ldo);
+        VX_REQUIRE(a.epi == VX_EPI_QKV || a.epi == VX_EPI_HEAD_OUT || a.ldo % 8 == 0, "vx_gemm_f16: ldo=%ld must be a multiple of 8", (long)a.ldo);
     }
     if (a.epi == VX_EPI_PIXSHUF) VX_REQUIRE(a.ps_Cout % 8 == 0, "vx_gemm_f16: pixel-shuffle Cout=%d must be a multiple of 8", a.ps_Cout);
     if (a.epi == VX_EPI_QKV) VX_REQUIRE(a.N == 3 * a.qkv_H * 64, "vx_gemm_f16: QKV epilogue needs N == 3*H*64");
+    if (a.epi == VX_EPI_HEAD_OUT) VX_REQUIRE(a.N == 32 && a.lambda, "vx_gemm_f16: head epilogue needs N == 32 and conv3 weights");
     if (a.conv_kh > 0) {
         VX_REQUIRE(a.conv_Cin % 8 == 0, "vx_gemm_f16: conv Cin=%d must be a multiple of 8", a.conv_Cin);
         VX_REQUIRE(a.K >= a.conv_kh * a.conv_kw * a.conv_Cin, "vx_gemm_f16: conv K too small");
