@@ -106,6 +106,12 @@ typedef struct {
 
 VX_API int vx_gemm_f16(const vx_gemm_args* args, void* stream);
 
+/* 3x3 / stride 1 / pad 1 NHWC convolution with the input halo staged once in LDS (Cin, Cout in {32, 64};
+ * epilogues F16, F16_RELU, F16_ADD, HEAD_OUT). Same argument block as the implicit-GEMM form (conv_* fields,
+ * W = [Cout][Kp] with k = (ky,kx,c)); used for the DPT fusion / head convs at >= 96 px (depth-anything.cpp:15-23, 81-94). */
+VX_API int vx_conv3x3_supported(const vx_gemm_args* args);
+VX_API int vx_conv3x3_f16(const vx_gemm_args* args, void* stream);
+
 /* ---- fused multi-head attention, head_dim 64 (nn.cpp:210-244, dino.cpp:59-74) ------------
  * q,k,v: f16 [B,H,T,64] (q pre-scaled by 1/sqrt(64)); out: f16 [B*T, H*64].
  * softmax in f32, S never leaves registers; V is transposed on the fly by ds_read_b64_tr_b16. */

@@ -73,11 +73,14 @@ def gemm(a_dev, w: np.ndarray, bias, M, epi, *, lda=None, out=None, ldo=None, ke
     g.out = out.ptr if out is not None else None
     g.ldo = ldo if ldo is not None else w.shape[0]
     for k, v in kw.items():
+        if k.startswith("_"):
+            continue
         if isinstance(v, DeviceBuffer):
             keep.append(v)
             v = v.ptr
         setattr(g, k, v)
-    L.vx_check(api().vx_gemm_f16(C.byref(g), None))
+    fn = api().vx_conv3x3_f16 if kw.get("_halo") else api().vx_gemm_f16
+    L.vx_check(fn(C.byref(g), None))
     sync()
     return keep
 

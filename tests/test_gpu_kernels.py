@@ -320,3 +320,42 @@ def test_conv3x3_fused_head_output():
     h2 = _h(np.maximum(oracle.conv2d_nhwc(x, w, b, 1, 1), 0))  # the fused kernel rounds conv2's output to f16 too
     want = np.maximum(h2 @ w3 + b3, 0) * 2.0
     assert rel_err(got, want) < 2e-3
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (32, 32), (32, 64)])
+@pytest.mark.parametrize("hw", [(8, 32), (37, 50), (21, 100)])
+@pytest.mark.parametrize("mode", ["plain", "rcu1", "rcu2", "head"])
+def test_conv3x3_halo_kernel(cin, cout, hw, mode):
+    """Halo-in-LDS 3x3 conv (kernels_conv.hip) vs the oracle, incl. ragged tiles at the right/bottom edges."""
+    if mode == "head" and cout != 32:
+        pytest.skip("fused head output is a 32-channel epilogue")
+    if mode in ("rcu1", "rcu2") and cin != cout:
+        pytest.skip("residual forms are same-shape convs")
+    rng = np.random.default_rng(cin * 7 + cout + hw[0])
+    B, (Hh, Ww) = 2, hw
+    x = _h(_rand(rng, B, Hh, Ww, cin))
+    w, b = _h(_rand(rng, cout, 3, 3, cin, scale=(9 * cin) ** -0.5)), _rand(rng, cout, scale=0.1)
+    kw = dict(conv_kh=3, conv_kw=3, conv_stride=1, conv_pad=1, conv_H=Hh, conv_W=Ww, conv_Cin=cin, conv_OH=Hh, conv_OW=Ww, _halo=True)
+    wp = pad_weight(w.reshape(cout, -1))
+    xd = dev(x.astype(np.float16))
+    M = B * Hh * Ww
+    if mode == "head":
+        w3, b3 = np.abs(_rand(rng, 32, scale=0.3)), 0.05
+        out = empty(M * 4)
+        gemm(xd, wp, b, M, L.EPI_HEAD_OUT, out=out, ldo=1, lambda_=dev(w3), head_bias=b3, head_scale=1.5, **kw)
+        h2 = _h(np.maximum(oracle.conv2d_nhwc(x, w, b, 1, 1), 0))
+        want = np.maximum(h2 @ w3 + b3, 0) * 1.5
+        assert rel_err(out.to_numpy(np.float32, (B, Hh, Ww)), want) < 2e-3
+        return
+    out = empty(M * cout * 2)
+    if mode == "plain":
+        gemm(xd, wp, b, M, L.EPI_F16, out=out, ldo=cout, **kw)
+        want = oracle.conv2d_nhwc(x, w, b, 1, 1)
+    elif mode == "rcu1":
+        gemm(xd, wp, b, M, L.EPI_F16_RELU, out=out, ldo=cout, a_relu=1, **kw)
+        want = np.maximum(oracle.conv2d_nhwc(np.maximum(x, 0), w, b, 1, 1), 0)
+    else:
+        r1, r2 = _h(_rand(rng, B, Hh, Ww, cout)), _h(_rand(rng, B, Hh, Ww, cout))
+        gemm(xd, wp, b, M, L.EPI_F16_ADD, out=out, ldo=cout, res1=dev(r1.astype(np.float16)), res2=dev(r2.astype(np.float16)), **kw)
+        want = oracle.conv2d_nhwc(x, w, b, 1, 1) + r1 + r2
+    assert rel_err(out.to_numpy(np.float16, (B, Hh, Ww, cout)).astype(np.float32), want) < F16_TOL

@@ -65,7 +65,8 @@ KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
     "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
     "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_graph_begin_capture",
-    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_attention_f16",
+    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_conv3x3_supported", "vx_conv3x3_f16",
+    "vx_attention_f16",
     "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
 ]
@@ -143,6 +144,8 @@ def init() -> ctypes.CDLL:
     lib.vx_graph_launch.argtypes = [c_void_p, c_void_p]
     lib.vx_graph_destroy.argtypes = [c_void_p]
     lib.vx_gemm_f16.argtypes = [POINTER(GemmArgs), c_void_p]
+    lib.vx_conv3x3_supported.argtypes = [POINTER(GemmArgs)]
+    lib.vx_conv3x3_f16.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.vx_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.vx_layernorm_f32_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
     lib.vx_preprocess_patches.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]

@@ -542,7 +542,12 @@ struct exec_ctx {
         a.n_valid = g.n_real;
         return a;
     }
-    void gemm(vx_gemm_args const& a) { VX(vx_gemm_f16(&a, stream)); }
+    void gemm(vx_gemm_args const& a) {
+        // 3x3 convs with few channels at high resolution: halo-in-LDS kernel (tile 8x32, so only where the
+        // map is wide enough for the edge tiles not to dominate); everything else: (implicit) GEMM
+        if (a.conv_kh == 3 && a.conv_W >= 96 && vx_conv3x3_supported(&a)) VX(vx_conv3x3_f16(&a, stream));
+        else VX(vx_gemm_f16(&a, stream));
+    }
 
     // NHWC 3x3 (or kxk) convolution as implicit GEMM
     void conv(packed_gemm const& g, const void* x, int B, int H, int W, int Cin, int k, int stride, int pad, void* y, int ldo,
