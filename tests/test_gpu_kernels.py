@@ -289,7 +289,7 @@ def test_constant_image_normalizes_to_zero():
     assert not out.to_numpy(np.float32, (1000,)).any()
 
 
-@pytest.mark.parametrize("stages", [2, 4, 8])
+@pytest.mark.parametrize("stages", [1, 2, 4, 8, 16, 32, 64])
 def test_gemm_tuning_variants(stages):
     """The LDS-ring depth / block-tile knob (vx_gemm_args.stages) must not change results."""
     rng = np.random.default_rng(stages)

@@ -35,7 +35,7 @@ def timeit(fn, iters=5 if '--quick' in sys.argv else 20, warm=1 if '--quick' in 
     return ms.value / iters
 
 
-def gemm_case(name, M, N, K, epi, stages):
+def gemm_case(name, M, N, K, epi, stages, n_valid=0):
     rng = np.random.default_rng(0)
     a = DeviceBuffer.from_numpy(rng.standard_normal((M, K)).astype(np.float16))
     w = DeviceBuffer.from_numpy((rng.standard_normal((N, K)) * K ** -0.5).astype(np.float16))
@@ -48,6 +48,7 @@ def gemm_case(name, M, N, K, epi, stages):
     g.epi, g.out, g.ldo, g.lambda_ = epi, out.ptr, N, lam.ptr
     g.q, g.k, g.vt, g.qkv_T, g.qkv_H, g.q_scale = q.ptr, k.ptr, v.ptr, 1370, 6, 0.125
     g.stages = stages
+    g.n_valid = n_valid
     ms = timeit(lambda: L.vx_check(api.vx_gemm_f16(C.byref(g), stream)))
     print(f"{name:10s} M={M} N={N} K={K} stages={stages}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
     return ms
@@ -103,6 +104,13 @@ if __name__ == "__main__":
         gemm_stamps("fc2_resid", M, 384, 1536, L.EPI_RESID_F32)
         gemm_stamps("out_resid", M, 384, 384, L.EPI_RESID_F32)
         sys.exit(0)
+    if "--writes" in sys.argv:  # is the f16 epilogue store-bound? same math, 1/16 of the stores
+        for _ in range(2):
+            gemm_case("fc1 full", M, 1536, 384, L.EPI_F16_GELU, 0)
+            gemm_case("fc1 nv=8", M, 1536, 384, L.EPI_F16_GELU, 0, n_valid=8)
+            gemm_case("f16 full", M, 1536, 384, L.EPI_F16, 0)
+            gemm_case("f16 nv=8", M, 1536, 384, L.EPI_F16, 0, n_valid=8)
+        sys.exit(0)
     if "--quick" in sys.argv:  # one pass, default variants (for rocprofv3 counter runs)
         gemm_case("qkv", M, 1152, 384, L.EPI_QKV, 0)
         gemm_case("fc1_gelu", M, 1536, 384, L.EPI_F16_GELU, 0)
@@ -111,7 +119,7 @@ if __name__ == "__main__":
         attn_case(32, 6, 1370)
         sys.exit(0)
     for rnd in range(2):
-        for st in (1, 16):
+        for st in (1, 64):
             gemm_case("qkv", M, 1152, 384, L.EPI_QKV, st)
             gemm_case("fc1_gelu", M, 1536, 384, L.EPI_F16_GELU, st)
             gemm_case("fc2_resid", M, 384, 1536, L.EPI_RESID_F32, st)

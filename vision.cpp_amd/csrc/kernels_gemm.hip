@@ -310,9 +310,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
         if constexpr (EPI == VX_EPI_QKV) out_scale = n0 < p.qkv_H * 64 ? p.q_scale : 1.0f;
         // The staging buffer holds 128 rows; taller block tiles are written in BM/128 passes, pass ps
         // taking MI/PASSES of every wave's row blocks (staged row sl <-> tile row wr*WM + ps*WPP + sl%WPP).
-        constexpr int PASSES = BM / 128;
-        constexpr int MPP = MI / PASSES;            // row blocks per wave per pass
-        constexpr int WPP = WM / PASSES;            // rows per wave per pass
+        constexpr int MPP = (MI % 2 == 0 && BM / WM <= 2) ? 2 : 1; // row blocks per wave per pass (staging <= 128 rows)
+        constexpr int PASSES = MI / MPP;
+        constexpr int WPP = 32 * MPP;               // rows per wave per pass
+        constexpr int STAGE_ROWS = (BM / WM) * WPP;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
         if (ps > 0) __syncthreads();                // previous pass fully read out
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
         __syncthreads();
         if (ps == 0) stamp(4);
         // Phase 2: coalesced 16-byte stores (consecutive lanes = consecutive chunks of one row)
-        constexpr int CHUNKS = 128 * NCH16;
+        constexpr int CHUNKS = STAGE_ROWS * NCH16;
+        static_assert(CHUNKS % THREADS == 0, "staging read-out");
 #pragma unroll
         for (int it = 0; it < CHUNKS / THREADS; ++it) {
             const int id = tid + it * THREADS;
@@ -436,6 +438,18 @@ int dispatch_tile(const vx_gemm_args& a, hipStream_t s) {
             if (a.stages == 4) return launch<256, 128, 128, 64, 1, EPI, CONV>(a, s); // 256x128 block tile, 4 waves
             if (a.stages == 8) return launch<256, 128, 64, 64, 1, EPI, CONV>(a, s);  // 256x128 block tile, 8 waves
             if (a.stages == 16) return launch<128, 64, 64, 32, 1, EPI, CONV>(a, s);  // 128x64 block tile
+            if (a.stages == 32) return launch<128, 128, 64, 32, 1, EPI, CONV>(a, s); // 128x128, 8 waves of 64x32
+            if (a.stages == 64) return launch<192, 128, 96, 64, 1, EPI, CONV>(a, s); // 192x128 block tile
+            if (a.stages == 0) {
+                // Wave quantisation: a block lives ~as long as its tile is tall, and the grid runs in
+                // ceil(tiles / resident slots) rounds (256 CUs x 4 blocks of 128x128, x 3 blocks of 192x128).
+                // Pick the tile height with the cheaper rounds x height product; e.g. M = 43840, N = 384 is
+                // 1029 tiles of 128 rows (2 rounds, the second one 5 blocks) but 687 tiles of 192 rows (1 round).
+                const long n_t = a.N / 128;
+                const long t128 = ((a.M + 127) / 128) * n_t, t192 = ((a.M + 191) / 192) * n_t;
+                const long c128 = ((t128 + 1023) / 1024) * 128, c192 = ((t192 + 767) / 768) * 192;
+                if (c192 < c128) return launch<192, 128, 96, 64, 1, EPI, CONV>(a, s);
+            }
             return launch<128, 128, 64, 64, 1, EPI, CONV>(a, s);
         } else {
             return launch<128, 128, 64, 64, 1, EPI, CONV>(a, s);
