@@ -61,35 +61,34 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
 // ---- pre-processing + patch im2col (reference depth-anything.cpp:130-140, image.cpp:215-226,
 // image-impl.h:23-27, nn.cpp:166-180). One thread writes 8 consecutive k of one patch row.
 __global__ __launch_bounds__(256) void preprocess_patches_kernel(const uint8_t* __restrict__ rgb, f16* __restrict__ patches,
-                                                                  int B, int H, int W, int ps, int Kp, float m0, float m1,
+                                                                  int H, int W, int ps, int Kp, float m0, float m1,
                                                                   float m2, float s0, float s1, float s2) {
+    // grid: (ceil(P*chunks / 256), B); thread = 8 consecutive k of one patch row, 32-bit index math
     const int chunks = Kp >> 3;
-    const long total = (long)B * (H / ps) * (W / ps) * chunks;
     const int pw = W / ps, ph = H / ps;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= pw * ph * chunks) return;
+    const int prow = t / chunks, ch = t - prow * chunks;
+    const int py = prow / pw, px = prow - py * pw;
+    const int b = blockIdx.y;
     const int kreal = ps * ps * 3;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        int ch = (int)(idx % chunks);
-        long prow = idx / chunks;
-        int px = (int)(prow % pw);
-        int py = (int)((prow / pw) % ph);
-        int b = (int)(prow / ((long)pw * ph));
-        f16x8 out;
+    const uint8_t* img = rgb + (long)b * H * W * 3;
+    f16x8 out;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int k = ch * 8 + j;
-            float v = 0.0f;
-            if (k < kreal) {
-                int c = k % 3, kk = k / 3;
-                int kx = kk % ps, ky = kk / ps;
-                float u = (float)rgb[(((long)b * H + py * ps + ky) * W + px * ps + kx) * 3 + c];
-                float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
-                float inv = c == 0 ? s0 : (c == 1 ? s1 : s2);
-                v = (u / 255.0f - mean) * inv;
-            }
-            out[j] = (f16)v;
+    for (int j = 0; j < 8; ++j) {
+        const int k = ch * 8 + j;
+        float v = 0.0f;
+        if (k < kreal) {
+            const int kk = k / 3, c = k - kk * 3;
+            const int ky = kk / ps, kx = kk - ky * ps;
+            const float u = (float)img[((py * ps + ky) * W + px * ps + kx) * 3 + c];
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+            const float inv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            v = (u / 255.0f - mean) * inv;
         }
-        *reinterpret_cast<f16x8*>(patches + prow * Kp + ch * 8) = out;
+        out[j] = (f16)v;
     }
+    *reinterpret_cast<f16x8*>(patches + ((long)b * pw * ph + prow) * Kp + ch * 8) = out;
 }
 
 __global__ __launch_bounds__(256) void preprocess_f32_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ out, long n,
@@ -110,34 +109,32 @@ __global__ void write_cls_kernel(float* __restrict__ x, const float* __restrict_
 // ---- bilinear, align_corners (ggml_interpolate BILINEAR|ALIGN_CORNERS; reference ml.cpp:782-788).
 // NHWC f16, one thread = 8 channels of one output pixel; source coords as ggml computes them:
 // sf = (out-1)/(in-1), src = i / sf.
-__global__ __launch_bounds__(256) void bilinear_ac_kernel(const f16* __restrict__ x, f16* __restrict__ y, int B, int H, int W,
-                                                           int C, int OH, int OW, float sfy, float sfx) {
-    const int c8n = C >> 3;
-    const long total = (long)B * OH * OW * c8n;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        int c8 = (int)(idx % c8n);
-        long pix = idx / c8n;
-        int ox = (int)(pix % OW);
-        int oy = (int)((pix / OW) % OH);
-        int b = (int)(pix / ((long)OW * OH));
-        float sy = (float)oy / sfy, sx = (float)ox / sfx;
-        int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
-        int y1 = y0 + 1, x1 = x0 + 1;
-        y0 = max(0, min(y0, H - 1)); y1 = max(0, min(y1, H - 1));
-        x0 = max(0, min(x0, W - 1)); x1 = max(0, min(x1, W - 1));
-        float dy = fminf(fmaxf(sy - (float)y0, 0.0f), 1.0f), dx = fminf(fmaxf(sx - (float)x0, 0.0f), 1.0f);
-        const f16* base = x + (long)b * H * W * C + c8 * 8;
-        f16x8 a = *reinterpret_cast<const f16x8*>(base + ((long)y0 * W + x0) * C);
-        f16x8 bb = *reinterpret_cast<const f16x8*>(base + ((long)y0 * W + x1) * C);
-        f16x8 c = *reinterpret_cast<const f16x8*>(base + ((long)y1 * W + x0) * C);
-        f16x8 d = *reinterpret_cast<const f16x8*>(base + ((long)y1 * W + x1) * C);
-        float w00 = (1 - dx) * (1 - dy), w01 = dx * (1 - dy), w10 = (1 - dx) * dy, w11 = dx * dy;
-        f16x8 o;
+__global__ __launch_bounds__(256) void bilinear_ac_kernel(const f16* __restrict__ x, f16* __restrict__ y, int H, int W,
+                                                           int c8n, int OH, int OW, float sfy, float sfx) {
+    // grid: (ceil(OW*c8n / 256), OH, B). One thread = 8 channels of one output pixel; the row terms are
+    // block-uniform, everything else is 32-bit arithmetic (c8n = C/8 channel chunks per pixel).
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= OW * c8n) return;
+    const int ox = t / c8n, c8 = t - ox * c8n;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const int C = c8n * 8;
+    const float sy = (float)oy / sfy, sx = (float)ox / sfx;
+    int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+    int y1 = y0 + 1, x1 = x0 + 1;
+    y0 = max(0, min(y0, H - 1)); y1 = max(0, min(y1, H - 1));
+    x0 = max(0, min(x0, W - 1)); x1 = max(0, min(x1, W - 1));
+    const float dy = fminf(fmaxf(sy - (float)y0, 0.0f), 1.0f), dx = fminf(fmaxf(sx - (float)x0, 0.0f), 1.0f);
+    const f16* base = x + (long)b * H * W * C + c8 * 8;
+    const f16x8 a = *reinterpret_cast<const f16x8*>(base + (y0 * W + x0) * C);
+    const f16x8 bb = *reinterpret_cast<const f16x8*>(base + (y0 * W + x1) * C);
+    const f16x8 c = *reinterpret_cast<const f16x8*>(base + (y1 * W + x0) * C);
+    const f16x8 d = *reinterpret_cast<const f16x8*>(base + (y1 * W + x1) * C);
+    const float w00 = (1 - dx) * (1 - dy), w01 = dx * (1 - dy), w10 = (1 - dx) * dy, w11 = dx * dy;
+    f16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            o[j] = (f16)((float)a[j] * w00 + (float)bb[j] * w01 + (float)c[j] * w10 + (float)d[j] * w11);
-        *reinterpret_cast<f16x8*>(y + pix * C + c8 * 8) = o;
-    }
+    for (int j = 0; j < 8; ++j)
+        o[j] = (f16)((float)a[j] * w00 + (float)bb[j] * w01 + (float)c[j] * w10 + (float)d[j] * w11);
+    *reinterpret_cast<f16x8*>(y + (((long)b * OH + oy) * OW + ox) * C + c8 * 8) = o;
 }
 
 // ---- head output: 1x1 conv C -> 1, ReLU, * max_depth (reference depth-anything.cpp:89-94)
@@ -176,7 +173,14 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ d
     const int b = blockIdx.y;
     const float* d = depth + (long)b * n;
     float mn = INFINITY, mx = -INFINITY;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long n4 = ((reinterpret_cast<uintptr_t>(d) & 15) == 0) ? n / 4 : 0; // 16-byte path when the image is aligned
+    const float4* d4 = reinterpret_cast<const float4*>(d);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = d4[i];
+        mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
+        mx = fmaxf(fmaxf(mx, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+    }
+    for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float v = d[i];
         mn = fminf(mn, v); mx = fmaxf(mx, v);
     }
@@ -238,9 +242,9 @@ int vx_preprocess_patches(const uint8_t* rgb, void* patches, int B, int H, int W
                           const float inv_std[3], void* stream) {
     VX_REQUIRE(H % ps == 0 && W % ps == 0, "vx_preprocess_patches: %dx%d not a multiple of patch size %d", W, H, ps);
     VX_REQUIRE(Kp % 8 == 0 && Kp >= ps * ps * 3, "vx_preprocess_patches: bad Kp=%d", Kp);
-    long total = (long)B * (H / ps) * (W / ps) * (Kp / 8);
-    hipLaunchKernelGGL(preprocess_patches_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), rgb,
-                       reinterpret_cast<f16*>(patches), B, H, W, ps, Kp, mean[0], mean[1], mean[2], inv_std[0], inv_std[1],
+    const int per_image = (H / ps) * (W / ps) * (Kp / 8);
+    hipLaunchKernelGGL(preprocess_patches_kernel, dim3((per_image + 255) / 256, B), dim3(256), 0, as_stream(stream), rgb,
+                       reinterpret_cast<f16*>(patches), H, W, ps, Kp, mean[0], mean[1], mean[2], inv_std[0], inv_std[1],
                        inv_std[2]);
     VX_LAUNCH_CHECK();
     return 1;
@@ -265,9 +269,11 @@ int vx_bilinear_ac_f16(const void* x, void* y, int B, int H, int W, int C, int O
     VX_REQUIRE(C % 8 == 0, "vx_bilinear_ac_f16: C=%d must be a multiple of 8", C);
     float sfy = (OH > 1 && H > 1) ? (float)(OH - 1) / (float)(H - 1) : (float)OH / (float)H;
     float sfx = (OW > 1 && W > 1) ? (float)(OW - 1) / (float)(W - 1) : (float)OW / (float)W;
-    long total = (long)B * OH * OW * (C / 8);
-    hipLaunchKernelGGL(bilinear_ac_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const f16*>(x), reinterpret_cast<f16*>(y), B, H, W, C, OH, OW, sfy, sfx);
+    VX_REQUIRE((long)H * W * C < 0x7fffffffL, "vx_bilinear_ac_f16: image too large for 32-bit offsets");
+    const int c8n = C / 8;
+    dim3 grid((OW * c8n + 255) / 256, OH, B);
+    hipLaunchKernelGGL(bilinear_ac_kernel, grid, dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(x),
+                       reinterpret_cast<f16*>(y), H, W, c8n, OH, OW, sfy, sfx);
     VX_LAUNCH_CHECK();
     return 1;
 }
