@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=32, help="bounded CPU-baseline sample (about 10 s at 16 threads)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (one GPU's share of the host)")
     ap.add_argument("--profile-groups", action="store_true", help="print the per-kernel-group table to stderr")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="force this HIP device for every rank (gloo rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -61,13 +63,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank if args.device is None else args.device
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     def barrier():
         if dist is not None:
@@ -79,11 +85,11 @@ def main():
     api = L.get_lib()
 
     # ---- load: rank 0 reads the GGUF and uploads; other ranks allocate and receive the arena over RCCL
-    tmp = Path(tempfile.gettempdir()) / "visp_bench_da_v2_small_f16.gguf"
+    tmp = Path(tempfile.gettempdir()) / f"visp_bench_da_v2_small_f16_{os.environ.get('MASTER_PORT', '0')}.gguf"
     if rank == 0:
         synth.write_gguf(tmp, cfg, seed=0)
     barrier()
-    dev = vision.Device.init(index=local_rank)
+    dev = vision.Device.init(index=device_index)
     model = vision.Model.load(tmp, dev, vision.Arch.depth_anything, no_upload=(rank != 0))
     if world > 1:
         ptr, nbytes = model.weights_arena()

@@ -21,3 +21,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The CPU oracle's OpenMP loops are fastest at <= 16 threads (tools/oracle_scaling.py: 0.33 s/image at 16,
+    2.9 s at 128 on the 256-thread GPU host): never let it default to every hardware thread."""
+    import os
+
+    from oracle import oracle
+
+    oracle.set_num_threads(min(16, os.cpu_count() or 1))
+    yield

@@ -189,3 +189,21 @@ def test_errors(small, device, tmp_path):
         L.check(api.visp_model_load(b"/x.gguf", device._handle, 4, C.byref(h)))
     with pytest.raises(L.Error, match="Failed to load GGUF model"):
         vision.Model.load(tmp_path / "missing.gguf", device, vision.Arch.depth_anything)
+
+
+def test_weight_arena_replication(device, tmp_path):
+    """The N>1 load path without the collective itself: a header-only model (VISP_LOAD_NO_UPLOAD, what ranks != 0
+    do) receives the packed arena of a fully loaded model by a device copy (RCCL broadcast in bench.py) and must
+    then produce bit-identical results."""
+    path = synth.write_gguf(tmp_path / "mini.gguf", synth.MINI, seed=4)
+    full = vision.Model.load(path, device)
+    empty = vision.Model.load(path, device, no_upload=True)
+    imgs = synth.images(2, 112, 112, seed=3)
+    with pytest.raises(L.Error, match="not uploaded"):
+        empty.compute_batch(imgs)
+    (src, n), (dst, n2) = full.weights_arena(), empty.weights_arena()
+    assert n == n2 and n > 0
+    L.vx_check(L.get_lib().vx_memcpy_d2d(dst, src, n, None))
+    L.vx_check(L.get_lib().vx_stream_sync(None))
+    empty.weights_ready()
+    np.testing.assert_array_equal(empty.compute_batch(imgs), full.compute_batch(imgs))

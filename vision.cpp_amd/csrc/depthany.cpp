@@ -405,6 +405,8 @@ void depthany_reserve(depthany_model& m, int B, int W, int H) {
     depthany_weights const& Wt = m.weights;
     const int ps = P.dino.patch_size;
     if (B <= 0 || W <= 0 || H <= 0) throw except("depthany: invalid batch/extent %d x %dx%d", B, W, H);
+    // the workspace caches the (possibly resized) position embeddings, so the weights must be in place first
+    if (!m.weights_uploaded) throw except("depthany: weights were not uploaded (VISP_LOAD_NO_UPLOAD): fill the arena and call visp_depthany_weights_ready first");
     if (W % ps || H % ps) throw except("depthany: extent %dx%d is not a multiple of the patch size %d", W, H, ps);
     if (m.ws.B == B && m.ws.W == W && m.ws.H == H && m.ws.arena.ptr) return;
 

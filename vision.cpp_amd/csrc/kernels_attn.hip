@@ -36,6 +36,14 @@ typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ int k_swz(int row, int chunk16) { return chunk16 ^ ((row >> 1) & 7); }
 __device__ __forceinline__ int v_swz(int row, int chunk16) { return chunk16 ^ (((row >> 1) & 1) << 2); }
 
+// value held by the same lane of the other 32-lane half (lanes l and l+32 own the same query column)
+__device__ __forceinline__ float other_half(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    // after the swap r[0] = {low: own low, high: low half's values}, r[1] = {low: high half's values, high: own high}
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
                                                          const f16* __restrict__ V, f16* __restrict__ O, int H, int T) {
     // LDS ring: 2 stages x (K tile, V tile)
@@ -44,8 +52,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y;                  // b * H + head
-    const int q0 = blockIdx.x * Q_PER_BLOCK + wave * Q_PER_WAVE;
+    // XCD-aware block order: blocks id and id+8 share an XCD (and its L2). Give every XCD a contiguous run of
+    // the (b*H+head major, q-block minor) sequence, so the q-blocks that sweep the same K/V (350 KB per head)
+    // hit it in ONE L2 instead of fetching it through all eight (measured: 5.5x the algorithmic fabric reads).
+    const int n_qblk = (T + Q_PER_BLOCK - 1) / Q_PER_BLOCK;
+    int logical;
+    {
+        const int total = gridDim.x, id = blockIdx.x;
+        const int per = total >> 3, rem = total & 7, xcd = id & 7;
+        logical = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (id >> 3);
+    }
+    const int bh = logical / n_qblk;            // b * H + head
+    const int q0 = (logical - bh * n_qblk) * Q_PER_BLOCK + wave * Q_PER_WAVE;
 
     const f16* Qb = Q + (long)bh * T * HD;
     const f16* Kb = K + (long)bh * T * HD;
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, s[kb][e]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = fmaxf(mloc, other_half(mloc)); // v_permlane32_swap: no LDS round trip on the softmax critical path
         const float m_new = fmaxf(m_run, mloc * LOG2E);
         // rescale the running output only when some query of this wave saw a larger maximum
         // (wave-uniform branch; after the first tiles the maxima rarely move)
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
     }
 
     // ---- finalize: O[q, head*64 + d] = o / l
-    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot = l_run + other_half(l_run);
     float inv = 1.0f / l_tot;
     const int q = q0 + r;
     if (q < T) {
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
 
 extern "C" int vx_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int T, void* stream) {
     VX_REQUIRE(B > 0 && H > 0 && T > 0, "vx_attention_f16: empty problem");
-    dim3 grid((T + Q_PER_BLOCK - 1) / Q_PER_BLOCK, B * H);
+    dim3 grid(((T + Q_PER_BLOCK - 1) / Q_PER_BLOCK) * B * H);
     hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
                        reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), H, T);
     VX_LAUNCH_CHECK();
