@@ -199,6 +199,14 @@ def main():
                 res["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM / 1e9,
                                    "unit": "GB/s", "frac": round(ach * 1e9 / PEAK_HBM, 4), "traffic": None,
                                    "avg_launch_ms": round(per_launch_ms, 4), "launches_per_step": dom["launches"]}
+            # HBM traffic per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+            # separately on tools/bench_kernels.py, same shapes; corrected per MI355X_MICROARCH.md): profiles/r01_pmc/
+            pmc = ROOT / "profiles" / "r01_pmc" / "traffic.json"
+            if pmc.exists():
+                k = json.loads(pmc.read_text())["kernels"].get(dom["name"])
+                if k:
+                    res["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+                    res["roofline"]["traffic_source"] = "profiles/r01_pmc/traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
             res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, imgs, o, args.cpu_images, args.cpu_threads)
