@@ -86,3 +86,34 @@ def test_image_view_abi_layout():
     assert C.sizeof(L.ImageView) == 24
     assert [f[0] for f in L.ImageView._fields_] == ["width", "height", "stride", "format", "data"]
     assert L.ImageView.data.offset == 16
+
+
+def test_converter_matches_reference_contract(tmp_path):
+    """tools/convert_depth_anything.py (scripts/convert.py:428-475 restated): safetensors in, GGUF out, identical
+    to the file synth.write_gguf produces for the same tensors, and readable by the C++ loader."""
+    from safetensors.numpy import save_file
+
+    from visioncpp_amd import convert
+
+    cfg = synth.Config(embed_dim=384, n_layers=12, n_heads=6, image_size=70, name="s70")  # real dims, 5x5 pos grid
+    sd = synth.state_dict(cfg, seed=2)
+    save_file(sd, str(tmp_path / "m.safetensors"))
+    loaded = convert.load_safetensors(tmp_path / "m.safetensors")  # file order (what the reference's converter iterates too)
+    assert set(loaded) == set(sd)
+    out = convert.convert_depth_anything(loaded, tmp_path / "m.gguf", image_size=70)
+    ref = synth.write_gguf(tmp_path / "ref.gguf", cfg, sd=loaded)
+    a, b = gguf.GGUFFile(out), gguf.GGUFFile(ref)
+    assert a.kv == b.kv and a.tensor_names == b.tensor_names
+    for k in a.tensor_names:
+        np.testing.assert_array_equal(a.tensors[k], b.tensors[k])
+    # on-disk rules: NHWC patch embed, untouched ConvTranspose, f32 cls/pos, conv2d index list
+    assert a.tensors["backbone.embeddings.patch_embeddings.projection.weight"].shape == (384, 14, 14, 3)
+    assert a.tensors["neck.reassemble_stage.layers.0.resize.weight"].shape == (48, 48, 4, 4)
+    assert a.tensors["backbone.embeddings.position_embeddings"].dtype == np.float32
+    assert a.tensors["head.conv1.weight"].dtype == np.float16
+    idx = a.kv["depthanything.conv2d_weights"]
+    assert a.tensor_names.index("head.conv1.weight") in idx and a.tensor_names.index("neck.convs.0.weight") in idx
+    assert a.tensor_names.index("neck.reassemble_stage.layers.0.projection.weight") not in idx
+    fam = C.c_int32(-1)
+    L.check(L.get_lib().visp_model_detect_family(str(out).encode(), C.byref(fam)))
+    assert fam.value == 2

@@ -207,3 +207,58 @@ def test_weight_arena_replication(device, tmp_path):
     L.vx_check(L.get_lib().vx_stream_sync(None))
     empty.weights_ready()
     np.testing.assert_array_equal(empty.compute_batch(imgs), full.compute_batch(imgs))
+
+
+def test_small_extents_and_ragged_tiles(small):
+    """Edge cases the reference's own API allows: extents far from 518 (position embeddings bicubic-resized to
+    8x5 and 1x1 grids, dino.cpp:10-30), maps narrower than one conv tile, a single patch (T = 2 tokens)."""
+    cfg = synth.SMALL
+    om, params = _oracle(cfg, 0)
+    for w, h in [(112, 70), (70, 112), (14, 14), (42, 14)]:
+        img = synth.images(2, w, h, seed=w + h)
+        out, raw = small.compute_batch(img, return_raw=True)
+        for b in range(2):
+            want_norm, want_raw = om.compute(params, img[b])
+            assert _rel(raw[b], want_raw) < 3e-2, (w, h, b)
+            assert np.abs(out[b] - want_norm).mean() < 2e-3, (w, h, b)
+
+
+def test_batch32_properties(small):
+    """BASELINE.json configs[1] at full size (batch 32, 518x518): size-independent properties -- every image is
+    min-max normalised on its own (min exactly 0, max ~1), the batch equals the concatenation of two half batches,
+    a checksum of per-image checksums is reproducible, and spot images match the oracle."""
+    imgs = synth.images(8, 518, 518, seed=4321)
+    imgs = np.concatenate([imgs, imgs[::-1], imgs[2:6], imgs[:4], imgs[4:], imgs[1:5]])[:32]
+    assert imgs.shape[0] == 32
+    out = small.compute_batch(imgs)
+    assert out.shape == (32, 518, 518) and np.isfinite(out).all()
+    assert (out.reshape(32, -1).min(axis=1) == 0).all()
+    assert np.abs(out.reshape(32, -1).max(axis=1) - 1).max() < 1e-6
+    halves = np.concatenate([small.compute_batch(imgs[:16]), small.compute_batch(imgs[16:])])
+    np.testing.assert_array_equal(halves, out)
+    sums = out.reshape(32, -1).astype(np.float64).sum(axis=1)
+    np.testing.assert_array_equal(sums[:8], sums[8:16][::-1])  # same pixels -> same bits wherever they sit in the batch
+    again = small.compute_batch(imgs).reshape(32, -1).astype(np.float64).sum(axis=1)
+    assert float(np.sum(sums * np.arange(1, 33))) == float(np.sum(again * np.arange(1, 33)))
+    om, params = _oracle(synth.SMALL, 0)
+    for b in (5, 31):
+        want, _ = om.compute(params, imgs[b])
+        assert np.abs(out[b] - want).mean() < 1e-3
+
+
+def test_converted_checkpoint_gives_identical_results(device, tmp_path):
+    """safetensors -> GGUF through vision.cpp_amd/convert.py (tensor order = file order, as with the reference's
+    converter) loads and computes bit-identically to the state-dict-ordered file: lookups are by name, the
+    conv2d_weights list by file index."""
+    from safetensors.numpy import save_file
+
+    from visioncpp_amd import convert
+
+    sd = synth.state_dict(synth.MINI, seed=4)
+    save_file(sd, str(tmp_path / "mini.safetensors"))
+    a = convert.convert_depth_anything(convert.load_safetensors(tmp_path / "mini.safetensors"), tmp_path / "a.gguf", image_size=112)
+    b = synth.write_gguf(tmp_path / "b.gguf", synth.MINI, sd=sd)
+    imgs = synth.images(2, 112, 112, seed=8)
+    ma = vision.Model.load(a, device)
+    assert (ma.info.n_layers, ma.info.n_heads, list(ma.info.feature_layers)) == (4, 2, [0, 1, 2, 3])
+    np.testing.assert_array_equal(ma.compute_batch(imgs), vision.Model.load(b, device).compute_batch(imgs))
