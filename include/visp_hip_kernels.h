@@ -40,6 +40,7 @@ VX_API int vx_event_create(void** ev);
 VX_API int vx_event_destroy(void* ev);
 VX_API int vx_event_record(void* ev, void* stream);
 VX_API int vx_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+VX_API int vx_stream_wait_event(void* stream, void* ev);            /* fork/join between streams (also under capture) */
 /* hipGraph capture of a launch sequence */
 VX_API int vx_graph_begin_capture(void* stream);
 VX_API int vx_graph_end_capture(void* stream, void** graph_exec);

@@ -64,7 +64,7 @@ C_API_SYMBOLS = [
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
     "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
-    "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_graph_begin_capture",
+    "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_stream_wait_event", "vx_graph_begin_capture",
     "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_conv3x3_supported", "vx_conv3x3_f16",
     "vx_attention_f16",
     "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
@@ -139,6 +139,7 @@ def init() -> ctypes.CDLL:
     lib.vx_event_destroy.argtypes = [c_void_p]
     lib.vx_event_record.argtypes = [c_void_p, c_void_p]
     lib.vx_event_elapsed_ms.argtypes = [c_void_p, c_void_p, POINTER(c_float)]
+    lib.vx_stream_wait_event.argtypes = [c_void_p, c_void_p]
     lib.vx_graph_begin_capture.argtypes = [c_void_p]
     lib.vx_graph_end_capture.argtypes = [c_void_p, POINTER(c_void_p)]
     lib.vx_graph_launch.argtypes = [c_void_p, c_void_p]

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/visp_hip_kernels.h"
@@ -321,6 +322,9 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
     }
 
     VX(vx_set_device(dev.index));
+    for (void*& s : model->aux_stream) VX(vx_stream_create(&s));
+    VX(vx_event_create(&model->fork_event));
+    for (void*& e : model->join_event) VX(vx_event_create(&e));
     model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256);
     VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
     if (with_data) {
@@ -339,6 +343,9 @@ void depthany_weights_ready(depthany_model& m) {
 
 depthany_model::~depthany_model() {
     if (ws.graph_exec) vx_graph_destroy(ws.graph_exec);
+    for (void* s : aux_stream) vx_stream_destroy(s);
+    vx_event_destroy(fork_event);
+    for (void* e : join_event) vx_event_destroy(e);
     for (auto& c : capture_bufs) vx_free(c.second.dev);
     vx_free(ws.arena.ptr);
     vx_free(weight_arena.ptr);
@@ -410,7 +417,7 @@ void depthany_reserve(depthany_model& m, int B, int W, int H) {
     if (W % ps || H % ps) throw except("depthany: extent %dx%d is not a multiple of the patch size %d", W, H, ps);
     if (m.ws.B == B && m.ws.W == W && m.ws.H == H && m.ws.arena.ptr) return;
 
-    const int pw = W / ps, ph = H / ps, Pn = pw * ph, T = Pn + 1, D = P.dino.embed_dim, Hh = P.dino.n_heads;
+    const int pw = W / ps, ph = H / ps, Pn = pw * ph, T = Pn + 1, D = P.dino.embed_dim;
     const long M = (long)B * T;
     const int F = Wt.fusion_c, HC = Wt.head_c;
     const int h3 = (ph + 2 - 3) / 2 + 1, w3 = (pw + 2 - 3) / 2 + 1;
@@ -674,49 +681,57 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     const int lh[4] = {4 * ph, 2 * ph, ph, (ph + 2 - 3) / 2 + 1};
     const int lw[4] = {4 * pw, 2 * pw, pw, (pw + 2 - 3) / 2 + 1};
     const void* lay[4];
-    for (int j = 0; j < 4; ++j) {
-        std::string fb = "feat" + std::to_string(j), rb = "r" + std::to_string(j);
-        vx_gemm_args a = c.base(Wt.re_proj[j], MP);
-        a.A = c.buf(fb.c_str()); a.lda = D;
-        a.a_group = Pn; a.a_group_stride = T; a.a_row_off = 1; // slice off the cls token (depth-anything.cpp:50)
-        a.epi = VX_EPI_F16;
-        a.out = c.buf(rb.c_str()); a.ldo = Wt.re_proj[j].N;
-        a.n_valid = Wt.re_proj[j].N; // pad columns are exact zeros and feed the next GEMM's padded K
-        c.mark("neck_proj", 1, 2.0 * MP * Wt.neck_c[j] * D, (double)MP * (D + Wt.re_proj[j].N) * 2);
-        c.gemm(a);
-    }
-    {
-        vx_gemm_args a = c.base(Wt.re_up0, MP); // conv_transpose k4 s4 as GEMM + pixel shuffle
-        a.A = c.buf("r0"); a.lda = Wt.re_proj[0].N;
-        a.epi = VX_EPI_PIXSHUF;
-        a.out = c.buf("l0"); a.ldo = Wt.neck_c[0];
-        a.ps_s = 4; a.ps_Cout = Wt.neck_c[0]; a.ps_H = ph; a.ps_W = pw;
-        c.mark("neck_convT", 1, 2.0 * MP * Wt.re_up0.n_real * Wt.neck_c[0], (double)MP * Wt.re_up0.n_real * 2);
-        c.gemm(a);
-        lay[0] = c.buf("l0");
-    }
-    {
-        vx_gemm_args a = c.base(Wt.re_up1, MP);
-        a.A = c.buf("r1"); a.lda = Wt.re_proj[1].N;
-        a.epi = VX_EPI_PIXSHUF;
-        a.out = c.buf("l1"); a.ldo = Wt.neck_c[1];
-        a.ps_s = 2; a.ps_Cout = Wt.neck_c[1]; a.ps_H = ph; a.ps_W = pw;
-        c.mark("neck_convT", 1, 2.0 * MP * Wt.re_up1.n_real * Wt.neck_c[1], (double)MP * Wt.re_up1.n_real * 2);
-        c.gemm(a);
-        lay[1] = c.buf("l1");
-    }
-    lay[2] = c.buf("r2");
-    c.conv(Wt.re_down3, c.buf("r3"), B, ph, pw, Wt.neck_c[3], 3, 2, 1, c.buf("l3"), Wt.neck_c[3], VX_EPI_F16, false, false, nullptr, nullptr, "neck_conv_s2");
-    lay[3] = c.buf("l3");
-    for (int j = 0; j < 4; ++j)
-        if (m.captures) { std::string nm = "reassemble_" + std::to_string(j); c.capture(nm.c_str(), lay[j], {B, lh[j], lw[j], Wt.neck_c[j]}, true); }
-
-    // ---- neck.convs (depth-anything.cpp:66-69): 3x3, no bias, -> F channels
     void* cb[4] = {c.buf("c0"), c.buf("c1"), c.buf("c2"), c.buf("c3")};
+    // Branch j = projection -> resize -> neck conv of tap j. The branches are independent (depth-anything.cpp:47-69)
+    // and several of their kernels have fewer blocks than the chip has CUs, so they CAN run on parallel streams.
+    // Measured (3 interleaved A/B rounds, batch 32): forking is 1-3 % SLOWER than the single stream (8.08-8.30 vs
+    // 8.00 ms per step), so it stays opt-in (VISP_FORK_NECK=1) as a documented negative result.
+    static const bool fork_enabled = getenv("VISP_FORK_NECK") != nullptr;
+    const bool fork = !m.timing && !m.captures && fork_enabled;
+    if (fork) {
+        VX(vx_event_record(m.fork_event, stream));
+        for (int j = 0; j < 3; ++j) VX(vx_stream_wait_event(m.aux_stream[j], m.fork_event));
+    }
     for (int j = 0; j < 4; ++j) {
+        c.stream = (fork && j < 3) ? m.aux_stream[j] : stream;
+        std::string fb = "feat" + std::to_string(j), rb = "r" + std::to_string(j);
+        {
+            vx_gemm_args a = c.base(Wt.re_proj[j], MP);
+            a.A = c.buf(fb.c_str()); a.lda = D;
+            a.a_group = Pn; a.a_group_stride = T; a.a_row_off = 1; // slice off the cls token (depth-anything.cpp:50)
+            a.epi = VX_EPI_F16;
+            a.out = c.buf(rb.c_str()); a.ldo = Wt.re_proj[j].N;
+            a.n_valid = Wt.re_proj[j].N; // pad columns are exact zeros and feed the next GEMM's padded K
+            c.mark("neck_proj", 1, 2.0 * MP * Wt.neck_c[j] * D, (double)MP * (D + Wt.re_proj[j].N) * 2);
+            c.gemm(a);
+        }
+        if (j < 2) { // conv_transpose k == stride (4, then 2) as GEMM + pixel shuffle
+            packed_gemm const& up = j == 0 ? Wt.re_up0 : Wt.re_up1;
+            vx_gemm_args a = c.base(up, MP);
+            a.A = c.buf(rb.c_str()); a.lda = Wt.re_proj[j].N;
+            a.epi = VX_EPI_PIXSHUF;
+            a.out = c.buf(j == 0 ? "l0" : "l1"); a.ldo = Wt.neck_c[j];
+            a.ps_s = j == 0 ? 4 : 2; a.ps_Cout = Wt.neck_c[j]; a.ps_H = ph; a.ps_W = pw;
+            c.mark("neck_convT", 1, 2.0 * MP * up.n_real * Wt.neck_c[j], (double)MP * up.n_real * 2);
+            c.gemm(a);
+            lay[j] = a.out;
+        } else if (j == 2) {
+            lay[2] = c.buf("r2");
+        } else {
+            c.conv(Wt.re_down3, c.buf("r3"), B, ph, pw, Wt.neck_c[3], 3, 2, 1, c.buf("l3"), Wt.neck_c[3], VX_EPI_F16, false, false, nullptr, nullptr, "neck_conv_s2");
+            lay[3] = c.buf("l3");
+        }
+        if (m.captures) { std::string nm = "reassemble_" + std::to_string(j); c.capture(nm.c_str(), lay[j], {B, lh[j], lw[j], Wt.neck_c[j]}, true); }
+        // neck.convs[j] (depth-anything.cpp:66-69): 3x3, no bias, -> F channels
         c.conv(Wt.neck_conv[j], lay[j], B, lh[j], lw[j], Wt.neck_c[j], 3, 1, 1, cb[j], F, VX_EPI_F16, false, false, nullptr, nullptr, "neck_convs");
         if (m.captures) { std::string nm = "neck_conv_" + std::to_string(j); c.capture(nm.c_str(), cb[j], {B, lh[j], lw[j], F}, true); }
     }
+    c.stream = stream;
+    if (fork)
+        for (int j = 0; j < 3; ++j) {
+            VX(vx_event_record(m.join_event[j], m.aux_stream[j]));
+            VX(vx_stream_wait_event(stream, m.join_event[j]));
+        }
 
     // ---- fusion stage (depth-anything.cpp:25-42, 71-77)
     void *t1 = c.buf("t1"), *t2 = c.buf("t2"), *t3 = c.buf("t3"), *up = c.buf("up"), *fused = c.buf("fused");

@@ -102,6 +102,11 @@ struct depthany_model { // vision.h:339-347 counterpart
     bool use_graph = false, captures = false, timing = false;
     std::map<std::string, capture_entry> capture_bufs;
     std::vector<timing_entry> last_timing;
+    // the four reassemble/neck-conv branches are independent until the fusion stage: they run on side
+    // streams (fork/join by events, captured into the hipGraph as parallel branches)
+    void* aux_stream[3] = {nullptr, nullptr, nullptr};
+    void* fork_event = nullptr;
+    void* join_event[3] = {nullptr, nullptr, nullptr};
     ~depthany_model();
 };
 

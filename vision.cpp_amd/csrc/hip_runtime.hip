@@ -107,6 +107,11 @@ int vx_event_elapsed_ms(void* start, void* stop, float* ms) {
     return 1;
 }
 
+int vx_stream_wait_event(void* stream, void* ev) {
+    VX_CHECK(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(ev), 0));
+    return 1;
+}
+
 int vx_graph_begin_capture(void* stream) {
     VX_CHECK(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
     return 1;

@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const vx_gemm_args p)
 
     // ---- halo: chunk index L = pix*CH + phys, lane-linear; logical chunk = phys ^ swz(pix)
     const f16* __restrict__ X = reinterpret_cast<const f16*>(p.A) + (long)b * H * W * CIN;
-#pragma unroll
     for (int i = wave; i < HALO_INSTR; i += 4) {
         const int L = i * 64 + lane;
         const int pix = L / CH, phys = L - pix * CH;
