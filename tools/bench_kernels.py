@@ -78,7 +78,7 @@ def gemm_stamps(name, M, N, K, epi):
     g.A, g.lda, g.W, g.bias, g.M, g.N, g.K = a.ptr, K, w.ptr, b.ptr, M, N, K
     g.epi, g.out, g.ldo, g.lambda_ = epi, out.ptr, N, lam.ptr
     g.q, g.k, g.vt, g.qkv_T, g.qkv_H, g.q_scale = q.ptr, k.ptr, v.ptr, 1370, 6, 0.125
-    for _ in range(2):
+    for _ in range(300):  # let the clock settle under sustained load before stamping
         L.vx_check(api.vx_gemm_f16(C.byref(g), stream))
     g.debug_stamps = st.ptr
     L.vx_check(api.vx_gemm_f16(C.byref(g), stream))
@@ -90,6 +90,10 @@ def gemm_stamps(name, M, N, K, epi):
     for i, nm in enumerate(names):
         d = t[:, i + 1] - t[:, i]
         print(f"   {nm:18s} median {np.median(d):9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}")
+    rt = (t[:, 7] - t[:, 6]).astype(np.float64)  # 100 MHz ticks
+    ok = rt > 0
+    mhz = (t[ok, 5] - t[ok, 0]) / rt[ok] * 100.0
+    print(f"   in-kernel shader clock (s_memtime / s_memrealtime): median {np.median(mhz):.0f} MHz  p10 {np.percentile(mhz, 10):.0f}  p90 {np.percentile(mhz, 90):.0f}")
     life = t[:, 5] - t[:, 0]
     print(f"   {'block lifetime':18s} median {np.median(life):9.0f}  p10 {np.percentile(life, 10):9.0f}  p90 {np.percentile(life, 90):9.0f}")
     starts = np.sort(t[:, 0] - t0)

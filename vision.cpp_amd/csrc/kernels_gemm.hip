@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
         if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); // 100 MHz reference
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int r = lane & 31, h = lane >> 5;
 
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
         } // passes
     }
     stamp(5);
+    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool CONV>
