@@ -317,3 +317,78 @@ def make_params(patch_size=14, embed_dim=384, n_layers=12, n_heads=6, image_size
                 feature_layers=(2, 5, 8, 11), max_depth=1.0, gelu_mode=GELU_GGML_F16_LUT) -> Params:
     return Params(patch_size, embed_dim, n_layers, n_heads, image_size, image_multiple,
                   (C.c_int * 4)(*feature_layers), max_depth, gelu_mode)
+
+
+# ---- ESRGAN (reference src/visp/arch/esrgan.cpp, vision.cpp:208-253, image.cpp:612-693) -------------
+
+class EsrganParams(C.Structure):
+    _fields_ = [("scale", C.c_int), ("n_blocks", C.c_int)]
+
+
+class TileLayout(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("image_w", "image_h", "overlap_x", "overlap_y", "n_x", "n_y", "tile_w", "tile_h")]
+
+
+def _esr_lib():
+    L = lib()
+    if not getattr(L, "_esr_ready", False):
+        fp, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+        L.vo_esrgan_generate.argtypes = [C.c_void_p, C.POINTER(EsrganParams), fp, C.c_int, C.c_int, fp, C.POINTER(Capture), C.c_int]
+        L.vo_esrgan_rdb.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int, C.c_int, C.c_int]
+        L.vo_tile_layout_init.argtypes = [C.POINTER(TileLayout), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.vo_tile_scale.argtypes = [C.POINTER(TileLayout), C.c_int, C.POINTER(TileLayout)]
+        L.vo_tile_merge.argtypes = [fp, fp, C.c_int, C.c_int, C.POINTER(TileLayout)]
+        L.vo_esrgan_compute.argtypes = [C.c_void_p, C.POINTER(EsrganParams), u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L._esr_ready = True
+    return L
+
+
+def tile_layout(w: int, h: int, max_tile_size: int, overlap: int, align: int = 16) -> TileLayout:
+    t = TileLayout()
+    _esr_lib().vo_tile_layout_init(C.byref(t), w, h, max_tile_size, overlap, align)
+    return t
+
+
+def tile_scale(t: TileLayout, scale: int) -> TileLayout:
+    r = TileLayout()
+    _esr_lib().vo_tile_scale(C.byref(t), scale, C.byref(r))
+    return r
+
+
+def tile_merge(tile: np.ndarray, dst: np.ndarray, cx: int, cy: int, layout: TileLayout):
+    """tile [tile_h, tile_w, 3] f32 blended into dst [image_h, image_w, 3] f32 (in place)."""
+    t = _f32(tile)
+    assert dst.dtype == np.float32 and dst.flags.c_contiguous
+    _esr_lib().vo_tile_merge(_fp(t), _fp(dst), cx, cy, C.byref(layout))
+
+
+def esrgan_generate(model: "Model", scale: int, n_blocks: int, x: np.ndarray, captures: dict[str, int] | None = None):
+    x = _f32(x)
+    h, w = x.shape[:2]
+    out = np.empty((h * scale, w * scale, 3), np.float32)
+    p = EsrganParams(scale, n_blocks)
+    caps = captures or {}
+    bufs = {k: np.empty(n, np.float32) for k, n in caps.items()}
+    names = [k.encode() for k in caps]
+    carr = (Capture * max(1, len(caps)))(*[Capture(nm, _fp(bufs[k]), bufs[k].size, 0) for nm, k in zip(names, caps)])
+    _check(_esr_lib().vo_esrgan_generate(model._h, C.byref(p), _fp(x), w, h, _fp(out), carr, len(caps)))
+    if captures is None:
+        return out
+    return out, {k: bufs[k][: carr[i].written].copy() for i, k in enumerate(caps)}
+
+
+def esrgan_rdb(model: "Model", prefix: str, x: np.ndarray) -> np.ndarray:
+    x = _f32(x).copy()
+    h, w, nf = x.shape
+    _check(_esr_lib().vo_esrgan_rdb(model._h, prefix.encode(), _fp(x), w, h, nf))
+    return x
+
+
+def esrgan_compute(model: "Model", scale: int, n_blocks: int, img_u8: np.ndarray, fmt: int = RGB_U8) -> np.ndarray:
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = img.shape[:2]
+    out = np.empty((h * scale, w * scale, 4), np.uint8)
+    p = EsrganParams(scale, n_blocks)
+    _check(_esr_lib().vo_esrgan_compute(model._h, C.byref(p), img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, fmt,
+                                        out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out

@@ -986,3 +986,200 @@ int vo_depthany_compute(const vo_model* m, const vo_depthany_params* P, const ui
     if (!out_raw) free(raw);
     return ok;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* ESRGAN (reference src/visp/arch/esrgan.cpp, src/visp/vision.cpp:208-253, src/visp/image.cpp:612-693) */
+
+static void leaky_relu_inplace(float* x, int64_t n, float slope) { /* ggml_leaky_relu(x, 0.2, inplace) */
+    for (int64_t i = 0; i < n; ++i) x[i] = x[i] > 0.0f ? x[i] : x[i] * slope;
+}
+
+/* channel concat of NHWC maps (concat(m, {a, b}, dim 0), esrgan.cpp:29-36) */
+static float* concat_c(const float* a, int ca, const float* b, int cb, int64_t pixels) {
+    float* o = (float*)malloc((size_t)pixels * (ca + cb) * 4);
+    for (int64_t p = 0; p < pixels; ++p) {
+        memcpy(o + p * (ca + cb), a + p * ca, (size_t)ca * 4);
+        memcpy(o + p * (ca + cb) + ca, b + p * cb, (size_t)cb * 4);
+    }
+    return o;
+}
+
+/* esrgan.cpp:21-25 conv_block: conv_2d(m[0], x, 1, 1) + leaky_relu 0.2 */
+static int esr_conv(const vo_model* m, const char* prefix, const float* x, int h, int w, int cin, int act, int* cout, float** y) {
+    int oh, ow;
+    if (!conv_m(m, prefix, x, 1, h, w, cin, 1, 1, &oh, &ow, cout, y)) return 0;
+    if (act) leaky_relu_inplace(*y, (int64_t)h * w * *cout, 0.2f);
+    return 1;
+}
+
+/* esrgan.cpp:27-41 */
+int vo_esrgan_rdb(const vo_model* m, const char* prefix, float* x, int w, int h, int nf) {
+    char p[160];
+    int64_t px = (int64_t)w * h;
+    float *cat = (float*)malloc((size_t)px * nf * 4), *xi = NULL;
+    memcpy(cat, x, (size_t)px * nf * 4);
+    int c = nf, gc = 0;
+    for (int k = 1; k <= 4; ++k) {
+        snprintf(p, sizeof p, "%s.conv%d.0", prefix, k);
+        if (!esr_conv(m, p, cat, h, w, c, 1, &gc, &xi)) { free(cat); return 0; }
+        float* nc = concat_c(cat, c, xi, gc, px);
+        free(cat); free(xi);
+        cat = nc; c += gc;
+    }
+    snprintf(p, sizeof p, "%s.conv5.0", prefix);
+    int c5;
+    if (!esr_conv(m, p, cat, h, w, c, 0, &c5, &xi)) { free(cat); return 0; }
+    free(cat);
+    if (c5 != nf) { free(xi); VO_FAIL("%s: conv5 has %d outputs, expected %d", prefix, c5, nf); }
+    for (int64_t i = 0; i < px * nf; ++i) { /* ggml_scale_inplace(x5, 0.2); ggml_add(x, x5) */
+        float s = xi[i] * 0.2f;
+        x[i] = x[i] + s;
+    }
+    free(xi);
+    return 1;
+}
+
+static float* upsample_nearest2(const float* x, int h, int w, int c) { /* interpolate NEAREST to (2w, 2h), esrgan.cpp:13-16 */
+    float* o = (float*)malloc((size_t)4 * h * w * c * 4);
+    for (int y = 0; y < 2 * h; ++y)
+        for (int xx = 0; xx < 2 * w; ++xx)
+            memcpy(o + ((int64_t)y * 2 * w + xx) * c, x + ((int64_t)(y / 2) * w + xx / 2) * c, (size_t)c * 4);
+    return o;
+}
+
+/* esrgan_generate, esrgan.cpp:55-79 */
+int vo_esrgan_generate(const vo_model* m, const vo_esrgan_params* P, const float* x_in, int w, int h, float* out,
+                       vo_capture* caps, int ncap) {
+    char p[160], cname[64];
+    int nf;
+    float* x = NULL;
+    if (!esr_conv(m, "model.0", x_in, h, w, 3, 0, &nf, &x)) return 0;
+    int64_t px = (int64_t)w * h;
+    capture(caps, ncap, "fea", x, px * nf);
+    float* sub = (float*)malloc((size_t)px * nf * 4);
+    memcpy(sub, x, (size_t)px * nf * 4);
+    for (int i = 0; i < P->n_blocks; ++i) { /* rrdb, esrgan.cpp:43-51 */
+        float* blk_in = (float*)malloc((size_t)px * nf * 4);
+        memcpy(blk_in, sub, (size_t)px * nf * 4);
+        for (int r = 1; r <= 3; ++r) {
+            snprintf(p, sizeof p, "model.1.sub.%d.RDB%d", i, r);
+            if (!vo_esrgan_rdb(m, p, sub, w, h, nf)) { free(x); free(sub); free(blk_in); return 0; }
+        }
+        for (int64_t k = 0; k < px * nf; ++k) { float s = sub[k] * 0.2f; sub[k] = s + blk_in[k]; }
+        free(blk_in);
+        snprintf(cname, sizeof cname, "rrdb_%d", i);
+        capture(caps, ncap, cname, sub, px * nf);
+    }
+    float* lr = NULL;
+    int c2;
+    snprintf(p, sizeof p, "model.1.sub.%d", P->n_blocks);
+    if (!esr_conv(m, p, sub, h, w, nf, 0, &c2, &lr)) { free(x); free(sub); return 0; }
+    free(sub);
+    for (int64_t k = 0; k < px * nf; ++k) x[k] = x[k] + lr[k];
+    free(lr);
+    capture(caps, ncap, "trunk", x, px * nf);
+    int seq = 2, cw = w, ch = h, n_up = 0;
+    for (int s = P->scale; s > 1; s >>= 1) ++n_up; /* log2(scale), src/util/math.h:24-31 */
+    for (int i = 0; i < n_up; ++i) { /* esrgan::upsample, esrgan.cpp:13-19 */
+        float* up = upsample_nearest2(x, ch, cw, nf);
+        free(x);
+        cw *= 2; ch *= 2;
+        snprintf(p, sizeof p, "model.%d", seq + 1);
+        if (!esr_conv(m, p, up, ch, cw, nf, 1, &c2, &x)) { free(up); return 0; }
+        free(up);
+        seq += 3;
+    }
+    float *h0 = NULL, *h1 = NULL;
+    snprintf(p, sizeof p, "model.%d", seq);
+    if (!esr_conv(m, p, x, ch, cw, nf, 1, &c2, &h0)) { free(x); return 0; }
+    free(x);
+    snprintf(p, sizeof p, "model.%d", seq + 2);
+    int c3;
+    if (!esr_conv(m, p, h0, ch, cw, c2, 0, &c3, &h1)) { free(h0); return 0; }
+    free(h0);
+    if (c3 != 3) { free(h1); VO_FAIL("esrgan: final conv has %d channels, expected 3", c3); }
+    memcpy(out, h1, (size_t)ch * cw * 3 * 4);
+    capture(caps, ncap, "result", h1, (int64_t)ch * cw * 3);
+    free(h1);
+    return 1;
+}
+
+/* tile_layout::tile_layout, image.cpp:612-620 */
+static int div_ceil_i(int a, int b) { return (a + b - 1) / b; }
+void vo_tile_layout_init(vo_tile_layout* t, int w, int h, int max_tile_size, int overlap, int align) {
+    t->image_w = w; t->image_h = h; t->overlap_x = t->overlap_y = overlap;
+    t->n_x = div_ceil_i(w, max_tile_size); t->n_y = div_ceil_i(h, max_tile_size);
+    int ow = w + (t->n_x - 1) * overlap, oh = h + (t->n_y - 1) * overlap;
+    t->tile_w = div_ceil_i(div_ceil_i(ow, t->n_x), align) * align;
+    t->tile_h = div_ceil_i(div_ceil_i(oh, t->n_y), align) * align;
+}
+void vo_tile_scale(const vo_tile_layout* o, int s, vo_tile_layout* r) { /* image.cpp:622-629 */
+    r->image_w = o->image_w * s; r->image_h = o->image_h * s;
+    r->overlap_x = o->overlap_x * s; r->overlap_y = o->overlap_y * s;
+    r->n_x = o->n_x; r->n_y = o->n_y; r->tile_w = o->tile_w * s; r->tile_h = o->tile_h * s;
+}
+static void tile_start(const vo_tile_layout* t, int cx, int cy, int px, int py, int* sx, int* sy) { /* :631-634 */
+    *sx = cx * (t->tile_w - t->overlap_x) + (cx == 0 ? 0 : px);
+    *sy = cy * (t->tile_h - t->overlap_y) + (cy == 0 ? 0 : py);
+}
+static void tile_end(const vo_tile_layout* t, int cx, int cy, int px, int py, int* ex, int* ey) { /* :636-641 */
+    int sx, sy;
+    tile_start(t, cx, cy, 0, 0, &sx, &sy);
+    int x = sx + t->tile_w - (cx == t->n_x - 1 ? 0 : px), y = sy + t->tile_h - (cy == t->n_y - 1 ? 0 : py);
+    *ex = x < t->image_w ? x : t->image_w;
+    *ey = y < t->image_h ? y : t->image_h;
+}
+
+/* tile_merge, image.cpp:653-693 */
+void vo_tile_merge(const float* tile, float* dst, int cx, int cy, const vo_tile_layout* t) {
+    int bx, by, ex, ey, pbx, pby, pex, pey;
+    tile_start(t, cx, cy, 0, 0, &bx, &by);
+    tile_end(t, cx, cy, 0, 0, &ex, &ey);
+    tile_start(t, cx, cy, t->overlap_x, t->overlap_y, &pbx, &pby);
+    tile_end(t, cx, cy, t->overlap_x, t->overlap_y, &pex, &pey);
+    const int ov[2] = {t->overlap_x, t->overlap_y}, pb[2] = {pbx, pby}, pe[2] = {pex, pey};
+    for (int y = by; y < ey; ++y)
+        for (int x = bx; x < ex; ++x) {
+            const int idx[2] = {x, y};
+            float weight = 1.0f;
+            int cov[2] = {0, 0};
+            for (int i = 0; i < 2; ++i) {
+                if (idx[i] < pb[i]) { weight *= (float)(ov[i] - (pb[i] - idx[i]) + 1); cov[i] = ov[i]; }
+                else if (idx[i] >= pe[i]) { weight *= (float)(ov[i] - (idx[i] - pe[i])); cov[i] = ov[i]; }
+            }
+            const float* tv = tile + ((int64_t)(y - by) * t->tile_w + (x - bx)) * 3;
+            float* dv = dst + ((int64_t)y * t->image_w + x) * 3;
+            if (weight > 0) {
+                float norm = (float)((cov[0] + 1) * (cov[1] + 1));
+                float blend = weight / norm;
+                for (int c = 0; c < 3; ++c) dv[c] = dv[c] + blend * tv[c];
+            } else {
+                for (int c = 0; c < 3; ++c) dv[c] = tv[c];
+            }
+        }
+}
+
+/* esrgan_compute, vision.cpp:220-253 (esrgan_default_tile_size = 224, overlap 16) */
+int vo_esrgan_compute(const vo_model* m, const vo_esrgan_params* P, const uint8_t* img, int w, int h, int format,
+                      uint8_t* out_rgba) {
+    vo_tile_layout tiles, tiles_out;
+    vo_tile_layout_init(&tiles, w, h, 224, 16, 16);
+    vo_tile_scale(&tiles, P->scale, &tiles_out);
+    int sch = fmt_channels(format);
+    float* in_tile = (float*)malloc((size_t)tiles.tile_w * tiles.tile_h * 3 * 4);
+    float* out_tile = (float*)malloc((size_t)tiles_out.tile_w * tiles_out.tile_h * 3 * 4);
+    int64_t on = (int64_t)tiles_out.image_w * tiles_out.image_h * 3;
+    float* out_img = (float*)calloc((size_t)on, 4);
+    const float off[4] = {0, 0, 0, 0}, sc[4] = {1, 1, 1, 1};
+    int ok = 1;
+    for (int t = 0; t < tiles.n_x * tiles.n_y && ok; ++t) {
+        int cx = t % tiles.n_x, cy = t / tiles.n_x, sx, sy;
+        tile_start(&tiles, cx, cy, 0, 0, &sx, &sy);
+        ok = vo_image_u8_to_f32(img, w, h, w * sch, format, in_tile, tiles.tile_w, tiles.tile_h, VO_RGB_F32, off, sc, sx, sy);
+        if (ok) ok = vo_esrgan_generate(m, P, in_tile, tiles.tile_w, tiles.tile_h, out_tile, NULL, 0);
+        if (ok) vo_tile_merge(out_tile, out_img, cx, cy, &tiles_out);
+    }
+    if (ok) ok = vo_image_f32_to_u8(out_img, tiles_out.image_w, tiles_out.image_h, VO_RGB_F32, out_rgba, VO_RGBA_U8, 1.0f, 0.0f);
+    free(in_tile); free(out_tile); free(out_img);
+    return ok;
+}

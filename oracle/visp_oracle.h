@@ -134,6 +134,25 @@ int vo_depthany_predict(const vo_model*, const vo_depthany_params*, const float*
 int vo_depthany_compute(const vo_model*, const vo_depthany_params*, const uint8_t* rgb, int w, int h,
                         float* out_normalized, float* out_raw /*nullable*/);
 
+/* ---- ESRGAN / Real-ESRGAN (reference src/visp/arch/esrgan.cpp, vision.cpp:208-253) ---- */
+typedef struct { int scale, n_blocks; } vo_esrgan_params;
+/* esrgan_generate (esrgan.cpp:55-79): x = rgb_f32 [h][w][3] in [0,1] -> out [h*scale][w*scale][3]; tensors are
+ * looked up as "model.0.weight", "model.1.sub.<i>.RDB<k>.conv<j>.0.weight", ... exactly as the reference does */
+int vo_esrgan_generate(const vo_model*, const vo_esrgan_params*, const float* x, int w, int h, float* out,
+                       vo_capture* captures, int n_captures);
+/* one residual dense block (esrgan.cpp:27-41), prefix e.g. "model.1.sub.0.RDB1"; x [h][w][nf] in/out */
+int vo_esrgan_rdb(const vo_model*, const char* prefix, float* x, int w, int h, int nf);
+
+/* tile_layout (src/visp/image.cpp:612-651) */
+typedef struct { int image_w, image_h, overlap_x, overlap_y, n_x, n_y, tile_w, tile_h; } vo_tile_layout;
+void vo_tile_layout_init(vo_tile_layout*, int w, int h, int max_tile_size, int overlap, int align);
+void vo_tile_scale(const vo_tile_layout* in, int scale, vo_tile_layout* out);
+/* tile_merge (image.cpp:653-693): blends an rgb_f32 tile into dst (rgb_f32 image, zero-initialised) */
+void vo_tile_merge(const float* tile, float* dst, int tile_x, int tile_y, const vo_tile_layout*);
+/* esrgan_compute (vision.cpp:220-253): any u8 colour image -> rgba_u8 [h*scale][w*scale][4] */
+int vo_esrgan_compute(const vo_model*, const vo_esrgan_params*, const uint8_t* img, int w, int h, int format,
+                      uint8_t* out_rgba);
+
 /* dino building blocks, exposed for module-level parity tests */
 int vo_dino_layer(const vo_model*, const char* prefix, int n_heads, int gelu_mode, float* x /*[N][C] in/out*/,
                   int64_t N, int64_t C);

@@ -177,3 +177,81 @@ def images(n: int, w: int = 518, h: int = 518, seed: int = 1234) -> np.ndarray:
         img = 0.5 + img + rng.uniform(-0.08, 0.08, img.shape).astype(np.float32)
         out[i] = np.clip(img * 255.0, 0, 255).astype(np.uint8)
     return out
+
+
+# ---- ESRGAN / Real-ESRGAN (RRDBNet, spandrel key layout; reference tests/test_esrgan.py:150-212) -------------
+
+@dataclass
+class EsrganConfig:
+    num_filters: int = 64
+    num_blocks: int = 23
+    scale: int = 4
+    gc: int = 32
+    name: str = "x4"
+
+
+ESRGAN_X4 = EsrganConfig()                                           # RealESRGAN_x4 (BASELINE.json configs[2])
+ESRGAN_TINY = EsrganConfig(num_filters=64, num_blocks=2, scale=2, name="tiny")
+
+
+def esrgan_state_dict(cfg: EsrganConfig = ESRGAN_X4, seed: int = 0) -> dict[str, np.ndarray]:
+    """float32 tensors with the names spandrel gives RRDBNet (what scripts/convert.py:524-527 writes)."""
+    rng = np.random.default_rng(seed)
+    sd: dict[str, np.ndarray] = {}
+    nf, gc = cfg.num_filters, cfg.gc
+
+    def conv(name, cout, cin, gain=1.0):
+        sd[f"{name}.weight"] = (rng.standard_normal((cout, cin, 3, 3)) * gain / np.sqrt(cin * 9)).astype(np.float32)
+        sd[f"{name}.bias"] = (rng.standard_normal(cout) * 0.02).astype(np.float32)
+
+    conv("model.0", nf, 3)
+    for i in range(cfg.num_blocks):
+        for r in (1, 2, 3):
+            p = f"model.1.sub.{i}.RDB{r}"
+            for k in range(4):
+                conv(f"{p}.conv{k + 1}.0", gc, nf + k * gc, gain=1.2)
+            conv(f"{p}.conv5.0", nf, nf + 4 * gc, gain=1.5)
+            if r == 3:
+                # random RRDBs grow the signal by ~1.2x each (x + 0.2*(x + ...)); trained nets do not. Cancel the
+                # identity part of the last dense block so 23 blocks stay O(1) in f16.
+                sd[f"{p}.conv5.0.weight"][np.arange(nf), np.arange(nf), 1, 1] -= 5.0
+    conv(f"model.1.sub.{cfg.num_blocks}", nf, nf, gain=0.7)
+    seq = 2
+    s = cfg.scale
+    while s > 1:
+        conv(f"model.{seq + 1}", nf, nf, gain=1.2)
+        seq += 3
+        s >>= 1
+    conv(f"model.{seq}", nf, nf, gain=1.2)
+    conv(f"model.{seq + 2}", 3, nf, gain=0.25)
+    sd[f"model.{seq + 2}.bias"] = np.array([0.45, 0.5, 0.55], np.float32)  # keeps the output inside [0, 1] mostly
+    return sd
+
+
+def esrgan_gguf_tensors(sd: dict[str, np.ndarray]):
+    """scripts/convert.py:504-527 (convert_esrgan, --quantize f16, default layout): every conv kernel stays OIHW and is
+    listed in esrgan.conv2d_weights; all float tensors -> f16."""
+    out: dict[str, np.ndarray] = {}
+    conv2d: list[int] = []
+    for name, t in sd.items():
+        if _is_conv_2d(name, t):
+            conv2d.append(len(out))
+        out[name] = t.astype(np.float16)
+    return out, conv2d
+
+
+def write_esrgan_gguf(path: str | Path, cfg: EsrganConfig = ESRGAN_X4, seed: int = 0, sd: dict[str, np.ndarray] | None = None) -> Path:
+    sd = sd if sd is not None else esrgan_state_dict(cfg, seed)
+    tensors, conv2d = esrgan_gguf_tensors(sd)
+    w = GGUFWriter(path, "esrgan")
+    w.add_string("esrgan.tensor_data_layout", "whcn")
+    w.add_int32("esrgan.scale", cfg.scale)
+    w.add_int32("esrgan.block_count", cfg.num_blocks)
+    w.add_int32("esrgan.filter_count", cfg.num_filters)
+    w.add_uint32("general.quantization_version", 2)
+    w.add_uint32("general.file_type", 1)
+    w.add_array_i32("esrgan.conv2d_weights", conv2d)
+    for name, t in tensors.items():
+        w.add_tensor(name, t)
+    w.write()
+    return Path(path)
