@@ -118,6 +118,28 @@ typedef struct visp_timing { char name[32]; float ms; int32_t launches; double f
 VISP_API int32_t visp_depthany_enable_timing(visp_model* m, int32_t enable);
 VISP_API int32_t visp_depthany_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
 
+/* ---- ESRGAN extension (family 4; reference vision.h:284-304, vision.cpp:208-253) ---------------------------
+ * visp_model_load / visp_model_compute work as in the reference (one image in, rgba_u8 at extent*scale out).
+ * The batched entry points take B images of one extent and push all their tiles through the network together. */
+typedef struct visp_esrgan_info { int32_t scale, n_blocks, n_filters, growth, tile_group; } visp_esrgan_info;
+VISP_API int32_t visp_esrgan_get_info(visp_model const* m, visp_esrgan_info* out);
+/* tiles per network pass (workspace bound / cache-locality knob); default 64 or $VISP_ESRGAN_TILE_GROUP */
+VISP_API int32_t visp_esrgan_set_tile_group(visp_model* m, int32_t tiles);
+VISP_API int32_t visp_esrgan_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes);
+VISP_API int32_t visp_esrgan_weights_ready(visp_model* m);
+/* tile_scale(tile_layout(extent, 224, 16), scale): out8 = image w,h, overlap x,y, n_tiles x,y, tile w,h (image.cpp:612-629) */
+VISP_API int32_t visp_esrgan_tile_layout(int32_t w, int32_t h, int32_t scale, int32_t out8[8]);
+/* img: u8 [B,h,w,channels(format)] (rgba/bgra/argb/rgb), out: rgba_u8 [B, h*scale, w*scale, 4]; device pointers;
+ * stream = hipStream_t or NULL (NULL: the device's stream, synchronised before returning) */
+VISP_API int32_t visp_esrgan_compute_batch_device(visp_model* m, void const* img, int32_t batch, int32_t w, int32_t h, int32_t format,
+                                                  void* out_rgba, void* stream);
+VISP_API int32_t visp_esrgan_compute_batch_host(visp_model* m, uint8_t const* img, int32_t batch, int32_t w, int32_t h, int32_t format,
+                                                uint8_t* out_rgba);
+/* esrgan_generate (esrgan.cpp:55-79) on n rgb_f32 tiles [n,h,w,3] -> [n,h*scale,w*scale,3] (host buffers; for tests) */
+VISP_API int32_t visp_esrgan_generate_host(visp_model* m, float const* rgb, int32_t n, int32_t w, int32_t h, float* out);
+VISP_API int32_t visp_esrgan_enable_timing(visp_model* m, int32_t enable);
+VISP_API int32_t visp_esrgan_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
+
 #ifdef __cplusplus
 }
 #endif

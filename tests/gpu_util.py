@@ -88,3 +88,49 @@ def gemm(a_dev, w: np.ndarray, bias, M, epi, *, lda=None, out=None, ldo=None, ke
 def rel_err(got: np.ndarray, want: np.ndarray) -> float:
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+# ---- ESRGAN dense-block conv (vx_dconv3x3_f16) -----------------------------------------------------------------
+
+def pack_dconv(w: np.ndarray, cin_pad: int | None = None, cout_pad: int | None = None) -> np.ndarray:
+    """torch conv weight [Cout, Cin, 3, 3] -> f16 [cin/32][9][cout][32] with the four 16-byte groups of each
+    (tap, n) row at position g ^ ((n >> 2) & 3) -- the layout include/visp_hip_kernels.h documents."""
+    co, ci = w.shape[:2]
+    cip = cin_pad or -(-ci // 32) * 32
+    cop = cout_pad or -(-co // 32) * 32
+    wp = np.zeros((cop, cip, 3, 3), np.float16)
+    wp[:co, :ci] = w.astype(np.float16)
+    t = wp.reshape(cop, cip // 32, 4, 8, 9).transpose(1, 4, 0, 2, 3)  # [chunk][tap][n][g][8]
+    out = np.empty_like(t)
+    n = np.arange(cop)
+    for g in range(4):
+        out[:, :, n, g ^ ((n >> 2) & 3)] = t[:, :, n, g]
+    return np.ascontiguousarray(out)
+
+
+def dconv(x_dev, x_ld, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=0, out=None, ldo=None, out_off=0,
+          res1=None, res1_ld=0, s1=1.0, res2=None, res2_ld=0, s2=1.0, rgb=False, cin_pad=None):
+    """Launches vx_dconv3x3_f16; returns the output as numpy (f16 [B,H,W,ldo] or f32 [B,H,W,3])."""
+    cout = w.shape[0]
+    cop = -(-cout // 32) * 32
+    wd = dev(pack_dconv(w, cin_pad or cin, cop))
+    bd = dev(pad_vec(bias, cop)) if bias is not None else None
+    if rgb:
+        ob = out or empty(B * H * W * 3 * 4)
+        ldo = 3
+    else:
+        ldo = ldo or cop
+        ob = out or empty(B * H * W * ldo * 2)
+    a = L.DconvArgs()
+    a.x, a.x_ld, a.cin, a.up2 = x_dev.ptr, x_ld, cin, int(up2)
+    a.B, a.H, a.W = B, H, W
+    a.w, a.bias, a.cout = wd.ptr, (bd.ptr if bd else None), cop
+    a.epi, a.act = (L.DC_RGB_F32 if rgb else L.DC_F16), act
+    a.s1, a.res1, a.res1_ld = s1, (res1.ptr if res1 else None), res1_ld
+    a.s2, a.res2, a.res2_ld = s2, (res2.ptr if res2 else None), res2_ld
+    a.out, a.ldo = ob.ptr + out_off * 2, ldo
+    L.vx_check(api().vx_dconv3x3_f16(C.byref(a), None))
+    sync()
+    if rgb:
+        return ob.to_numpy(np.float32, (B, H, W, 3))
+    return ob.to_numpy(np.float16, (B, H, W, ldo))

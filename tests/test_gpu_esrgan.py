@@ -1,0 +1,252 @@
+"""GPU parity of the ESRGAN row: dense-block conv kernel, tile pre/post-processing and (below) the whole
+RRDBNet through the C ABI, each against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    from tests import gpu_util as G
+    G.release()
+
+
+def _conv_ref(x, w, b, act=0):
+    """x [B,H,W,Cin] f32, w torch [Cout,Cin,3,3] (f16-rounded), oracle conv + optional LeakyReLU 0.2."""
+    B, H, W, Cin = x.shape
+    wf = np.ascontiguousarray(w.astype(np.float16).astype(np.float32).transpose(0, 2, 3, 1))
+    y = O.conv2d_nhwc(x, wf, b, stride=1, pad=1)
+    if act:
+        y = np.where(y > 0, y, y * np.float32(0.2))
+    return y
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 32, 16, 32, 1), (96, 32, 24, 40, 2), (128, 32, 33, 47, 1), (160, 32, 16, 16, 3),
+                                            (192, 64, 48, 48, 2), (64, 64, 37, 70, 1), (32, 64, 20, 36, 1)])
+def test_dconv_channel_prefix(cin, cout, H, W, B):
+    from tests import gpu_util as G
+    rng = np.random.default_rng(cin * 7 + cout)
+    x_ld = 192
+    buf = (rng.standard_normal((B, H, W, x_ld)) * 0.5).astype(np.float16)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    ref = _conv_ref(buf[..., :cin].astype(np.float32), w, b, act=1)
+    xd = G.dev(buf)
+    # output into a channel slice of a second 192-wide buffer; the rest must stay untouched
+    canary = np.full((B, H, W, x_ld), 7.0, np.float16)
+    od = G.dev(canary)
+    off = 64 if cout == 32 else 0
+    got = G.dconv(xd, x_ld, cin, B, H, W, w, b, act=1, out=od, ldo=x_ld, out_off=off)
+    np.testing.assert_allclose(got[..., off:off + cout].astype(np.float32), ref, atol=4e-3, rtol=4e-3)
+    mask = np.ones(x_ld, bool)
+    mask[off:off + cout] = False
+    assert (got[..., mask] == np.float16(7.0)).all()
+
+
+def test_dconv_scaled_residuals():
+    """conv5 of a dense block at the end of an RRDB: (conv*0.2 + x)*0.2 + rrdb_in (esrgan.cpp:38-40, 49-50)."""
+    from tests import gpu_util as G
+    rng = np.random.default_rng(3)
+    B, H, W = 2, 40, 52
+    buf = (rng.standard_normal((B, H, W, 192)) * 0.5).astype(np.float16)
+    r2 = (rng.standard_normal((B, H, W, 64)) * 0.5).astype(np.float16)
+    w = (rng.standard_normal((64, 192, 3, 3)) / np.sqrt(192 * 9)).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    y = _conv_ref(buf.astype(np.float32), w, b)
+    xd, r2d = G.dev(buf), G.dev(r2)
+    got1 = G.dconv(xd, 192, 192, B, H, W, w, b, res1=xd, res1_ld=192, s1=0.2)
+    np.testing.assert_allclose(got1.astype(np.float32), y * 0.2 + buf[..., :64].astype(np.float32), atol=3e-3, rtol=3e-3)
+    got2 = G.dconv(xd, 192, 192, B, H, W, w, b, res1=xd, res1_ld=192, s1=0.2, res2=r2d, res2_ld=64, s2=0.2)
+    ref2 = (y * 0.2 + buf[..., :64].astype(np.float32)) * 0.2 + r2.astype(np.float32)
+    np.testing.assert_allclose(got2.astype(np.float32), ref2, atol=3e-3, rtol=3e-3)
+
+
+def test_dconv_upsample_and_rgb_head():
+    from tests import gpu_util as G
+    rng = np.random.default_rng(4)
+    B, h, w_ = 2, 18, 26
+    x = (rng.standard_normal((B, h, w_, 64)) * 0.5).astype(np.float16)
+    w = (rng.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    up = np.repeat(np.repeat(x.astype(np.float32), 2, axis=1), 2, axis=2)   # nearest x2 (esrgan.cpp:13-16)
+    ref = _conv_ref(up, w, b, act=1)
+    got = G.dconv(G.dev(x), 64, 64, B, 2 * h, 2 * w_, w, b, up2=True, act=1)
+    np.testing.assert_allclose(got.astype(np.float32), ref, atol=4e-3, rtol=4e-3)
+    w3 = (rng.standard_normal((3, 64, 3, 3)) / 24).astype(np.float32)
+    b3 = np.array([0.4, 0.5, 0.6], np.float32)
+    ref3 = _conv_ref(x.astype(np.float32), w3, b3)
+    got3 = G.dconv(G.dev(x), 64, 64, B, h, w_, w3, b3, rgb=True)
+    np.testing.assert_allclose(got3, ref3, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("w,h,fmt", [(256, 256, O.RGB_U8), (300, 260, O.RGBA_U8), (100, 50, O.BGRA_U8), (64, 64, O.ARGB_U8)])
+def test_tiles_in_out(w, h, fmt):
+    """vx_esrgan_tiles_in == image_u8_to_f32 per tile (clamped reads); vx_esrgan_tiles_out == tile_merge of all
+    tiles in order + f32->u8, bit for bit against the oracle."""
+    from tests import gpu_util as G
+    from visioncpp_amd import _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(w + h)
+    B, ch = 2, O._CH[fmt]
+    img = rng.integers(0, 256, (B, h, w, ch), dtype=np.uint8)
+    t = O.tile_layout(w, h, 224, 16, 16)
+    lt = L.TileLayout(*[getattr(t, n) for n, _ in L.TileLayout._fields_])
+    nt = t.n_x * t.n_y
+    out = G.empty(B * nt * t.tile_h * t.tile_w * 32 * 2)
+    L.vx_check(G.api().vx_esrgan_tiles_in(G.dev(img).ptr, B, w, h, fmt, C.byref(lt), out.ptr, None))
+    G.sync()
+    got = out.to_numpy(np.float16, (B, nt, t.tile_h, t.tile_w, 32)).astype(np.float32)
+    for b in range(B):
+        for ti in range(nt):
+            cx, cy = ti % t.n_x, ti // t.n_x
+            off = (cx * (t.tile_w - t.overlap_x), cy * (t.tile_h - t.overlap_y))
+            ref = O.image_u8_to_f32(img[b], fmt, O.RGB_F32, dst_extent=(t.tile_w, t.tile_h), tile_offset=off)
+            np.testing.assert_allclose(got[b, ti, ..., 0:3] + got[b, ti, ..., 3:6], ref, atol=2e-7)
+            assert (got[b, ti, ..., 6:] == 0).all()
+    # merge: random f32 tiles at scale 2
+    ts = O.tile_scale(t, 2)
+    lts = L.TileLayout(*[getattr(ts, n) for n, _ in L.TileLayout._fields_])
+    tiles = rng.random((B, nt, ts.tile_h, ts.tile_w, 3), dtype=np.float32) * 1.2 - 0.1
+    of, ou = G.empty(B * ts.image_h * ts.image_w * 12), G.empty(B * ts.image_h * ts.image_w * 4)
+    L.vx_check(G.api().vx_esrgan_tiles_out(G.dev(tiles).ptr, B, C.byref(lts), of.ptr, ou.ptr, None))
+    G.sync()
+    gf = of.to_numpy(np.float32, (B, ts.image_h, ts.image_w, 3))
+    gu = ou.to_numpy(np.uint8, (B, ts.image_h, ts.image_w, 4))
+    for b in range(B):
+        dst = np.zeros((ts.image_h, ts.image_w, 3), np.float32)
+        for ti in range(nt):
+            O.tile_merge(tiles[b, ti], dst, ti % t.n_x, ti // t.n_x, ts)
+        assert np.array_equal(gf[b], dst)
+        ref_u8 = O.image_f32_to_u8(dst, O.RGB_F32, O.RGBA_U8)
+        assert np.array_equal(gu[b], ref_u8)
+
+
+# ---- whole network through the C ABI ---------------------------------------------------------------------------
+
+from pathlib import Path  # noqa: E402
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def device():
+    from visioncpp_amd.vision import Backend, Device
+    return Device.init(Backend.gpu)
+
+
+def _load(tmp_path_factory, device, cfg, seed):
+    from visioncpp_amd import synth
+    from visioncpp_amd.vision import Arch, Model
+    path = tmp_path_factory.mktemp("esrgan") / f"esrgan_{cfg.name}.gguf"
+    synth.write_esrgan_gguf(path, cfg, seed)
+    m = Model.load(path, device)
+    assert m.arch is Arch.esrgan
+    sd = synth.esrgan_state_dict(cfg, seed)
+    tensors, conv2d = synth.esrgan_gguf_tensors(sd)
+    return m, O.Model(tensors, conv2d, "whcn")
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory, device):
+    from visioncpp_amd import synth
+    return _load(tmp_path_factory, device, synth.ESRGAN_TINY, 7) + (synth.ESRGAN_TINY,)
+
+
+@pytest.fixture(scope="module")
+def x4(tmp_path_factory, device):
+    from visioncpp_amd import synth
+    return _load(tmp_path_factory, device, synth.ESRGAN_X4, 1) + (synth.ESRGAN_X4,)
+
+
+def test_generate_tiny_vs_oracle(tiny):
+    from visioncpp_amd import synth
+    m, om, cfg = tiny
+    info = m.esrgan_info
+    assert (info.scale, info.n_blocks, info.n_filters, info.growth) == (2, 2, 64, 32)
+    imgs = synth.images(3, 40, 56, seed=11).astype(np.float32) / np.float32(255.0)   # [3, 56, 40, 3]
+    got = m.esrgan_generate(imgs)
+    for i in range(3):
+        ref = O.esrgan_generate(om, cfg.scale, cfg.num_blocks, imgs[i])
+        assert np.abs(got[i] - ref).mean() < 1e-3 and np.abs(got[i] - ref).max() < 8e-3
+
+
+def test_generate_matches_reference_torch_fixture(tiny, x4):
+    """The fixtures hold outputs of the reference's own torch RRDBNet (tests/golden/make_golden_esrgan.py)."""
+    from visioncpp_amd import synth
+    for (m, om, cfg), name in ((tiny, "tiny"), (x4, "x4_64")):
+        g = np.load(GOLD / f"esrgan_{name}.npz")
+        size = int(g["size"])
+        img = synth.images(1, size, size, seed=int(g["image_seed"])).astype(np.float32) / np.float32(255.0)
+        y = m.esrgan_generate(img)[0]
+        stride = y.shape[0] // g["result_sample"].shape[0]
+        err = np.abs(y[::stride, ::stride] - g["result_sample"])
+        assert err.mean() < 1e-3 and err.max() < 1e-2, (name, err.mean(), err.max())   # fp16 tolerance: pixel MAE < 1e-3
+
+
+def test_upscale_batch_vs_oracle_compute(tiny):
+    """esrgan_compute (vision.cpp:220-253): tiling 224/16, merge, rgba_u8 -- batched GPU path vs the oracle per image."""
+    from visioncpp_amd import synth
+    from visioncpp_amd.vision import ImageFormat
+    m, om, cfg = tiny
+    for (w, h, fmt, ofmt) in ((300, 260, ImageFormat.rgb_u8, O.RGB_U8), (96, 80, ImageFormat.bgra_u8, O.BGRA_U8)):
+        ch = 3 if fmt is ImageFormat.rgb_u8 else 4
+        rng = np.random.default_rng(w)
+        base = synth.images(2, w, h, seed=w)
+        imgs = base if ch == 3 else np.concatenate([base, rng.integers(0, 256, (2, h, w, 1), dtype=np.uint8)], -1)
+        got = m.upscale_batch(imgs, fmt)
+        assert got.shape == (2, h * cfg.scale, w * cfg.scale, 4) and (got[..., 3] == 255).all()
+        for i in range(2):
+            ref = O.esrgan_compute(om, cfg.scale, cfg.num_blocks, imgs[i], ofmt)
+            d = np.abs(got[i].astype(np.int32) - ref.astype(np.int32))
+            assert d.max() <= 2 and (d > 0).mean() < 0.05, (w, h, d.max(), (d > 0).mean())
+
+
+def test_upscale_x4_batch_properties(x4):
+    """Full 23-block Real-ESRGAN-x4 shape at the BASELINE extent (256^2 -> 1024^2, 2x2 tiles of 144): one image
+    against the oracle; a batch is independent of its neighbours and of the tile grouping."""
+    from visioncpp_amd import synth
+    m, om, cfg = x4
+    imgs = synth.images(3, 256, 256, seed=5)
+    out = m.upscale_batch(imgs)
+    assert out.shape == (3, 1024, 1024, 4)
+    ref = O.esrgan_compute(om, cfg.scale, cfg.num_blocks, imgs[1], O.RGB_U8)
+    d = np.abs(out[1].astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 3 and d.mean() < 0.25, (d.max(), d.mean())
+    single = m.upscale_batch(imgs[1:2])
+    assert np.array_equal(single[0], out[1])
+    m.set_tile_group(5)
+    regroup = m.upscale_batch(imgs)
+    m.set_tile_group(64)
+    assert np.array_equal(regroup, out)
+
+
+def test_c_api_compute_esrgan(tiny):
+    """visp_model_compute family 4 (c-api.cpp:103-106): one image view in, rgba_u8 image at extent*scale out."""
+    from visioncpp_amd import synth
+    from visioncpp_amd.vision import ImageFormat
+    m, om, cfg = tiny
+    img = synth.images(1, 70, 50, seed=9)[0]
+    res = m.compute(img, ImageFormat.rgb_u8)
+    assert res.shape == (100, 140, 4)
+    assert np.array_equal(res, m.upscale_batch(img[None])[0])
+
+
+def test_esrgan_errors(tiny, device, tmp_path):
+    from visioncpp_amd import synth
+    from visioncpp_amd import _lib as L
+    from visioncpp_amd.vision import Arch, ImageFormat, Model
+    import ctypes as C
+    m, _, _ = tiny
+    with pytest.raises(L.Error, match="8-bit colour"):
+        m.upscale_batch(np.zeros((1, 8, 8, 1), np.uint8), ImageFormat.alpha_u8)
+    info = L.DepthAnyInfo()
+    assert L.get_lib().visp_depthany_get_info(m._handle, C.byref(info)) == 0   # wrong family handle is refused
+    assert b"not a depth_anything model" in L.get_lib().visp_get_last_error()
+    bad = tmp_path / "nf48.gguf"
+    synth.write_esrgan_gguf(bad, synth.EsrganConfig(num_filters=48, num_blocks=1, scale=2, gc=16, name="bad"), 0)
+    with pytest.raises(L.Error, match="not built in this backend"):
+        Model.load(bad, device, Arch.esrgan)

@@ -30,6 +30,26 @@ class Timing(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 32), ("ms", c_float), ("launches", c_int32), ("flops", c_double), ("bytes", c_double)]
 
 
+class EsrganInfo(ctypes.Structure):  # == visp_esrgan_info
+    _fields_ = [(n, c_int32) for n in ("scale", "n_blocks", "n_filters", "growth", "tile_group")]
+
+
+class DconvArgs(ctypes.Structure):  # == vx_dconv_args
+    _fields_ = [
+        ("x", c_void_p), ("x_ld", c_int), ("cin", c_int), ("up2", c_int), ("B", c_int), ("H", c_int), ("W", c_int),
+        ("w", c_void_p), ("bias", c_void_p), ("cout", c_int), ("epi", c_int), ("act", c_int),
+        ("s1", c_float), ("res1", c_void_p), ("res1_ld", c_int), ("s2", c_float), ("res2", c_void_p), ("res2_ld", c_int),
+        ("out", c_void_p), ("ldo", c_int),
+    ]
+
+
+class TileLayout(ctypes.Structure):  # == vx_tile_layout
+    _fields_ = [(n, c_int) for n in ("image_w", "image_h", "overlap_x", "overlap_y", "n_x", "n_y", "tile_w", "tile_h")]
+
+
+DC_F16, DC_RGB_F32 = 0, 1
+
+
 class GemmArgs(ctypes.Structure):  # == vx_gemm_args
     _fields_ = [
         ("A", c_void_p), ("lda", c_int64), ("a_group", c_int), ("a_group_stride", c_int), ("a_row_off", c_int),
@@ -60,6 +80,9 @@ C_API_SYMBOLS = [
     "visp_depthany_compute_batch_device", "visp_depthany_compute_batch_host", "visp_depthany_use_graph",
     "visp_depthany_enable_captures", "visp_depthany_read_capture", "visp_depthany_enable_timing",
     "visp_depthany_read_timing",
+    "visp_esrgan_get_info", "visp_esrgan_set_tile_group", "visp_esrgan_weights_arena", "visp_esrgan_weights_ready",
+    "visp_esrgan_tile_layout", "visp_esrgan_compute_batch_device", "visp_esrgan_compute_batch_host",
+    "visp_esrgan_generate_host", "visp_esrgan_enable_timing", "visp_esrgan_read_timing",
 ]
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
@@ -69,6 +92,7 @@ KERNEL_SYMBOLS = [
     "vx_attention_f16",
     "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
+    "vx_dconv3x3_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
 ]
 
 
@@ -121,6 +145,16 @@ def init() -> ctypes.CDLL:
     lib.visp_depthany_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
     lib.visp_depthany_enable_timing.argtypes = [c_void_p, c_int32]
     lib.visp_depthany_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
+    lib.visp_esrgan_get_info.argtypes = [c_void_p, POINTER(EsrganInfo)]
+    lib.visp_esrgan_set_tile_group.argtypes = [c_void_p, c_int32]
+    lib.visp_esrgan_weights_arena.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]
+    lib.visp_esrgan_weights_ready.argtypes = [c_void_p]
+    lib.visp_esrgan_tile_layout.argtypes = [c_int32, c_int32, c_int32, POINTER(c_int32)]
+    lib.visp_esrgan_compute_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.visp_esrgan_compute_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]
+    lib.visp_esrgan_generate_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
+    lib.visp_esrgan_enable_timing.argtypes = [c_void_p, c_int32]
+    lib.visp_esrgan_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
     for name in C_API_SYMBOLS[15:]:
         getattr(lib, name).restype = c_int32
 
@@ -156,6 +190,9 @@ def init() -> ctypes.CDLL:
     lib.vx_head_out_f32.argtypes = [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_int, c_void_p]
     lib.vx_minmax_normalize.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
     lib.vx_f32_to_u8.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    lib.vx_dconv3x3_f16.argtypes = [POINTER(DconvArgs), c_void_p]
+    lib.vx_esrgan_tiles_in.argtypes = [c_void_p, c_int, c_int, c_int, c_int, POINTER(TileLayout), c_void_p, c_void_p]
+    lib.vx_esrgan_tiles_out.argtypes = [c_void_p, c_int, POINTER(TileLayout), c_void_p, c_void_p, c_void_p]
     for name in KERNEL_SYMBOLS[1:]:
         getattr(lib, name).restype = c_int
     return lib

@@ -10,6 +10,7 @@
 
 #include "../../include/visp_hip_kernels.h"
 #include "depthany.h"
+#include "esrgan.h"
 #include "visp_util.h"
 
 using namespace visp;
@@ -38,14 +39,23 @@ int32_t handle_errors(F&& f) {
     return 1;
 }
 
-depthany_model& as_depthany(visp_model* m) {
+int32_t family_of(visp_model const* m) {
     if (!m) throw except("model handle is null");
-    return *reinterpret_cast<depthany_model*>(m);
+    return reinterpret_cast<model_base const*>(m)->family;
+}
+depthany_model& as_depthany(visp_model* m) {
+    if (family_of(m) != VISP_DEPTH_ANYTHING) throw except("model handle is not a depth_anything model (family %d)", family_of(m));
+    return *static_cast<depthany_model*>(reinterpret_cast<model_base*>(m));
 }
 depthany_model const& as_depthany(visp_model const* m) {
-    if (!m) throw except("model handle is null");
-    return *reinterpret_cast<depthany_model const*>(m);
+    if (family_of(m) != VISP_DEPTH_ANYTHING) throw except("model handle is not a depth_anything model (family %d)", family_of(m));
+    return *static_cast<depthany_model const*>(reinterpret_cast<model_base const*>(m));
 }
+esrgan_model& as_esrgan(visp_model* m) {
+    if (family_of(m) != VISP_ESRGAN) throw except("model handle is not an esrgan model (family %d)", family_of(m));
+    return *static_cast<esrgan_model*>(reinterpret_cast<model_base*>(m));
+}
+visp_model* handle_of(model_base* m) { return reinterpret_cast<visp_model*>(m); }
 
 int32_t detect_family(model_file const& file) { // reference vision.cpp:7-21
     std::string_view arch = file.arch();
@@ -57,10 +67,21 @@ int32_t detect_family(model_file const& file) { // reference vision.cpp:7-21
     return VISP_FAMILY_COUNT;
 }
 
-void require_depth_anything(int32_t family) {
+void require_built(int32_t family) {
     if (family < 0 || family >= VISP_FAMILY_COUNT) throw except("Unsupported model family");
-    if (family != VISP_DEPTH_ANYTHING)
-        throw except("Model family %d is not built in this backend (MI355X backend implements depth_anything)", family);
+    if (family != VISP_DEPTH_ANYTHING && family != VISP_ESRGAN)
+        throw except("Model family %d is not built in this backend (MI355X backend implements depth_anything and esrgan)", family);
+}
+
+void return_image(image_data&& img, visp_image_view* out_image, visp_image_data** out_data) {
+    auto* owned = new visp_image_data;
+    static_cast<image_data&>(*owned) = std::move(img);
+    *out_data = owned;
+    out_image->width = owned->extent[0];
+    out_image->height = owned->extent[1];
+    out_image->stride = owned->extent[0] * n_bytes(owned->format);
+    out_image->format = int32_t(owned->format);
+    out_image->data = owned->data.get();
 }
 
 } // namespace
@@ -108,8 +129,9 @@ int32_t visp_model_load_ex(char const* filepath, visp_device const* dev, int32_t
             model_file file = model_load(filepath, true);
             family = detect_family(file);
         }
-        require_depth_anything(family);
-        *out = reinterpret_cast<visp_model*>(depthany_load_model(filepath, *dev, flags));
+        require_built(family);
+        if (family == VISP_ESRGAN) *out = handle_of(esrgan_load_model(filepath, *dev, flags));
+        else *out = handle_of(depthany_load_model(filepath, *dev, flags));
     });
 }
 
@@ -118,31 +140,33 @@ int32_t visp_model_load(char const* filepath, visp_device const* dev, int32_t ar
 }
 
 void visp_model_destroy(visp_model* model, int32_t arch) {
-    if (arch == VISP_DEPTH_ANYTHING) delete reinterpret_cast<depthany_model*>(model);
+    if (!model) return;
+    // the handle carries its own family; `arch` is what the reference's destroy switch uses (c-api.cpp:224-229)
+    model_base* base = reinterpret_cast<model_base*>(model);
+    (void)arch;
+    if (base->family == VISP_DEPTH_ANYTHING) delete static_cast<depthany_model*>(base);
+    else if (base->family == VISP_ESRGAN) delete static_cast<esrgan_model*>(base);
 }
 
 int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* inputs, int32_t n_inputs, int32_t*, int32_t,
                            visp_image_view* out_image, visp_image_data** out_data) {
     return handle_errors([&]() {
-        require_depth_anything(family);
+        require_built(family);
+        if (family_of(model) != family) throw except("model handle belongs to family %d, not %d", family_of(model), family);
         if (n_inputs != 1) throw except("Expected %d input images, but got %d.", 1, n_inputs);
         image_view in;
         in.extent = {{inputs[0].width, inputs[0].height}};
         in.stride = inputs[0].stride;
         in.format = image_format(inputs[0].format);
         in.data = inputs[0].data;
+        if (family == VISP_ESRGAN) { // model_funcs<esrgan>::compute (reference c-api.cpp:103-106)
+            return_image(esrgan_compute(as_esrgan(model), in), out_image, out_data);
+            return;
+        }
         // model_funcs<depth_anything>::compute (reference c-api.cpp:72-77)
         image_data result_f32 = depthany_compute(as_depthany(model), in);
         image_data normalized = image_normalize(view_of(result_f32));
-        image_data u8 = image_f32_to_u8(view_of(normalized), image_format::alpha_u8);
-        auto* owned = new visp_image_data;
-        static_cast<image_data&>(*owned) = std::move(u8);
-        *out_data = owned;
-        out_image->width = owned->extent[0];
-        out_image->height = owned->extent[1];
-        out_image->stride = owned->extent[0] * n_bytes(owned->format);
-        out_image->format = int32_t(owned->format);
-        out_image->data = owned->data.get();
+        return_image(image_f32_to_u8(view_of(normalized), image_format::alpha_u8), out_image, out_data);
     });
 }
 
@@ -249,6 +273,89 @@ int32_t visp_depthany_read_timing(visp_model* m, visp_timing* out, int32_t cap, 
         depthany_model& dm = as_depthany(m);
         int32_t count = 0;
         for (timing_entry const& t : dm.last_timing) {
+            if (count >= cap) break;
+            snprintf(out[count].name, sizeof out[count].name, "%s", t.name.c_str());
+            out[count].ms = t.ms;
+            out[count].launches = t.launches;
+            out[count].flops = t.flops;
+            out[count].bytes = t.bytes;
+            ++count;
+        }
+        *n = count;
+    });
+}
+
+// ---- ESRGAN extension ----------------------------------------------------------------------
+
+int32_t visp_esrgan_get_info(visp_model const* m, visp_esrgan_info* out) {
+    return handle_errors([&]() {
+        esrgan_model const& em = as_esrgan(const_cast<visp_model*>(m));
+        out->scale = em.params.scale;
+        out->n_blocks = em.params.n_blocks;
+        out->n_filters = em.weights.nf;
+        out->growth = em.weights.gc;
+        out->tile_group = em.tile_group;
+    });
+}
+
+int32_t visp_esrgan_set_tile_group(visp_model* m, int32_t tiles) {
+    return handle_errors([&]() {
+        if (tiles < 1) throw except("esrgan: tile group must be >= 1");
+        as_esrgan(m).tile_group = tiles;
+    });
+}
+
+int32_t visp_esrgan_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes) {
+    return handle_errors([&]() {
+        esrgan_model& em = as_esrgan(m);
+        *device_ptr = em.weight_arena.ptr;
+        *n_bytes = em.weight_arena.bytes;
+    });
+}
+
+int32_t visp_esrgan_weights_ready(visp_model* m) {
+    return handle_errors([&]() { esrgan_weights_ready(as_esrgan(m)); });
+}
+
+int32_t visp_esrgan_tile_layout(int32_t w, int32_t h, int32_t scale, int32_t out8[8]) {
+    return handle_errors([&]() {
+        tile_layout t = tile_scale(tile_layout({{w, h}}, 224, 16), scale);
+        int32_t v[8] = {t.image_extent[0], t.image_extent[1], t.overlap[0], t.overlap[1], t.n_tiles[0], t.n_tiles[1], t.tile_size[0], t.tile_size[1]};
+        memcpy(out8, v, sizeof v);
+    });
+}
+
+int32_t visp_esrgan_compute_batch_device(visp_model* m, void const* img, int32_t batch, int32_t w, int32_t h, int32_t format, void* out_rgba,
+                                         void* stream) {
+    return handle_errors([&]() {
+        if (!img || !out_rgba) throw except("esrgan: null input/output pointer");
+        esrgan_compute_batch_device(as_esrgan(m), img, batch, w, h, image_format(format), out_rgba, stream);
+    });
+}
+
+int32_t visp_esrgan_compute_batch_host(visp_model* m, uint8_t const* img, int32_t batch, int32_t w, int32_t h, int32_t format, uint8_t* out_rgba) {
+    return handle_errors([&]() {
+        if (!img || !out_rgba) throw except("esrgan: null input/output pointer");
+        esrgan_compute_batch_host(as_esrgan(m), img, batch, w, h, image_format(format), out_rgba);
+    });
+}
+
+int32_t visp_esrgan_generate_host(visp_model* m, float const* rgb, int32_t n, int32_t w, int32_t h, float* out) {
+    return handle_errors([&]() {
+        if (!rgb || !out) throw except("esrgan: null input/output pointer");
+        esrgan_generate_host(as_esrgan(m), rgb, n, w, h, out);
+    });
+}
+
+int32_t visp_esrgan_enable_timing(visp_model* m, int32_t enable) {
+    return handle_errors([&]() { as_esrgan(m).timing = enable != 0; });
+}
+
+int32_t visp_esrgan_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n) {
+    return handle_errors([&]() {
+        esrgan_model& em = as_esrgan(m);
+        int32_t count = 0;
+        for (timing_entry const& t : em.last_timing) {
             if (count >= cap) break;
             snprintf(out[count].name, sizeof out[count].name, "%s", t.name.c_str());
             out[count].ms = t.ms;

@@ -92,7 +92,15 @@ struct depthany_workspace {
     void* graph_exec = nullptr;
 };
 
-struct depthany_model { // vision.h:339-347 counterpart
+// every model handle starts with its family (the C ABI's handles are untyped: c-api.cpp:193 any_model)
+enum model_family_id : int32_t { family_sam = 0, family_birefnet, family_depth_anything, family_migan, family_esrgan, family_count };
+struct model_base {
+    int32_t family;
+    explicit model_base(int32_t f) : family(f) {}
+};
+
+struct depthany_model : model_base { // vision.h:339-347 counterpart
+    depthany_model() : model_base(family_depth_anything) {}
     backend_device const* backend = nullptr;
     depthany_params params;
     depthany_weights weights;

@@ -108,7 +108,10 @@ class Model:
         try:
             n = out_view.height * out_view.stride
             buf = (ctypes.c_uint8 * n).from_address(out_view.data)
-            res = np.frombuffer(buf, np.uint8).reshape(out_view.height, out_view.width).copy()
+            ch = out_view.stride // max(1, out_view.width)
+            res = np.frombuffer(buf, np.uint8).reshape(out_view.height, out_view.width, ch).copy()
+            if ch == 1:
+                res = res[..., 0]
         finally:
             self._api.visp_image_destroy(out_data)
         return res
@@ -127,11 +130,13 @@ class Model:
 
     def weights_arena(self):
         p, n = c_void_p(), c_size_t()
-        check(self._api.visp_depthany_weights_arena(self._handle, byref(p), byref(n)))
+        f = self._api.visp_esrgan_weights_arena if self.arch is Arch.esrgan else self._api.visp_depthany_weights_arena
+        check(f(self._handle, byref(p), byref(n)))
         return p.value, n.value
 
     def weights_ready(self):
-        check(self._api.visp_depthany_weights_ready(self._handle))
+        f = self._api.visp_esrgan_weights_ready if self.arch is Arch.esrgan else self._api.visp_depthany_weights_ready
+        check(f(self._handle))
 
     def reserve(self, batch: int, w: int, h: int):
         check(self._api.visp_depthany_reserve(self._handle, batch, w, h))
@@ -168,13 +173,56 @@ class Model:
         return out.reshape(dims)
 
     def enable_timing(self, enable: bool = True):
-        check(self._api.visp_depthany_enable_timing(self._handle, int(enable)))
+        f = self._api.visp_esrgan_enable_timing if self.arch is Arch.esrgan else self._api.visp_depthany_enable_timing
+        check(f(self._handle, int(enable)))
 
     def read_timing(self):
         arr, n = (lib.Timing * 64)(), c_int32()
-        check(self._api.visp_depthany_read_timing(self._handle, arr, 64, byref(n)))
+        f = self._api.visp_esrgan_read_timing if self.arch is Arch.esrgan else self._api.visp_depthany_read_timing
+        check(f(self._handle, arr, 64, byref(n)))
         return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches, flops=arr[i].flops, bytes=arr[i].bytes)
                 for i in range(n.value)]
+
+
+    # ---- ESRGAN (family 4): batched extension
+    @property
+    def esrgan_info(self) -> lib.EsrganInfo:
+        i = lib.EsrganInfo()
+        check(self._api.visp_esrgan_get_info(self._handle, byref(i)))
+        return i
+
+    def set_tile_group(self, tiles: int):
+        check(self._api.visp_esrgan_set_tile_group(self._handle, tiles))
+
+    def upscale_batch(self, images: np.ndarray, format: ImageFormat = ImageFormat.rgb_u8) -> np.ndarray:
+        """images: uint8 [B, h, w, C] on the host -> rgba uint8 [B, h*scale, w*scale, 4] (esrgan_compute per image)."""
+        imgs = np.ascontiguousarray(images, dtype=np.uint8)
+        b, h, w, c = imgs.shape
+        assert c == _CHANNELS[format.value]
+        s = self.esrgan_info.scale
+        out = np.empty((b, h * s, w * s, 4), np.uint8)
+        check(self._api.visp_esrgan_compute_batch_host(self._handle, imgs.ctypes.data, b, w, h, format.value, out.ctypes.data))
+        return out
+
+    def upscale_batch_device(self, img_dev: int, batch: int, w: int, h: int, out_dev: int, format: ImageFormat = ImageFormat.rgb_u8,
+                             stream: int | None = None):
+        check(self._api.visp_esrgan_compute_batch_device(self._handle, img_dev, batch, w, h, format.value, out_dev, stream))
+
+    def esrgan_generate(self, tiles: np.ndarray) -> np.ndarray:
+        """rgb float32 tiles [n, h, w, 3] -> [n, h*scale, w*scale, 3] (esrgan_generate, no tiling / u8 conversion)."""
+        t = np.ascontiguousarray(tiles, dtype=np.float32)
+        n, h, w, c = t.shape
+        assert c == 3
+        s = self.esrgan_info.scale
+        out = np.empty((n, h * s, w * s, 3), np.float32)
+        check(self._api.visp_esrgan_generate_host(self._handle, t.ctypes.data, n, w, h, out.ctypes.data))
+        return out
+
+
+def esrgan_tile_layout(w: int, h: int, scale: int = 1) -> dict:
+    v = (c_int32 * 8)()
+    check(get_lib().visp_esrgan_tile_layout(w, h, scale, v))
+    return dict(zip(("image_w", "image_h", "overlap_x", "overlap_y", "n_x", "n_y", "tile_w", "tile_h"), [int(x) for x in v]))
 
 
 class DeviceBuffer:
