@@ -118,9 +118,11 @@ VX_API int vx_conv3x3_f16(const vx_gemm_args* args, void* stream);
  * keeps [x|x1|x2|x3|x4] in one 192-wide row, so concat (esrgan.cpp:29-36) is never materialised) and writes
  * `cout` channels at out (pixel stride ldo; the channel-slice offset is folded into the pointer).
  *   v = conv(x) + bias;  act: v = max(v, 0.2 v);  res1: v = v*s1 + res1;  res2: v = v*s2 + res2.
+ *   x_residual (cout = 64): v = v*s1 + x[:, 0:64] with x taken from the halo already in LDS (no second read of x);
+ *   mutually exclusive with res1, res2 still applies afterwards.
  * up2: the source is [B, H/2, W/2, x_ld] and is nearest-upsampled on the fly (esrgan.cpp:13-19).
  * w: packed by the host as [cin/32][9 taps][cout][32] f16 with the four 16-byte groups of every (tap, n) row
- *    stored at position g ^ ((n >> 2) & 3)  (see pack_dconv_weights in csrc/esrgan.cpp).
+ *    stored at position g ^ ((n >> 2) & 3)  (see packer::conv in csrc/esrgan.cpp).
  * VX_DC_RGB_F32: cout = 32 (3 real), out = f32 [B, H, W, 3], no activation / residuals. */
 enum { VX_DC_F16 = 0, VX_DC_RGB_F32 = 1 };
 typedef struct {
@@ -131,6 +133,7 @@ typedef struct {
     float s1; const void* res1; int res1_ld;
     float s2; const void* res2; int res2_ld;
     void* out; int ldo;
+    int x_residual;
 } vx_dconv_args;
 VX_API int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream);
 

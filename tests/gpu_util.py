@@ -109,7 +109,7 @@ def pack_dconv(w: np.ndarray, cin_pad: int | None = None, cout_pad: int | None =
 
 
 def dconv(x_dev, x_ld, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=0, out=None, ldo=None, out_off=0,
-          res1=None, res1_ld=0, s1=1.0, res2=None, res2_ld=0, s2=1.0, rgb=False, cin_pad=None):
+          res1=None, res1_ld=0, s1=1.0, res2=None, res2_ld=0, s2=1.0, rgb=False, cin_pad=None, x_residual=False):
     """Launches vx_dconv3x3_f16; returns the output as numpy (f16 [B,H,W,ldo] or f32 [B,H,W,3])."""
     cout = w.shape[0]
     cop = -(-cout // 32) * 32
@@ -129,6 +129,7 @@ def dconv(x_dev, x_ld, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=0, o
     a.s1, a.res1, a.res1_ld = s1, (res1.ptr if res1 else None), res1_ld
     a.s2, a.res2, a.res2_ld = s2, (res2.ptr if res2 else None), res2_ld
     a.out, a.ldo = ob.ptr + out_off * 2, ldo
+    a.x_residual = int(x_residual)
     L.vx_check(api().vx_dconv3x3_f16(C.byref(a), None))
     sync()
     if rgb:

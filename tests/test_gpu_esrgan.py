@@ -63,6 +63,11 @@ def test_dconv_scaled_residuals():
     got2 = G.dconv(xd, 192, 192, B, H, W, w, b, res1=xd, res1_ld=192, s1=0.2, res2=r2d, res2_ld=64, s2=0.2)
     ref2 = (y * 0.2 + buf[..., :64].astype(np.float32)) * 0.2 + r2.astype(np.float32)
     np.testing.assert_allclose(got2.astype(np.float32), ref2, atol=3e-3, rtol=3e-3)
+    # the same through the identity fold (x taken from the halo in LDS instead of a second read)
+    got3 = G.dconv(xd, 192, 192, B, H, W, w, b, x_residual=True, s1=0.2)
+    np.testing.assert_allclose(got3.astype(np.float32), y * 0.2 + buf[..., :64].astype(np.float32), atol=3e-3, rtol=3e-3)
+    got4 = G.dconv(xd, 192, 192, B, H, W, w, b, x_residual=True, s1=0.2, res2=r2d, res2_ld=64, s2=0.2)
+    np.testing.assert_allclose(got4.astype(np.float32), ref2, atol=3e-3, rtol=3e-3)
 
 
 def test_dconv_upsample_and_rgb_head():

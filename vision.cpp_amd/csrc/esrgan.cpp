@@ -278,7 +278,7 @@ struct exec {
     }
 
     struct opts {
-        bool up2 = false, lrelu = false, rgb = false;
+        bool up2 = false, lrelu = false, rgb = false, x_residual = false;
         float s1 = 1, s2 = 1;
         const void* res1 = nullptr; int res1_ld = 0;
         const void* res2 = nullptr; int res2_ld = 0;
@@ -291,10 +291,11 @@ struct exec {
         a.B = n; a.H = H; a.W = W;
         a.w = wa + g.w; a.bias = reinterpret_cast<const float*>(wa + g.b); a.cout = g.cout;
         a.epi = o.rgb ? VX_DC_RGB_F32 : VX_DC_F16;
-        a.act = o.lrelu;
+        a.act = o.lrelu | (getenv("VISP_DCONV_DBG") ? atoi(getenv("VISP_DCONV_DBG")) << 4 : 0);
         a.s1 = o.s1; a.res1 = o.res1; a.res1_ld = o.res1_ld;
         a.s2 = o.s2; a.res2 = o.res2; a.res2_ld = o.res2_ld;
         a.out = out; a.ldo = ldo;
+        a.x_residual = o.x_residual;
         const double px = (double)n * H * W;
         mark(group, 2.0 * px * 9 * g.cin_real * g.cout_real,
              px * (o.up2 ? 0.25 : 1.0) * cin * 2 + px * (o.rgb ? 12 : g.cout * 2) + (o.res1 ? px * g.cout * 2 : 0) + (o.res2 ? px * g.cout * 2 : 0));
@@ -318,10 +319,11 @@ struct exec {
                 for (int k = 0; k < 4; ++k) {
                     opts o;
                     o.lrelu = true;
-                    conv(blk[r][k], src[r], LD, 64 + 32 * k, n, h, w, sl(src[r], 64 + 32 * k), LD, o, "rdb_conv1-4");
+                    static const char* const names[4] = {"rdb_conv1", "rdb_conv2", "rdb_conv3", "rdb_conv4"};
+                    conv(blk[r][k], src[r], LD, 64 + 32 * k, n, h, w, sl(src[r], 64 + 32 * k), LD, o, names[k]);
                 }
                 opts o;
-                o.s1 = 0.2f; o.res1 = src[r]; o.res1_ld = LD;
+                o.s1 = 0.2f; o.x_residual = true; // x5*0.2 + x, x = channels 0..63 of the halo the conv already holds
                 if (r == 2) { o.s2 = 0.2f; o.res2 = A; o.res2_ld = LD; }
                 conv(blk[r][4], src[r], LD, 192, n, h, w, dst[r], LD, o, "rdb_conv5");
             }

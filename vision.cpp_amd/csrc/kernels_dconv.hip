@@ -20,30 +20,56 @@
 //  * the RGB head (Cout = 3 padded to 32) writes f32 straight from the accumulators.
 #include "vx_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __attribute__((aligned(16))) unsigned char g_dconv_zero_page[64];
+// out-of-map lanes of an edge tile store here (one KiB per wave) instead of being masked off, so every wave issues
+// the same number of store instructions per tile and the ring can wait with a COUNTED vmcnt that leaves the
+// stores in flight
+constexpr int TRASH_BLOCKS = 1024;
+__device__ __attribute__((aligned(16))) unsigned char g_dconv_trash[TRASH_BLOCKS * 8 * 1024];
 
 constexpr int CK = 32;      // channels per chunk
 constexpr int PIXB = CK * 2; // bytes per pixel per chunk
 constexpr int NW = 8;       // waves per block
 
-template <int COUT, int MT, int TW, int EPI>
+// tile enumeration of one H x W map: 16x32 tiles over the columns that fill whole 32-wide tiles, and -- when the
+// remainder is 1..16 columns -- a strip of 32x16 tiles for it (same 512 pixels and the same 612-pixel halo,
+// transposed), so a 144-wide ESRGAN tile costs 41 blocks instead of 45.
+struct tile_grid {
+    int ncols, nrows, n_main, n_strip, strip_x0;
+    __host__ __device__ tile_grid(int H, int W) {
+        const int q = W / 32, rem = W % 32;
+        const bool strip = rem > 0 && rem <= 16;
+        ncols = q + ((rem > 16) ? 1 : 0);
+        nrows = (H + 15) / 16;
+        n_main = ncols * nrows;
+        n_strip = strip ? (H + 31) / 32 : 0;
+        strip_x0 = q * 32;
+    }
+    __host__ __device__ int total() const { return n_main + n_strip; }
+};
+
+template <int COUT, int EPI>
 __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
-    constexpr int TH = NW * MT * 32 / TW;
-    constexpr int HH = TH + 2, HW = TW + 2, HALO_PIX = HH * HW;
+    constexpr int MT = 2;                       // M-tiles (32 pixels) per wave
+    constexpr int HALO_PIX = 18 * 34;           // both tile shapes
+    // a stage holds [pixel][64 B] (the chunk's 32 channels) with the four 16-byte groups XOR-swizzled by
+    // (pixel >> 2) & 3: 16 consecutive pixels cover all 64 banks, and a pixel is ONE 64-byte global segment for the
+    // LDS-DMA (two 32-byte k-step planes would need one address register set less but double the number of
+    // cache-line requests per byte: measured 15-25 % slower)
     constexpr int HALO_INSTR = (HALO_PIX * 4 + 63) / 64, HALO_BYTES = HALO_INSTR * 1024;
     constexpr int NI = COUT / 32;
     constexpr int W_BYTES = 9 * COUT * PIXB, W_INSTR = W_BYTES / 1024;
     constexpr int HJ = (HALO_INSTR + NW - 1) / NW, WJ = (W_INSTR + NW - 1) / NW;
-    constexpr int W_BASE = 2 * HALO_BYTES;
+    constexpr int W_BASE = 2 * HALO_BYTES;      // LDS: [halo 0 | halo 1 | slab 0 | slab 1 | bias]
     constexpr int BIAS_BASE = W_BASE + 2 * W_BYTES;
     constexpr int NCH16 = COUT / 8, PITCH = COUT * 2;
-    static_assert(TH * TW == NW * MT * 32, "tile does not split into whole M-tiles");
-    static_assert(TH * TW * PITCH <= W_BASE + 2 * W_BYTES, "output staging does not fit");
+    static_assert(256 * PITCH <= HALO_BYTES && 256 * PITCH <= W_BYTES + (COUT == 32 ? HALO_BYTES : 0), "output staging does not fit a stage");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* const s_bias = reinterpret_cast<float*>(smem + BIAS_BASE);
@@ -52,212 +78,358 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int H = p.H, W = p.W;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const tile_grid tg(H, W);
+    const int per_image = tg.total();
+    const int total = p.B * per_image;
 
-    // XCD-aware order: blocks id and id+8 share an L2; give each XCD a contiguous run of tiles so neighbouring
-    // tiles (which share halo rows) and one image's slabs meet in one L2.
-    int tile;
+    // persistent blocks; XCD-aware order: blocks id and id+8 share an L2. Every XCD owns a contiguous run of the
+    // tile sequence (neighbouring tiles share halo rows, one image's tiles share their slabs) and its blocks walk
+    // that run with a stride of the XCD's block count.
+    int t_next, t_end, t_step;
     {
-        const int total = gridDim.x, id = blockIdx.x;
-        const int per = total >> 3, rem = total & 7, xcd = id & 7;
-        tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (id >> 3);
+        const int id = blockIdx.x, xcd = id & 7;
+        const int per = total >> 3, rem = total & 7;
+        const int lo = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
+        t_end = lo + per + (xcd < rem ? 1 : 0);
+        t_step = ((int)gridDim.x - xcd + 7) >> 3;
+        t_next = lo + (id >> 3);
     }
-    const int b = tile / (tiles_x * tiles_y), trem = tile - b * (tiles_x * tiles_y);
-    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
+    if (t_next >= t_end) return;
 
     if (tid < COUT) s_bias[tid] = p.bias ? p.bias[tid] : 0.0f;
 
-    // ---- per-lane halo source addresses (chunk 0); later chunks add c*32 channels
     const int up = p.up2 ? 1 : 0;
     const int Hs = H >> up, Ws = W >> up;
-    const f16* __restrict__ X = reinterpret_cast<const f16*>(p.x) + (long)b * Hs * Ws * p.x_ld;
-    const f16* hsrc[HJ];
-    int hstep[HJ];
-#pragma unroll
-    for (int j = 0; j < HJ; ++j) {
-        const int i = wave + j * NW;
-        const int L = i * 64 + lane;
-        const int pix = L >> 2, phys = L & 3;
-        const int hy = pix / HW, hx = pix - hy * HW;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        const bool valid = pix < HALO_PIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        hsrc[j] = valid ? X + ((long)(iy >> up) * Ws + (ix >> up)) * p.x_ld + ((phys ^ ((pix >> 2) & 3)) << 3)
-                        : reinterpret_cast<const f16*>(g_dconv_zero_page);
-        hstep[j] = valid ? CK : 0;
-    }
-    const f16* __restrict__ Wg = reinterpret_cast<const f16*>(p.w) + lane * 8;
+    const int nch = p.cin / CK;
+    const int nch_total_bytes = nch * 9 * COUT * PIXB;
 
+    // ---- tile geometry (wave-uniform) and per-lane halo sources
+    struct geom { int b, y0, x0, tws; }; // tws = log2(tile width): 5 (16x32) or 4 (32x16)
+    auto locate = [&](int t) {
+        geom g;
+        g.b = t / per_image;
+        const int k = t - g.b * per_image;
+        if (k < tg.n_main) {
+            const int ty = k / tg.ncols;
+            g.y0 = ty * 16; g.x0 = (k - ty * tg.ncols) * 32; g.tws = 5;
+        } else {
+            g.y0 = (k - tg.n_main) * 32; g.x0 = tg.strip_x0; g.tws = 4;
+        }
+        return g;
+    };
+    // Both streams go through buffer_load ... lds: the descriptor (base, size) sits in SGPRs, a lane contributes a
+    // 32-bit byte offset and the chunk a scalar offset, so no 64-bit per-lane pointers stay live across the tile
+    // loop; halo pixels outside the map use an offset beyond the descriptor's size and are zero-filled by the
+    // hardware's range check (conv zero padding, nn.cpp:83-97 pad = 1).
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned hoff[HJ];  // byte offset of the lane's 16 bytes (chunk 0) inside the current image
+    unsigned hpack[HJ]; // shape-dependent, tile-invariant part: halo row | halo col << 8 | swizzled group << 16 | valid << 24
+    auto setup_shape_src = [&](int tws) {
+        const int hw = (1 << tws) + 2;
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+            const int L = (wave + j * NW) * 64 + lane;
+            const int pix = L >> 2, phys = L & 3;
+            const int hy = tws == 5 ? pix / 34 : pix / 18;
+            const int hx = pix - hy * hw;
+            hpack[j] = (unsigned)hy | (unsigned)hx << 8 | (unsigned)(phys ^ ((pix >> 2) & 3)) << 16 | (pix < HALO_PIX ? 1u << 24 : 0u);
+        }
+    };
+    __amdgpu_buffer_rsrc_t x_rsrc;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, nch_total_bytes, 0x00020000);
+    auto setup_src = [&](const geom& g) {
+        const long img_bytes = (long)Hs * Ws * p.x_ld * 2;
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + g.b * img_bytes, 0, (int)img_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+            unsigned pk = hpack[j];
+            asm volatile("" : "+v"(pk)); // keep the unpacked fields out of registers across the tile loop
+            const int iy = g.y0 - 1 + (int)(pk & 0xff), ix = g.x0 - 1 + (int)((pk >> 8) & 0xff);
+            const bool valid = (pk >> 24) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int e = ((iy >> up) * Ws + (ix >> up)) * p.x_ld + (int)(((pk >> 16) & 3) << 3);
+            hoff[j] = valid ? (unsigned)(e * 2) : OOB;
+        }
+    };
+    const int dbg = p.act >> 4; // TEMP ablation: 1 = no halo DMA, 2 = no slab DMA, 4 = no MFMA
     auto issue = [&](int c, int stage) {
 #pragma unroll
         for (int j = 0; j < HJ; ++j) {
             const int i = wave + j * NW;
-            if (i < HALO_INSTR)
-                __builtin_amdgcn_global_load_lds((gptr_t)(hsrc[j] + c * hstep[j]), (lptr_t)(smem + stage * HALO_BYTES + i * 1024), 16, 0, 0);
+            if (i < HALO_INSTR && !(dbg & 1))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + stage * HALO_BYTES + i * 1024), 16, hoff[j], c * (CK * 2), 0, 0);
         }
-        const f16* wc = Wg + (long)c * (W_BYTES / 2);
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const int i = wave + j * NW;
-            if (i < W_INSTR)
-                __builtin_amdgcn_global_load_lds((gptr_t)(wc + i * 512), (lptr_t)(smem + W_BASE + stage * W_BYTES + i * 1024), 16, 0, 0);
+            if (i < W_INSTR && !(dbg & 2))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem + W_BASE + stage * W_BYTES + i * 1024), 16, lane * 16, c * W_BYTES + i * 1024, 0, 0);
         }
     };
 
-    // ---- chunk-invariant fragment addresses
+    // ---- fragment addresses: chunk-invariant, depend on the tile shape only
     int a_addr[9][MT][2];
+    auto setup_addr = [&](int tws) {
+        const int hw = (1 << tws) + 2;
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        const int f = (wave * MT + mi) * 32 + r;
-        const int trow = f / TW, tcol = f - trow * TW;
+        for (int mi = 0; mi < MT; ++mi) {
+            const int f = (wave * MT + mi) * 32 + r;
+            const int trow = f >> tws, tcol = f & ((1 << tws) - 1);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int pix = (trow + tap / 3) * HW + tcol + tap % 3;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int pix = (trow + tap / 3) * hw + tcol + tap % 3;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a_addr[tap][mi][ks] = pix * PIXB + (((ks * 2 + h) ^ ((pix >> 2) & 3)) << 4);
+                for (int ks = 0; ks < 2; ++ks) a_addr[tap][mi][ks] = pix * PIXB + (((ks * 2 + h) ^ ((pix >> 2) & 3)) << 4);
+            }
         }
-    }
-    int w_addr[2];
+    };
+    int w_addr[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) w_addr[ks] = W_BASE + r * PIXB + (((ks * 2 + h) ^ ((r >> 2) & 3)) << 4);
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w_addr[st][ks] = W_BASE + st * W_BYTES + r * PIXB + (((ks * 2 + h) ^ ((r >> 2) & 3)) << 4);
 
     f32x16 acc[MT][NI];
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
-    auto load_tap = [&](int stage, int tap, f16x8 (&af)[MT][2], f16x8 (&wf)[NI][2]) {
+    // fragments are prefetched one GROUP of k-steps ahead (register double buffer): a whole tap (2 k-steps) for
+    // COUT = 32, one k-step for COUT = 64 where the accumulators leave fewer registers
+    constexpr int G = COUT == 32 ? 2 : 1;
+    auto load_group = [&](auto stage_c, int grp, f16x8 (&af)[G][MT], f16x8 (&wf)[G][NI]) {
+        constexpr int S = decltype(stage_c)::value;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int q = 0; q < G; ++q) {
+            const int step = grp * G + q, tap = step >> 1, ks = step & 1;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                wf[ni][ks] = *reinterpret_cast<const f16x8*>(smem + w_addr[ks] + stage * W_BYTES + (tap * COUT + ni * 32) * PIXB);
+                wf[q][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[S][ks] + (tap * COUT + ni * 32) * PIXB);
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
-                af[mi][ks] = *reinterpret_cast<const f16x8*>(smem + a_addr[tap][mi][ks] + stage * HALO_BYTES);
+                af[q][mi] = *reinterpret_cast<const f16x8*>(smem + a_addr[tap][mi][ks] + S * HALO_BYTES);
         }
     };
-
-    auto compute = [&](int stage) {
-        f16x8 af[2][MT][2], wf[2][NI][2];
-        load_tap(stage, 0, af[0], wf[0]);
+    // x_residual (COUT = 64): "+ x" of a dense block's last conv (esrgan.cpp:38-40) without reading x again: the
+    // centre-tap pixel fragments of chunks 0 and 1 ARE x[0:64], so two extra k-steps per chunk multiply them with
+    // (1/s1) * identity (exact in f16) into the matching channel tile; the epilogue's * s1 makes it "+ x".
+    const bool xres = NI == 2 && p.x_residual != 0;
+    const f16 inv_s1 = (f16)(1.0f / p.s1);
+    auto compute = [&](auto stage_c, int chunk) {
+        f16x8 af[2][G][MT], wf[2][G][NI];
+        load_group(stage_c, 0, af[0], wf[0]);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) load_tap(stage, tap + 1, af[(tap + 1) & 1], wf[(tap + 1) & 1]);
+        for (int grp = 0; grp < 18 / G; ++grp) {
+            if (grp + 1 < 18 / G) load_group(stage_c, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int q = 0; q < G; ++q)
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap & 1][ni][ks], af[tap & 1][mi][ks], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][q][ni], af[grp & 1][q][mi], acc[mi][ni], 0, 0, 0);
+            if constexpr (NI == 2) {
+                if ((grp * G) >> 1 == 4 && xres && chunk < 2) { // centre tap
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {
+                        const int ks = (grp * G + q) & 1;
+                        f16x8 id;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) id[j] = (r == ks * 16 + h * 8 + j) ? inv_s1 : (f16)0;
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) {
+                            if (chunk == 0) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id, af[grp & 1][q][mi], acc[mi][0], 0, 0, 0);
+                            else acc[mi][NI - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id, af[grp & 1][q][mi], acc[mi][NI - 1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
         }
     };
 
-    const int nch = p.cin / CK;
+    geom cur = locate(t_next);
+    int shape = cur.tws;
+    setup_addr(shape);
+    int src_shape = shape;
+    setup_shape_src(src_shape);
+    setup_src(cur);
     issue(0, 0);
-    for (int c = 0; c < nch; c += 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // chunk c is in stage 0 for everyone; everyone is done reading stage 1
-        if (c + 1 < nch) issue(c + 1, 1);
-        compute(0);
-        if (c + 1 < nch) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (c + 2 < nch) issue(c + 2, 0);
-            compute(1);
-        }
-    }
-
-    // ---- epilogue
-    if constexpr (EPI == VX_DC_RGB_F32) {
-        // channels 0..2 of pixel r sit in acc[mi][0][0..2] of the lanes with h == 0
-        if (h == 0) {
+    auto zero_acc = [&]() {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const int f = (wave * MT + mi) * 32 + r;
-                const int trow = f / TW, tcol = f - trow * TW;
-                const int oy = y0 + trow, ox = x0 + tcol;
-                if (oy < H && ox < W) {
-                    float* o = reinterpret_cast<float*>(p.out) + (((long)b * H + oy) * W + ox) * 3;
-                    o[0] = acc[mi][0][0] + s_bias[0];
-                    o[1] = acc[mi][0][1] + s_bias[1];
-                    o[2] = acc[mi][0][2] + s_bias[2];
-                }
-            }
-        }
-    } else {
-        __syncthreads(); // every wave is done with the ring: reuse it as the output staging buffer
-        unsigned char* const st = smem;
-        const bool lrelu = p.act != 0;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int ml = (wave * MT + mi) * 32 + r; // staged row = pixel index in the tile
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nl = ni * 32 + 8 * g + 4 * h;
-                    const float4 bias = *reinterpret_cast<const float4*>(s_bias + nl);
-                    float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
-                                  acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
-                    if (lrelu) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.2f * v[j]);
-                    }
-                    f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                    const int c8 = nl >> 2;
-                    const int phys16 = (c8 >> 1) ^ (ml & (NCH16 - 1));
-                    *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
-                }
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+    };
+    zero_acc();
+    int c = 0; // chunk of the current tile
+    bool stores_in_flight = false;
+    f16* const trash = reinterpret_cast<f16*>(g_dconv_trash + ((blockIdx.x % TRASH_BLOCKS) * 8 + wave) * 1024 + lane * 16);
+
+    // One step = one (tile, chunk) of the block's stream, computed out of ring stage S. The two instantiations run
+    // back to back in the loop below (stage parity is a property of the code position, so every LDS address is
+    // base register + immediate); a tile boundary may fall after either of them.
+    auto step = [&](auto stage_c) -> bool {
+        constexpr int S = decltype(stage_c)::value;
+        const int t_after = t_next + t_step;
+        // the chunk's LDS-DMA must have landed; vector memory returns in order, so after a tile boundary the wait
+        // leaves that tile's NCH16 output stores (younger than the DMA) in flight instead of draining them
+        if (EPI == VX_DC_F16 && stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH16) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stores_in_flight = false;
+        __syncthreads(); // this chunk has landed for everyone; everyone is done with the other stage
+        if (c + 1 < nch) issue(c + 1, S ^ 1);
+        else if (t_after < t_end) { // the next tile's first chunk streams in under this tile's last chunk + epilogue
+            const geom nx = locate(t_after);
+            if (nx.tws != src_shape) {
+                src_shape = nx.tws;
+                setup_shape_src(src_shape);
+            }
+            setup_src(nx);
+            issue(0, S ^ 1);
         }
-        __syncthreads();
-        constexpr int CHUNKS = TH * TW * NCH16;
-        const f16* __restrict__ R1 = reinterpret_cast<const f16*>(p.res1);
-        const f16* __restrict__ R2 = reinterpret_cast<const f16*>(p.res2);
-        const float s1 = p.s1, s2 = p.s2;
+        if (!(dbg & 4)) compute(stage_c, c);
+        if (++c < nch) return false;
+
+        constexpr int done = S; // the stage of the last chunk: free once every wave has left compute()
+        const int tw_mask = (1 << cur.tws) - 1;
+
+        // ---- epilogue
+        if constexpr (EPI == VX_DC_RGB_F32) {
+            // channels 0..2 of pixel r sit in acc[mi][0][0..2] of the lanes with h == 0
+            if (h == 0) {
 #pragma unroll
-        for (int it = 0; it < CHUNKS / 512; ++it) {
-            const int id = tid + it * 512;
-            const int ml = id / NCH16, j = id % NCH16;
-            const int trow = ml / TW, tcol = ml - trow * TW;
-            const int oy = y0 + trow, ox = x0 + tcol;
-            if (oy >= H || ox >= W) continue;
-            f16x8 v = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ (ml & (NCH16 - 1))) * 16);
-            const long pixel = ((long)b * H + oy) * W + ox;
-            if (R1) {
-                const f16x8 a = *reinterpret_cast<const f16x8*>(R1 + pixel * p.res1_ld + j * 8);
-                if (R2) {
-                    const f16x8 c = *reinterpret_cast<const f16x8*>(R2 + pixel * p.res2_ld + j * 8);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = (f16)(((float)v[q] * s1 + (float)a[q]) * s2 + (float)c[q]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = (f16)((float)v[q] * s1 + (float)a[q]);
+                for (int mi = 0; mi < MT; ++mi) {
+                    const int f = (wave * MT + mi) * 32 + r;
+                    const int oy = cur.y0 + (f >> cur.tws), ox = cur.x0 + (f & tw_mask);
+                    if (oy < H && ox < W) {
+                        float* o = reinterpret_cast<float*>(p.out) + (((long)cur.b * H + oy) * W + ox) * 3;
+                        o[0] = acc[mi][0][0] + s_bias[0];
+                        o[1] = acc[mi][0][1] + s_bias[1];
+                        o[2] = acc[mi][0][2] + s_bias[2];
+                    }
                 }
             }
-            *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + pixel * p.ldo + j * 8) = v;
+        } else {
+            __syncthreads(); // every wave is done reading stage `done`: its space stages the f16 tile
+            // rows 0..255 (waves 0-3) in the halo space of the stage, rows 256..511 (waves 4-7) in its slab space
+            // (COUT = 32: both halves fit the halo space); each wave stages and drains its own 64 rows
+            unsigned char* st;
+            if constexpr (COUT == 32) st = smem + done * HALO_BYTES + wave * 64 * PITCH;
+            else st = (wave < 4 ? smem + done * HALO_BYTES : smem + W_BASE + done * W_BYTES) + (wave & 3) * 64 * PITCH;
+            const bool lrelu = (p.act & 1) != 0;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                const int ml = mi * 32 + r; // row inside the wave's staging block
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = ni * 32 + 8 * g + 4 * h;
+                        const float4 bias = *reinterpret_cast<const float4*>(s_bias + nl);
+                        float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
+                                      acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
+                        if (lrelu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.2f * v[j]);
+                        }
+                        if (xres) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= p.s1;
+                        }
+                        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                        const int c8 = nl >> 2;
+                        const int phys16 = (c8 >> 1) ^ (ml & (NCH16 - 1));
+                        *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
+                    }
+            }
+            // drain in batches of NB rows-groups: residual loads of a batch are issued together (out-of-map pixels
+            // read a clamped, valid address and are masked at the store)
+            const f16* __restrict__ R1 = reinterpret_cast<const f16*>(p.res1);
+            const f16* __restrict__ R2 = reinterpret_cast<const f16*>(p.res2);
+            constexpr int ROWS_PER_IT = 64 / NCH16;
+            constexpr int NB = 4; // iterations whose loads are in flight together
+            const int j = lane % NCH16;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-local hand-over of the staged rows: no block barrier
+            const float s1 = p.s1, s2 = p.s2;
+#pragma unroll
+            for (int ib = 0; ib < NCH16; ib += NB) {
+                long pixel[NB];
+                bool ok[NB];
+                f16x8 ra[NB], rc[NB], v[NB];
+#pragma unroll
+                for (int it = 0; it < NB; ++it) {
+                    const int f = wave * 64 + (ib + it) * ROWS_PER_IT + lane / NCH16;
+                    const int oy = cur.y0 + (f >> cur.tws), ox = cur.x0 + (f & tw_mask);
+                    ok[it] = oy < H && ox < W;
+                    pixel[it] = ((long)cur.b * H + min(oy, H - 1)) * W + min(ox, W - 1);
+                }
+                if (R1) {
+#pragma unroll
+                    for (int it = 0; it < NB; ++it) ra[it] = *reinterpret_cast<const f16x8*>(R1 + pixel[it] * p.res1_ld + j * 8);
+                }
+                if (R2) {
+#pragma unroll
+                    for (int it = 0; it < NB; ++it) rc[it] = *reinterpret_cast<const f16x8*>(R2 + pixel[it] * p.res2_ld + j * 8);
+                }
+#pragma unroll
+                for (int it = 0; it < NB; ++it) {
+                    const int ml = (ib + it) * ROWS_PER_IT + lane / NCH16;
+                    v[it] = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ (ml & (NCH16 - 1))) * 16);
+                }
+#pragma unroll
+                for (int it = 0; it < NB; ++it) {
+                    if (R1) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s1 + (float)ra[it][q]);
+                    }
+                    if (R2) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s2 + (float)rc[it][q]);
+                    }
+                    f16* dst = ok[it] ? reinterpret_cast<f16*>(p.out) + pixel[it] * p.ldo + j * 8 : trash;
+                    *reinterpret_cast<f16x8*>(dst) = v[it];
+                }
+            }
+            stores_in_flight = true;
         }
+
+        t_next = t_after;
+        if (t_next >= t_end) return true;
+        cur = locate(t_next);
+        if (cur.tws != shape) {
+            shape = cur.tws;
+            setup_addr(shape);
+        }
+        zero_acc();
+        c = 0;
+        return false;
+    };
+    for (;;) {
+        if (step(std::integral_constant<int, 0>{})) break;
+        if (step(std::integral_constant<int, 1>{})) break;
     }
 }
 
-template <int COUT, int MT, int TW, int EPI>
+int dconv_grid_blocks() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    return n_cu; // one 8-wave block per CU (its LDS ring takes the whole 160 KB)
+}
+
+template <int COUT, int EPI>
 int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
-    constexpr int TH = NW * MT * 32 / TW;
-    constexpr int HALO_BYTES = (((TH + 2) * (TW + 2) * 4 + 63) / 64) * 1024;
+    constexpr int HALO_BYTES = ((18 * 34 * 4 + 63) / 64) * 1024;
     constexpr int smem = 2 * HALO_BYTES + 2 * 9 * COUT * PIXB + COUT * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, MT, TW, EPI>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
-    hipLaunchKernelGGL((dconv3x3_kernel<COUT, MT, TW, EPI>), dim3(tiles), dim3(512), smem, s, a);
+    const long tiles = (long)a.B * tile_grid(a.H, a.W).total();
+    const int blocks = (int)(tiles < dconv_grid_blocks() ? tiles : dconv_grid_blocks());
+    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI>), dim3(blocks), dim3(512), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
 }
@@ -371,13 +543,15 @@ extern "C" int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream) {
     hipStream_t s = as_stream(stream);
     if (a.epi == VX_DC_RGB_F32) {
         VX_REQUIRE(a.cout == 32, "vx_dconv3x3_f16: the rgb head takes weights padded to 32 outputs");
-        return launch_dconv<32, 2, 32, VX_DC_RGB_F32>(a, s);
+        return launch_dconv<32, VX_DC_RGB_F32>(a, s);
     }
     VX_REQUIRE(a.epi == VX_DC_F16, "vx_dconv3x3_f16: unknown epilogue %d", a.epi);
-    VX_REQUIRE(a.ldo % 8 == 0 && (!a.res1 || a.res1_ld % 8 == 0) && (!a.res2 || a.res2_ld % 8 == 0) && (a.res1 || !a.res2),
-               "vx_dconv3x3_f16: output/residual pixel strides must be multiples of 8 (res2 needs res1)");
-    if (a.cout == 32) return launch_dconv<32, 2, 32, VX_DC_F16>(a, s);
-    if (a.cout == 64) return launch_dconv<64, 2, 32, VX_DC_F16>(a, s);
+    VX_REQUIRE(a.ldo % 8 == 0 && (!a.res1 || a.res1_ld % 8 == 0) && (!a.res2 || a.res2_ld % 8 == 0),
+               "vx_dconv3x3_f16: output/residual pixel strides must be multiples of 8");
+    VX_REQUIRE(!a.x_residual || (a.cout == 64 && a.cin >= 64 && !a.res1 && !a.up2 && a.s1 != 0.0f),
+               "vx_dconv3x3_f16: x_residual needs cout = 64 <= cin, no res1, no upsampling");
+    if (a.cout == 32) return launch_dconv<32, VX_DC_F16>(a, s);
+    if (a.cout == 64) return launch_dconv<64, VX_DC_F16>(a, s);
     vx_set_error("vx_dconv3x3_f16: Cout %d not in {32, 64}", a.cout);
     return 0;
 }
