@@ -58,17 +58,22 @@ template <int COUT, int EPI>
 __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     constexpr int MT = 2;                       // M-tiles (32 pixels) per wave
     constexpr int HALO_PIX = 18 * 34;           // both tile shapes
-    // a stage holds [pixel][64 B] (the chunk's 32 channels) with the four 16-byte groups XOR-swizzled by
+    // a halo stage holds [pixel][64 B] (the chunk's 32 channels) with the four 16-byte groups XOR-swizzled by
     // (pixel >> 2) & 3: 16 consecutive pixels cover all 64 banks, and a pixel is ONE 64-byte global segment for the
     // LDS-DMA (two 32-byte k-step planes would need one address register set less but double the number of
-    // cache-line requests per byte: measured 15-25 % slower)
-    constexpr int HALO_INSTR = (HALO_PIX * 4 + 63) / 64, HALO_BYTES = HALO_INSTR * 1024;
+    // cache-line requests per byte: measured 15-25 % slower). 612 pixels = 38.25 KiB, padded to 40 wave
+    // instructions so that every wave issues exactly HJ = 5 of them (the counted vmcnt below relies on it).
+    constexpr int HJ = 5, HALO_INSTR = HJ * NW, HALO_BYTES = HALO_INSTR * 1024;
     constexpr int NI = COUT / 32;
     constexpr int W_BYTES = 9 * COUT * PIXB, W_INSTR = W_BYTES / 1024;
-    constexpr int HJ = (HALO_INSTR + NW - 1) / NW, WJ = (W_INSTR + NW - 1) / NW;
-    constexpr int W_BASE = 2 * HALO_BYTES;      // LDS: [halo 0 | halo 1 | slab 0 | slab 1 | bias]
+    constexpr int WJ = (W_INSTR + NW - 1) / NW;
+    // The kernel is bound by the LDS-DMA stream (57/77 KB per 36/72 MFMAs per wave), i.e. by bytes in flight per
+    // CU: with COUT = 32 the LDS has room for a THIRD halo stage, so halos are issued two steps ahead.
+    constexpr int HS = COUT == 32 ? 3 : 2;      // halo stages; slabs always 2
+    constexpr int W_BASE = HS * HALO_BYTES;     // LDS: [halo 0 .. HS-1 | slab 0 | slab 1 | bias]
     constexpr int BIAS_BASE = W_BASE + 2 * W_BYTES;
     constexpr int NCH16 = COUT / 8, PITCH = COUT * 2;
+    static_assert(BIAS_BASE + COUT * 4 <= 160 * 1024, "LDS ring too large");
     static_assert(256 * PITCH <= HALO_BYTES && 256 * PITCH <= W_BYTES + (COUT == 32 ? HALO_BYTES : 0), "output staging does not fit a stage");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -85,16 +90,16 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // persistent blocks; XCD-aware order: blocks id and id+8 share an L2. Every XCD owns a contiguous run of the
     // tile sequence (neighbouring tiles share halo rows, one image's tiles share their slabs) and its blocks walk
     // that run with a stride of the XCD's block count.
-    int t_next, t_end, t_step;
+    int t_cur, t_end, t_step;
     {
         const int id = blockIdx.x, xcd = id & 7;
         const int per = total >> 3, rem = total & 7;
         const int lo = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
         t_end = lo + per + (xcd < rem ? 1 : 0);
         t_step = ((int)gridDim.x - xcd + 7) >> 3;
-        t_next = lo + (id >> 3);
+        t_cur = lo + (id >> 3);
     }
-    if (t_next >= t_end) return;
+    if (t_cur >= t_end) return;
 
     if (tid < COUT) s_bias[tid] = p.bias ? p.bias[tid] : 0.0f;
 
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // loop; halo pixels outside the map use an offset beyond the descriptor's size and are zero-filled by the
     // hardware's range check (conv zero padding, nn.cpp:83-97 pad = 1).
     constexpr unsigned OOB = 0x80000000u;
-    unsigned hoff[HJ];  // byte offset of the lane's 16 bytes (chunk 0) inside the current image
+    unsigned hoff[HJ];  // byte offset of the lane's 16 bytes (chunk 0) inside the image the halo cursor is in
     unsigned hpack[HJ]; // shape-dependent, tile-invariant part: halo row | halo col << 8 | swizzled group << 16 | valid << 24
     auto setup_shape_src = [&](int tws) {
         const int hw = (1 << tws) + 2;
@@ -150,19 +155,17 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             hoff[j] = valid ? (unsigned)(e * 2) : OOB;
         }
     };
-    const int dbg = p.act >> 4; // TEMP ablation: 1 = no halo DMA, 2 = no slab DMA, 4 = no MFMA
-    auto issue = [&](int c, int stage) {
+    auto issue_halo = [&](int c, int hstage) {
 #pragma unroll
-        for (int j = 0; j < HJ; ++j) {
-            const int i = wave + j * NW;
-            if (i < HALO_INSTR && !(dbg & 1))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + stage * HALO_BYTES + i * 1024), 16, hoff[j], c * (CK * 2), 0, 0);
-        }
+        for (int j = 0; j < HJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + hstage * HALO_BYTES + (wave + j * NW) * 1024), 16, hoff[j], c * (CK * 2), 0, 0);
+    };
+    auto issue_slab = [&](int c, int wstage) {
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const int i = wave + j * NW;
-            if (i < W_INSTR && !(dbg & 2))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem + W_BASE + stage * W_BYTES + i * 1024), 16, lane * 16, c * W_BYTES + i * 1024, 0, 0);
+            if (i < W_INSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem + W_BASE + wstage * W_BYTES + i * 1024), 16, lane * 16, c * W_BYTES + i * 1024, 0, 0);
         }
     };
 
@@ -193,17 +196,17 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // fragments are prefetched one GROUP of k-steps ahead (register double buffer): a whole tap (2 k-steps) for
     // COUT = 32, one k-step for COUT = 64 where the accumulators leave fewer registers
     constexpr int G = COUT == 32 ? 2 : 1;
-    auto load_group = [&](auto stage_c, int grp, f16x8 (&af)[G][MT], f16x8 (&wf)[G][NI]) {
-        constexpr int S = decltype(stage_c)::value;
+    auto load_group = [&](auto hs_c, auto ws_c, int grp, f16x8 (&af)[G][MT], f16x8 (&wf)[G][NI]) {
+        constexpr int HSt = decltype(hs_c)::value, WSt = decltype(ws_c)::value;
 #pragma unroll
         for (int q = 0; q < G; ++q) {
             const int step = grp * G + q, tap = step >> 1, ks = step & 1;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                wf[q][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[S][ks] + (tap * COUT + ni * 32) * PIXB);
+                wf[q][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[WSt][ks] + (tap * COUT + ni * 32) * PIXB);
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
-                af[q][mi] = *reinterpret_cast<const f16x8*>(smem + a_addr[tap][mi][ks] + S * HALO_BYTES);
+                af[q][mi] = *reinterpret_cast<const f16x8*>(smem + a_addr[tap][mi][ks] + HSt * HALO_BYTES);
         }
     };
     // x_residual (COUT = 64): "+ x" of a dense block's last conv (esrgan.cpp:38-40) without reading x again: the
@@ -211,12 +214,12 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // (1/s1) * identity (exact in f16) into the matching channel tile; the epilogue's * s1 makes it "+ x".
     const bool xres = NI == 2 && p.x_residual != 0;
     const f16 inv_s1 = (f16)(1.0f / p.s1);
-    auto compute = [&](auto stage_c, int chunk) {
+    auto compute = [&](auto hs_c, auto ws_c, int chunk) {
         f16x8 af[2][G][MT], wf[2][G][NI];
-        load_group(stage_c, 0, af[0], wf[0]);
+        load_group(hs_c, ws_c, 0, af[0], wf[0]);
 #pragma unroll
         for (int grp = 0; grp < 18 / G; ++grp) {
-            if (grp + 1 < 18 / G) load_group(stage_c, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
+            if (grp + 1 < 18 / G) load_group(hs_c, ws_c, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < G; ++q)
@@ -243,14 +246,6 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             }
         }
     };
-
-    geom cur = locate(t_next);
-    int shape = cur.tws;
-    setup_addr(shape);
-    int src_shape = shape;
-    setup_shape_src(src_shape);
-    setup_src(cur);
-    issue(0, 0);
     auto zero_acc = [&]() {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
@@ -259,37 +254,73 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
     };
+
+    // ---- the block's stream of (tile, chunk) steps. Two cursors run over it: the compute cursor (cur, c) and the
+    // halo cursor (h_t, h_c), HS-1 steps ahead. Per step, after the barrier: slab of the next step, then the halo
+    // HS-1 steps ahead -- in that order, so that the counted vmcnt of the next step (vector memory returns in
+    // order) can leave the younger halo and the tile's output stores in flight.
+    geom cur = locate(t_cur);
+    int shape = cur.tws;
+    setup_addr(shape);
+    int src_shape = shape;
+    setup_shape_src(src_shape);
+    setup_src(cur);
+    int h_t = t_cur, h_c = 0;
+    auto advance_halo = [&](int hstage) -> bool { // issues the halo at the cursor, moves the cursor; false = stream ended
+        if (h_t >= t_end) return false;
+        issue_halo(h_c, hstage);
+        if (++h_c == nch) {
+            h_c = 0;
+            h_t += t_step;
+            if (h_t < t_end) {
+                const geom nx = locate(h_t);
+                if (nx.tws != src_shape) {
+                    src_shape = nx.tws;
+                    setup_shape_src(src_shape);
+                }
+                setup_src(nx);
+            }
+        }
+        return true;
+    };
+    issue_slab(0, 0);
+    bool prev_halo = false; // did the previous step issue a halo (younger than the slab this step waits for)?
+#pragma unroll
+    for (int k = 0; k < HS - 1; ++k) prev_halo = advance_halo(k);
+    if (HS == 2) prev_halo = false; // with two stages the only halo in flight is the one this step needs
     zero_acc();
     int c = 0; // chunk of the current tile
     bool stores_in_flight = false;
     f16* const trash = reinterpret_cast<f16*>(g_dconv_trash + ((blockIdx.x % TRASH_BLOCKS) * 8 + wave) * 1024 + lane * 16);
 
-    // One step = one (tile, chunk) of the block's stream, computed out of ring stage S. The two instantiations run
-    // back to back in the loop below (stage parity is a property of the code position, so every LDS address is
-    // base register + immediate); a tile boundary may fall after either of them.
-    auto step = [&](auto stage_c) -> bool {
-        constexpr int S = decltype(stage_c)::value;
-        const int t_after = t_next + t_step;
-        // the chunk's LDS-DMA must have landed; vector memory returns in order, so after a tile boundary the wait
-        // leaves that tile's NCH16 output stores (younger than the DMA) in flight instead of draining them
-        if (EPI == VX_DC_F16 && stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH16) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stores_in_flight = false;
-        __syncthreads(); // this chunk has landed for everyone; everyone is done with the other stage
-        if (c + 1 < nch) issue(c + 1, S ^ 1);
-        else if (t_after < t_end) { // the next tile's first chunk streams in under this tile's last chunk + epilogue
-            const geom nx = locate(t_after);
-            if (nx.tws != src_shape) {
-                src_shape = nx.tws;
-                setup_shape_src(src_shape);
+    // One step, computed out of halo stage HSt and slab stage WSt. The HS x 2 instantiations run back to back in
+    // the loop below (stage parity is a property of the code position, so every LDS address is base register +
+    // immediate); a tile boundary may fall after any of them.
+    auto step = [&](auto hs_c, auto ws_c) -> bool {
+        constexpr int HSt = decltype(hs_c)::value, WSt = decltype(ws_c)::value;
+        // this step's halo and slab must have landed; leave what is younger than them in flight
+        {
+            const bool st = EPI == VX_DC_F16 && stores_in_flight;
+            if (HS == 3 && prev_halo) {
+                if (st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HJ + NCH16) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HJ) : "memory");
+            } else {
+                if (st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH16) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            setup_src(nx);
-            issue(0, S ^ 1);
         }
-        if (!(dbg & 4)) compute(stage_c, c);
+        stores_in_flight = false;
+        // raw s_barrier: __syncthreads() carries a fence that drains vmcnt, i.e. the halo prefetched for later steps
+        __builtin_amdgcn_s_barrier(); // the step's data is in LDS for everyone; everyone has left the previous step's stages
+        asm volatile("" ::: "memory");
+        const bool last_chunk = c + 1 == nch;
+        const bool more = !last_chunk || t_cur + t_step < t_end;
+        if (more) issue_slab(last_chunk ? 0 : c + 1, WSt ^ 1);
+        prev_halo = advance_halo((HSt + HS - 1) % HS);
+        compute(hs_c, ws_c, c);
         if (++c < nch) return false;
 
-        constexpr int done = S; // the stage of the last chunk: free once every wave has left compute()
+        constexpr int done = HSt; // the halo stage of the last chunk: free once every wave has left compute()
         const int tw_mask = (1 << cur.tws) - 1;
 
         // ---- epilogue
@@ -308,13 +339,18 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                     }
                 }
             }
+            // the number of store instructions is data dependent here: drain before the next counted wait
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prev_halo = false;
         } else {
-            __syncthreads(); // every wave is done reading stage `done`: its space stages the f16 tile
-            // rows 0..255 (waves 0-3) in the halo space of the stage, rows 256..511 (waves 4-7) in its slab space
-            // (COUT = 32: both halves fit the halo space); each wave stages and drains its own 64 rows
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // every wave is done reading stage `done`: its space stages the f16 tile
+            asm volatile("" ::: "memory");
+            // rows 0..255 (waves 0-3) in the halo space of the stage, rows 256..511 (waves 4-7) in the slab space
+            // of the step (COUT = 32: both halves fit the halo space); each wave stages and drains its own 64 rows
             unsigned char* st;
             if constexpr (COUT == 32) st = smem + done * HALO_BYTES + wave * 64 * PITCH;
-            else st = (wave < 4 ? smem + done * HALO_BYTES : smem + W_BASE + done * W_BYTES) + (wave & 3) * 64 * PITCH;
+            else st = (wave < 4 ? smem + done * HALO_BYTES : smem + W_BASE + WSt * W_BYTES) + (wave & 3) * 64 * PITCH;
             const bool lrelu = (p.act & 1) != 0;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
@@ -341,8 +377,8 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                         *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
                     }
             }
-            // drain in batches of NB rows-groups: residual loads of a batch are issued together (out-of-map pixels
-            // read a clamped, valid address and are masked at the store)
+            // drain in batches of NB row groups: residual loads of a batch are issued together (out-of-map pixels
+            // read a clamped, valid address and store to the trash page)
             const f16* __restrict__ R1 = reinterpret_cast<const f16*>(p.res1);
             const f16* __restrict__ R2 = reinterpret_cast<const f16*>(p.res2);
             constexpr int ROWS_PER_IT = 64 / NCH16;
@@ -392,9 +428,9 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             stores_in_flight = true;
         }
 
-        t_next = t_after;
-        if (t_next >= t_end) return true;
-        cur = locate(t_next);
+        t_cur += t_step;
+        if (t_cur >= t_end) return true;
+        cur = locate(t_cur);
         if (cur.tws != shape) {
             shape = cur.tws;
             setup_addr(shape);
@@ -403,9 +439,19 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         c = 0;
         return false;
     };
+    using std::integral_constant;
     for (;;) {
-        if (step(std::integral_constant<int, 0>{})) break;
-        if (step(std::integral_constant<int, 1>{})) break;
+        if constexpr (HS == 3) {
+            if (step(integral_constant<int, 0>{}, integral_constant<int, 0>{})) break;
+            if (step(integral_constant<int, 1>{}, integral_constant<int, 1>{})) break;
+            if (step(integral_constant<int, 2>{}, integral_constant<int, 0>{})) break;
+            if (step(integral_constant<int, 0>{}, integral_constant<int, 1>{})) break;
+            if (step(integral_constant<int, 1>{}, integral_constant<int, 0>{})) break;
+            if (step(integral_constant<int, 2>{}, integral_constant<int, 1>{})) break;
+        } else {
+            if (step(integral_constant<int, 0>{}, integral_constant<int, 0>{})) break;
+            if (step(integral_constant<int, 1>{}, integral_constant<int, 1>{})) break;
+        }
     }
 }
 
@@ -420,8 +466,8 @@ int dconv_grid_blocks() {
 
 template <int COUT, int EPI>
 int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
-    constexpr int HALO_BYTES = ((18 * 34 * 4 + 63) / 64) * 1024;
-    constexpr int smem = 2 * HALO_BYTES + 2 * 9 * COUT * PIXB + COUT * 4;
+    constexpr int HALO_BYTES = 5 * NW * 1024;
+    constexpr int smem = (COUT == 32 ? 3 : 2) * HALO_BYTES + 2 * 9 * COUT * PIXB + COUT * 4;
     static bool attr_set = false;
     if (!attr_set) {
         VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
