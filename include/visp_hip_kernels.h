@@ -114,32 +114,33 @@ VX_API int vx_conv3x3_supported(const vx_gemm_args* args);
 VX_API int vx_conv3x3_f16(const vx_gemm_args* args, void* stream);
 
 /* ---- ESRGAN dense-block 3x3 convolution (esrgan.cpp:13-79) ---------------------------------
- * Reads the first `cin` channels of an f16 NHWC map whose pixel stride is x_ld elements (a residual dense block
- * keeps [x|x1|x2|x3|x4] in one 192-wide row, so concat (esrgan.cpp:29-36) is never materialised) and writes
- * `cout` channels at out (pixel stride ldo; the channel-slice offset is folded into the pointer).
+ * Activations are f16, PLANAR in groups of 32 channels: a C-channel map is C/32 planes of [B, H, W, 32], consecutive
+ * planes `*_plane` elements apart. A residual dense block keeps [x|x1|x2|x3|x4] as six planes of one buffer: a conv
+ * reads the first cin/32 planes and writes its 32 (or 64) outputs as the next plane(s), so concat
+ * (esrgan.cpp:29-36) is never materialised.
  *   v = conv(x) + bias;  act: v = max(v, 0.2 v);  res1: v = v*s1 + res1;  res2: v = v*s2 + res2.
- *   x_residual (cout = 64): v = v*s1 + x[:, 0:64] with x taken from the halo already in LDS (no second read of x);
+ *   x_residual (cout = 64): v = v*s1 + x[planes 0,1] with x taken from the halo already in LDS (no second read);
  *   mutually exclusive with res1, res2 still applies afterwards.
- * up2: the source is [B, H/2, W/2, x_ld] and is nearest-upsampled on the fly (esrgan.cpp:13-19).
+ * up2: the source is [B, H/2, W/2, 32] per plane and is nearest-upsampled on the fly (esrgan.cpp:13-19).
  * w: packed by the host as [cin/32][9 taps][cout][32] f16 with the four 16-byte groups of every (tap, n) row
  *    stored at position g ^ ((n >> 2) & 3)  (see packer::conv in csrc/esrgan.cpp).
  * VX_DC_RGB_F32: cout = 32 (3 real), out = f32 [B, H, W, 3], no activation / residuals. */
 enum { VX_DC_F16 = 0, VX_DC_RGB_F32 = 1 };
 typedef struct {
-    const void* x; int x_ld; int cin; int up2;
+    const void* x; int64_t x_plane; int cin; int up2;
     int B, H, W;                 /* output (= conv-space) extent */
     const void* w; const float* bias; int cout;
     int epi, act;
-    float s1; const void* res1; int res1_ld;
-    float s2; const void* res2; int res2_ld;
-    void* out; int ldo;
+    float s1; const void* res1; int64_t res1_plane;
+    float s2; const void* res2; int64_t res2_plane;
+    void* out; int64_t out_plane;
     int x_residual;
 } vx_dconv_args;
 VX_API int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream);
 
 /* tile_layout (include/visp/image.h:163-181, src/visp/image.cpp:612-651) */
 typedef struct { int image_w, image_h, overlap_x, overlap_y, n_x, n_y, tile_w, tile_h; } vx_tile_layout;
-/* image_u8_to_f32 with tile offset for every tile (vision.cpp:236-241) -> f16 [B*n_tiles, tile_h, tile_w, 32]
+/* image_u8_to_f32 with tile offset for every tile (vision.cpp:236-241) -> one plane f16 [B*n_tiles, tile_h, tile_w, 32]
  * (channels 0..2 = value, 3..5 = f16 rounding residue, rest 0). format = visp::image_format (u8 colour). */
 VX_API int vx_esrgan_tiles_in(const uint8_t* img, int B, int w, int h, int format, const vx_tile_layout* t, void* out, void* stream);
 /* tile_merge of all tiles in the reference's order + image_f32_to_u8 rgba (image.cpp:653-693, vision.cpp:246-252).

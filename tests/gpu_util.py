@@ -108,30 +108,44 @@ def pack_dconv(w: np.ndarray, cin_pad: int | None = None, cout_pad: int | None =
     return np.ascontiguousarray(out)
 
 
-def dconv(x_dev, x_ld, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=0, out=None, ldo=None, out_off=0,
-          res1=None, res1_ld=0, s1=1.0, res2=None, res2_ld=0, s2=1.0, rgb=False, cin_pad=None, x_residual=False):
-    """Launches vx_dconv3x3_f16; returns the output as numpy (f16 [B,H,W,ldo] or f32 [B,H,W,3])."""
+def to_planes(x: np.ndarray) -> np.ndarray:
+    """[B,H,W,C] -> [C/32][B,H,W,32] (the planar activation layout of vx_dconv3x3_f16)."""
+    B, H, W, C = x.shape
+    return np.ascontiguousarray(x.reshape(B, H, W, C // 32, 32).transpose(3, 0, 1, 2, 4))
+
+
+def from_planes(p: np.ndarray) -> np.ndarray:
+    P, B, H, W, _ = p.shape
+    return np.ascontiguousarray(p.transpose(1, 2, 3, 0, 4).reshape(B, H, W, P * 32))
+
+
+def dconv(x_dev, n_planes, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=0, out=None, out_planes=None, out_plane0=0,
+          res1=None, s1=1.0, res2=None, s2=1.0, rgb=False, cin_pad=None, x_residual=False):
+    """Launches vx_dconv3x3_f16 on planar buffers (x_dev: n_planes planes of [B,H(/2),W(/2),32]); the output goes to
+    planes out_plane0.. of `out` (out_planes planes of [B,H,W,32]). Returns all planes of the output buffer as
+    [B,H,W,32*planes] f16, or f32 [B,H,W,3] for the rgb head. res1/res2: planar device buffers [cout/32][B,H,W,32]."""
     cout = w.shape[0]
     cop = -(-cout // 32) * 32
     wd = dev(pack_dconv(w, cin_pad or cin, cop))
     bd = dev(pad_vec(bias, cop)) if bias is not None else None
+    src_px = B * (H // 2 if up2 else H) * (W // 2 if up2 else W) * 32
+    dst_px = B * H * W * 32
     if rgb:
         ob = out or empty(B * H * W * 3 * 4)
-        ldo = 3
     else:
-        ldo = ldo or cop
-        ob = out or empty(B * H * W * ldo * 2)
+        out_planes = out_planes or cop // 32
+        ob = out or empty(out_planes * dst_px * 2)
     a = L.DconvArgs()
-    a.x, a.x_ld, a.cin, a.up2 = x_dev.ptr, x_ld, cin, int(up2)
+    a.x, a.x_plane, a.cin, a.up2 = x_dev.ptr, src_px, cin, int(up2)
     a.B, a.H, a.W = B, H, W
     a.w, a.bias, a.cout = wd.ptr, (bd.ptr if bd else None), cop
     a.epi, a.act = (L.DC_RGB_F32 if rgb else L.DC_F16), act
-    a.s1, a.res1, a.res1_ld = s1, (res1.ptr if res1 else None), res1_ld
-    a.s2, a.res2, a.res2_ld = s2, (res2.ptr if res2 else None), res2_ld
-    a.out, a.ldo = ob.ptr + out_off * 2, ldo
+    a.s1, a.res1, a.res1_plane = s1, (res1.ptr if res1 else None), dst_px
+    a.s2, a.res2, a.res2_plane = s2, (res2.ptr if res2 else None), dst_px
+    a.out, a.out_plane = ob.ptr + out_plane0 * dst_px * 2, dst_px
     a.x_residual = int(x_residual)
     L.vx_check(api().vx_dconv3x3_f16(C.byref(a), None))
     sync()
     if rgb:
         return ob.to_numpy(np.float32, (B, H, W, 3))
-    return ob.to_numpy(np.float16, (B, H, W, ldo))
+    return from_planes(ob.to_numpy(np.float16, (out_planes, B, H, W, 32)))

@@ -26,23 +26,24 @@ def _conv_ref(x, w, b, act=0):
 
 
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 32, 16, 32, 1), (96, 32, 24, 40, 2), (128, 32, 33, 47, 1), (160, 32, 16, 16, 3),
-                                            (192, 64, 48, 48, 2), (64, 64, 37, 70, 1), (32, 64, 20, 36, 1)])
+                                            (192, 64, 48, 48, 2), (64, 64, 37, 70, 1), (32, 64, 20, 36, 1), (64, 32, 144, 144, 1)])
 def test_dconv_channel_prefix(cin, cout, H, W, B):
     from tests import gpu_util as G
     rng = np.random.default_rng(cin * 7 + cout)
-    x_ld = 192
-    buf = (rng.standard_normal((B, H, W, x_ld)) * 0.5).astype(np.float16)
+    C = 192
+    buf = (rng.standard_normal((B, H, W, C)) * 0.5).astype(np.float16)
     w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
     b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
     ref = _conv_ref(buf[..., :cin].astype(np.float32), w, b, act=1)
-    xd = G.dev(buf)
-    # output into a channel slice of a second 192-wide buffer; the rest must stay untouched
-    canary = np.full((B, H, W, x_ld), 7.0, np.float16)
-    od = G.dev(canary)
-    off = 64 if cout == 32 else 0
-    got = G.dconv(xd, x_ld, cin, B, H, W, w, b, act=1, out=od, ldo=x_ld, out_off=off)
+    xd = G.dev(G.to_planes(buf))
+    # output into plane(s) of a second six-plane buffer; the other planes must stay untouched
+    canary = np.full((B, H, W, C), 7.0, np.float16)
+    od = G.dev(G.to_planes(canary))
+    p0 = 2 if cout == 32 else 0
+    got = G.dconv(xd, 6, cin, B, H, W, w, b, act=1, out=od, out_planes=6, out_plane0=p0)
+    off = p0 * 32
     np.testing.assert_allclose(got[..., off:off + cout].astype(np.float32), ref, atol=4e-3, rtol=4e-3)
-    mask = np.ones(x_ld, bool)
+    mask = np.ones(C, bool)
     mask[off:off + cout] = False
     assert (got[..., mask] == np.float16(7.0)).all()
 
@@ -57,16 +58,17 @@ def test_dconv_scaled_residuals():
     w = (rng.standard_normal((64, 192, 3, 3)) / np.sqrt(192 * 9)).astype(np.float32)
     b = (rng.standard_normal(64) * 0.1).astype(np.float32)
     y = _conv_ref(buf.astype(np.float32), w, b)
-    xd, r2d = G.dev(buf), G.dev(r2)
-    got1 = G.dconv(xd, 192, 192, B, H, W, w, b, res1=xd, res1_ld=192, s1=0.2)
-    np.testing.assert_allclose(got1.astype(np.float32), y * 0.2 + buf[..., :64].astype(np.float32), atol=3e-3, rtol=3e-3)
-    got2 = G.dconv(xd, 192, 192, B, H, W, w, b, res1=xd, res1_ld=192, s1=0.2, res2=r2d, res2_ld=64, s2=0.2)
-    ref2 = (y * 0.2 + buf[..., :64].astype(np.float32)) * 0.2 + r2.astype(np.float32)
+    x64 = buf[..., :64].astype(np.float32)
+    xd, x64d, r2d = G.dev(G.to_planes(buf)), G.dev(G.to_planes(buf[..., :64])), G.dev(G.to_planes(r2))
+    got1 = G.dconv(xd, 6, 192, B, H, W, w, b, res1=x64d, s1=0.2)
+    np.testing.assert_allclose(got1.astype(np.float32), y * 0.2 + x64, atol=3e-3, rtol=3e-3)
+    got2 = G.dconv(xd, 6, 192, B, H, W, w, b, res1=x64d, s1=0.2, res2=r2d, s2=0.2)
+    ref2 = (y * 0.2 + x64) * 0.2 + r2.astype(np.float32)
     np.testing.assert_allclose(got2.astype(np.float32), ref2, atol=3e-3, rtol=3e-3)
     # the same through the identity fold (x taken from the halo in LDS instead of a second read)
-    got3 = G.dconv(xd, 192, 192, B, H, W, w, b, x_residual=True, s1=0.2)
-    np.testing.assert_allclose(got3.astype(np.float32), y * 0.2 + buf[..., :64].astype(np.float32), atol=3e-3, rtol=3e-3)
-    got4 = G.dconv(xd, 192, 192, B, H, W, w, b, x_residual=True, s1=0.2, res2=r2d, res2_ld=64, s2=0.2)
+    got3 = G.dconv(xd, 6, 192, B, H, W, w, b, x_residual=True, s1=0.2)
+    np.testing.assert_allclose(got3.astype(np.float32), y * 0.2 + x64, atol=3e-3, rtol=3e-3)
+    got4 = G.dconv(xd, 6, 192, B, H, W, w, b, x_residual=True, s1=0.2, res2=r2d, s2=0.2)
     np.testing.assert_allclose(got4.astype(np.float32), ref2, atol=3e-3, rtol=3e-3)
 
 
@@ -79,12 +81,12 @@ def test_dconv_upsample_and_rgb_head():
     b = (rng.standard_normal(64) * 0.1).astype(np.float32)
     up = np.repeat(np.repeat(x.astype(np.float32), 2, axis=1), 2, axis=2)   # nearest x2 (esrgan.cpp:13-16)
     ref = _conv_ref(up, w, b, act=1)
-    got = G.dconv(G.dev(x), 64, 64, B, 2 * h, 2 * w_, w, b, up2=True, act=1)
+    got = G.dconv(G.dev(G.to_planes(x)), 2, 64, B, 2 * h, 2 * w_, w, b, up2=True, act=1)
     np.testing.assert_allclose(got.astype(np.float32), ref, atol=4e-3, rtol=4e-3)
     w3 = (rng.standard_normal((3, 64, 3, 3)) / 24).astype(np.float32)
     b3 = np.array([0.4, 0.5, 0.6], np.float32)
     ref3 = _conv_ref(x.astype(np.float32), w3, b3)
-    got3 = G.dconv(G.dev(x), 64, 64, B, h, w_, w3, b3, rgb=True)
+    got3 = G.dconv(G.dev(G.to_planes(x)), 2, 64, B, h, w_, w3, b3, rgb=True)
     np.testing.assert_allclose(got3, ref3, atol=2e-3, rtol=2e-3)
 
 

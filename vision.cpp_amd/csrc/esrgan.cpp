@@ -280,21 +280,22 @@ struct exec {
     struct opts {
         bool up2 = false, lrelu = false, rgb = false, x_residual = false;
         float s1 = 1, s2 = 1;
-        const void* res1 = nullptr; int res1_ld = 0;
-        const void* res2 = nullptr; int res2_ld = 0;
+        const void* res1 = nullptr; int64_t res1_plane = 0;
+        const void* res2 = nullptr; int64_t res2_plane = 0;
     };
-    // x: [n, H(/2), W(/2), x_ld] f16, first g.cin channels; out: pixel stride ldo (f16) or f32 rgb
-    void conv(packed_dconv const& g, const void* x, int x_ld, int cin, int n, int H, int W, void* out, int ldo, opts const& o, const char* group) {
+    // x: cin/32 planes of [n, H(/2), W(/2), 32] f16, x_plane elements apart; out: planes of [n, H, W, 32] or f32 rgb
+    void conv(packed_dconv const& g, const void* x, int64_t x_plane, int cin, int n, int H, int W, void* out, int64_t out_plane, opts const& o,
+              const char* group) {
         vx_dconv_args a;
         memset(&a, 0, sizeof a);
-        a.x = x; a.x_ld = x_ld; a.cin = cin; a.up2 = o.up2;
+        a.x = x; a.x_plane = x_plane; a.cin = cin; a.up2 = o.up2;
         a.B = n; a.H = H; a.W = W;
         a.w = wa + g.w; a.bias = reinterpret_cast<const float*>(wa + g.b); a.cout = g.cout;
         a.epi = o.rgb ? VX_DC_RGB_F32 : VX_DC_F16;
-        a.act = o.lrelu | (getenv("VISP_DCONV_DBG") ? atoi(getenv("VISP_DCONV_DBG")) << 4 : 0);
-        a.s1 = o.s1; a.res1 = o.res1; a.res1_ld = o.res1_ld;
-        a.s2 = o.s2; a.res2 = o.res2; a.res2_ld = o.res2_ld;
-        a.out = out; a.ldo = ldo;
+        a.act = o.lrelu;
+        a.s1 = o.s1; a.res1 = o.res1; a.res1_plane = o.res1_plane;
+        a.s2 = o.s2; a.res2 = o.res2; a.res2_plane = o.res2_plane;
+        a.out = out; a.out_plane = out_plane;
         a.x_residual = o.x_residual;
         const double px = (double)n * H * W;
         mark(group, 2.0 * px * 9 * g.cin_real * g.cout_real,
@@ -306,10 +307,12 @@ struct exec {
     void generate(const void* x0, int n, int w, int h, float* out) {
         esrgan_weights const& Wt = m.weights;
         esrgan_workspace& ws = m.ws;
-        const int LD = 192;
-        auto sl = [](void* base, int ch) { return static_cast<void*>(static_cast<uint16_t*>(base) + ch); };
-        conv(Wt.first, x0, 32, 32, n, h, w, ws.fea, 64, {}, "first");
-        conv(Wt.first, x0, 32, 32, n, h, w, ws.d[0], LD, {}, "first");
+        // every activation buffer is planar (32 channels per plane); plane strides are those of the full tile group
+        const int64_t PL = (int64_t)ws.group * w * h * 32;             // low-resolution plane
+        const int64_t PH = PL * ws.scale * ws.scale;                    // plane of the up-sampled maps
+        auto plane = [](void* base, int64_t stride, int k) { return static_cast<void*>(static_cast<uint16_t*>(base) + stride * k); };
+        conv(Wt.first, x0, 0, 32, n, h, w, ws.fea, PL, {}, "first");
+        conv(Wt.first, x0, 0, 32, n, h, w, ws.d[0], PL, {}, "first");
         int a = 0;
         for (auto const& blk : Wt.rdb) { // rrdb, esrgan.cpp:43-51
             void *A = ws.d[a], *B = ws.d[(a + 1) % 3], *C = ws.d[(a + 2) % 3];
@@ -320,38 +323,40 @@ struct exec {
                     opts o;
                     o.lrelu = true;
                     static const char* const names[4] = {"rdb_conv1", "rdb_conv2", "rdb_conv3", "rdb_conv4"};
-                    conv(blk[r][k], src[r], LD, 64 + 32 * k, n, h, w, sl(src[r], 64 + 32 * k), LD, o, names[k]);
+                    conv(blk[r][k], src[r], PL, 64 + 32 * k, n, h, w, plane(src[r], PL, 2 + k), PL, o, names[k]);
                 }
                 opts o;
-                o.s1 = 0.2f; o.x_residual = true; // x5*0.2 + x, x = channels 0..63 of the halo the conv already holds
-                if (r == 2) { o.s2 = 0.2f; o.res2 = A; o.res2_ld = LD; }
-                conv(blk[r][4], src[r], LD, 192, n, h, w, dst[r], LD, o, "rdb_conv5");
+                o.s1 = 0.2f; o.x_residual = true; // x5*0.2 + x, x = planes 0,1 of the halo the conv already holds
+                if (r == 2) { o.s2 = 0.2f; o.res2 = A; o.res2_plane = PL; }
+                conv(blk[r][4], src[r], PL, 192, n, h, w, dst[r], PL, o, "rdb_conv5");
             }
             a = (a + 1) % 3;
         }
         {
             opts o;
-            o.res1 = ws.fea; o.res1_ld = 64;
-            conv(Wt.trunk, ws.d[a], LD, 64, n, h, w, ws.tr, 64, o, "trunk");
+            o.res1 = ws.fea; o.res1_plane = PL;
+            conv(Wt.trunk, ws.d[a], PL, 64, n, h, w, ws.tr, PL, o, "trunk");
         }
         const void* cur = ws.tr;
+        int64_t cur_plane = PL;
         void* nxt[2] = {ws.hr_a, ws.hr_b};
         int flip = 0, cw = w, ch = h;
         for (packed_dconv const& u : Wt.up) { // esrgan::upsample, esrgan.cpp:13-19
             cw *= 2; ch *= 2;
             opts o;
             o.up2 = true; o.lrelu = true;
-            conv(u, cur, 64, 64, n, ch, cw, nxt[flip], 64, o, "upconv");
+            conv(u, cur, cur_plane, 64, n, ch, cw, nxt[flip], PH, o, "upconv");
             cur = nxt[flip];
+            cur_plane = PH;
             flip ^= 1;
         }
         {
             opts o;
             o.lrelu = true;
-            conv(Wt.hr, cur, 64, 64, n, ch, cw, nxt[flip], 64, o, "hrconv");
+            conv(Wt.hr, cur, cur_plane, 64, n, ch, cw, nxt[flip], PH, o, "hrconv");
             opts l;
             l.rgb = true;
-            conv(Wt.last, nxt[flip], 64, 64, n, ch, cw, out, 3, l, "last");
+            conv(Wt.last, nxt[flip], PH, 64, n, ch, cw, out, 0, l, "last");
         }
     }
 };

@@ -3,9 +3,10 @@
 //  x5*0.2 + x, nearest x2 upsample before the up-convs).
 //
 // What is different from the DPT halo kernel (kernels_conv.hip):
-//  * the input is a CHANNEL PREFIX of a wider pixel row (x_ld elements per pixel): a residual dense block keeps
-//    [x | x1 | x2 | x3 | x4] in one [pixels][192] buffer, every conv reads the first 64+32k channels and writes its
-//    32 outputs into the next channel slice, so the reference's four concat copies never happen;
+//  * activations are PLANAR in groups of 32 channels: a map is [C/32 planes][pixels][32] f16 (plane stride given by
+//    the caller). A residual dense block keeps [x | x1 | x2 | x3 | x4] as six planes of one buffer, every conv reads
+//    the first 2+k planes and writes its 32 outputs as the next plane, so the reference's four concat copies never
+//    happen -- and a chunk's halo row is one contiguous 2 KB run in HBM, a tile's output rows likewise;
 //  * Cin is walked in chunks of 32 channels: a chunk's 18x34 halo (39 KB) and its weight slab 9 x COUT x 32
 //    (18/36 KB, pre-swizzled at load time so the copy is linear) are streamed by LDS-DMA into a 2-stage ring while
 //    the MFMAs of the previous chunk run; ONE barrier per chunk. Weights come from LDS, not from L1: with 8 waves
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     const int Hs = H >> up, Ws = W >> up;
     const int nch = p.cin / CK;
     const int nch_total_bytes = nch * 9 * COUT * PIXB;
+    const long x_plane_bytes = p.x_plane * 2;
 
     // ---- tile geometry (wave-uniform) and per-lane halo sources
     struct geom { int b, y0, x0, tws; }; // tws = log2(tile width): 5 (16x32) or 4 (32x16)
@@ -143,22 +145,24 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     __amdgpu_buffer_rsrc_t x_rsrc;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, nch_total_bytes, 0x00020000);
     auto setup_src = [&](const geom& g) {
-        const long img_bytes = (long)Hs * Ws * p.x_ld * 2;
-        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + g.b * img_bytes, 0, (int)img_bytes, 0x00020000);
+        const long img_bytes = (long)Hs * Ws * (CK * 2);
+        // the descriptor spans image b of plane 0 .. image b of the last plane; chunk c is reached by a scalar offset
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + g.b * img_bytes, 0,
+                                                   (int)((nch - 1) * x_plane_bytes + img_bytes), 0x00020000);
 #pragma unroll
         for (int j = 0; j < HJ; ++j) {
             unsigned pk = hpack[j];
             asm volatile("" : "+v"(pk)); // keep the unpacked fields out of registers across the tile loop
             const int iy = g.y0 - 1 + (int)(pk & 0xff), ix = g.x0 - 1 + (int)((pk >> 8) & 0xff);
             const bool valid = (pk >> 24) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int e = ((iy >> up) * Ws + (ix >> up)) * p.x_ld + (int)(((pk >> 16) & 3) << 3);
+            const int e = ((iy >> up) * Ws + (ix >> up)) * CK + (int)(((pk >> 16) & 3) << 3);
             hoff[j] = valid ? (unsigned)(e * 2) : OOB;
         }
     };
     auto issue_halo = [&](int c, int hstage) {
 #pragma unroll
         for (int j = 0; j < HJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + hstage * HALO_BYTES + (wave + j * NW) * 1024), 16, hoff[j], c * (CK * 2), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + hstage * HALO_BYTES + (wave + j * NW) * 1024), 16, hoff[j], c * (int)x_plane_bytes, 0, 0);
     };
     auto issue_slab = [&](int c, int wstage) {
 #pragma unroll
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             constexpr int ROWS_PER_IT = 64 / NCH16;
             constexpr int NB = 4; // iterations whose loads are in flight together
             const int j = lane % NCH16;
+            const int jp = j >> 2, je = (j & 3) * 8; // plane of the lane's 8 channels, element offset inside the pixel
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-local hand-over of the staged rows: no block barrier
             const float s1 = p.s1, s2 = p.s2;
 #pragma unroll
@@ -400,11 +405,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                 }
                 if (R1) {
 #pragma unroll
-                    for (int it = 0; it < NB; ++it) ra[it] = *reinterpret_cast<const f16x8*>(R1 + pixel[it] * p.res1_ld + j * 8);
+                    for (int it = 0; it < NB; ++it) ra[it] = *reinterpret_cast<const f16x8*>(R1 + jp * p.res1_plane + pixel[it] * CK + je);
                 }
                 if (R2) {
 #pragma unroll
-                    for (int it = 0; it < NB; ++it) rc[it] = *reinterpret_cast<const f16x8*>(R2 + pixel[it] * p.res2_ld + j * 8);
+                    for (int it = 0; it < NB; ++it) rc[it] = *reinterpret_cast<const f16x8*>(R2 + jp * p.res2_plane + pixel[it] * CK + je);
                 }
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s2 + (float)rc[it][q]);
                     }
-                    f16* dst = ok[it] ? reinterpret_cast<f16*>(p.out) + pixel[it] * p.ldo + j * 8 : trash;
+                    f16* dst = ok[it] ? reinterpret_cast<f16*>(p.out) + jp * p.out_plane + pixel[it] * CK + je : trash;
                     *reinterpret_cast<f16x8*>(dst) = v[it];
                 }
             }
@@ -581,19 +586,25 @@ __global__ void esr_tiles_out_kernel(const float* __restrict__ tiles, int B, vx_
 extern "C" int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream) {
     const vx_dconv_args& a = *args;
     VX_REQUIRE(a.x && a.w && a.out, "vx_dconv3x3_f16: null operand");
-    VX_REQUIRE(a.cin >= 32 && a.cin % 32 == 0 && a.x_ld >= a.cin && a.x_ld % 8 == 0, "vx_dconv3x3_f16: Cin %d / pixel stride %d must be multiples of 32 / 8", a.cin, a.x_ld);
+    VX_REQUIRE(a.cin >= 32 && a.cin % 32 == 0, "vx_dconv3x3_f16: Cin %d must be a multiple of 32", a.cin);
     VX_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "vx_dconv3x3_f16: empty extent");
     VX_REQUIRE(!a.up2 || (a.H % 2 == 0 && a.W % 2 == 0), "vx_dconv3x3_f16: upsampled extent must be even");
     VX_REQUIRE((reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(a.out) & 15) == 0, "vx_dconv3x3_f16: operands must be 16-byte aligned");
+    {
+        const int64_t src_pixels = (int64_t)(a.H >> (a.up2 ? 1 : 0)) * (a.W >> (a.up2 ? 1 : 0));
+        VX_REQUIRE(a.cin == 32 || (a.x_plane >= (int64_t)a.B * src_pixels * 32 && a.x_plane % 8 == 0), "vx_dconv3x3_f16: bad input plane stride");
+        // buffer descriptors address with 32-bit offsets; 2^31 is the zero-fill sentinel
+        VX_REQUIRE((int64_t)(a.cin / 32 - 1) * a.x_plane * 2 + src_pixels * 64 < (int64_t)0x7fffffff,
+                   "vx_dconv3x3_f16: input planes span more than 2 GiB; run fewer images per call");
+    }
     hipStream_t s = as_stream(stream);
     if (a.epi == VX_DC_RGB_F32) {
         VX_REQUIRE(a.cout == 32, "vx_dconv3x3_f16: the rgb head takes weights padded to 32 outputs");
         return launch_dconv<32, VX_DC_RGB_F32>(a, s);
     }
     VX_REQUIRE(a.epi == VX_DC_F16, "vx_dconv3x3_f16: unknown epilogue %d", a.epi);
-    VX_REQUIRE(a.ldo % 8 == 0 && (!a.res1 || a.res1_ld % 8 == 0) && (!a.res2 || a.res2_ld % 8 == 0),
-               "vx_dconv3x3_f16: output/residual pixel strides must be multiples of 8");
+    VX_REQUIRE(a.out_plane % 8 == 0 && a.res1_plane % 8 == 0 && a.res2_plane % 8 == 0, "vx_dconv3x3_f16: plane strides must be multiples of 8");
     VX_REQUIRE(!a.x_residual || (a.cout == 64 && a.cin >= 64 && !a.res1 && !a.up2 && a.s1 != 0.0f),
                "vx_dconv3x3_f16: x_residual needs cout = 64 <= cin, no res1, no upsampling");
     if (a.cout == 32) return launch_dconv<32, VX_DC_F16>(a, s);
