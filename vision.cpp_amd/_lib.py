@@ -39,7 +39,7 @@ class DconvArgs(ctypes.Structure):  # == vx_dconv_args
         ("x", c_void_p), ("x_plane", c_int64), ("cin", c_int), ("up2", c_int), ("B", c_int), ("H", c_int), ("W", c_int),
         ("w", c_void_p), ("bias", c_void_p), ("cout", c_int), ("epi", c_int), ("act", c_int),
         ("s1", c_float), ("res1", c_void_p), ("res1_plane", c_int64), ("s2", c_float), ("res2", c_void_p), ("res2_plane", c_int64),
-        ("out", c_void_p), ("out_plane", c_int64), ("x_residual", c_int),
+        ("out", c_void_p), ("out_plane", c_int64), ("x_residual", c_int), ("stamps", c_void_p),
     ]
 
 
