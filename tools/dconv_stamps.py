@@ -15,7 +15,7 @@ from tests import gpu_util as G  # noqa: E402
 from visioncpp_amd import _lib as L  # noqa: E402
 
 
-def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3, alias=False, abl=0):
+def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3):
     rng = np.random.default_rng(0)
     planes = max(cin // 32, 6)
     x = G.dev((rng.standard_normal((planes, B, H, W, 32)) * 0.5).astype(np.float16))
@@ -28,7 +28,7 @@ def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3, alias=False, ab
     a.x, a.x_plane, a.cin = x.ptr, B * H * W * 32, cin
     a.B, a.H, a.W = B, H, W
     a.w, a.bias, a.cout = wd.ptr, bd.ptr, cout
-    a.epi, a.act, a.s1, a.s2 = L.DC_F16, 1 | (2 if alias else 0) | abl, 0.2, 1.0
+    a.epi, a.act, a.s1, a.s2 = L.DC_F16, 1, 0.2, 1.0
     a.out, a.out_plane = out.ptr, B * H * W * 32
     a.x_residual = int(x_residual)
     api = G.api()
@@ -51,7 +51,7 @@ def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3, alias=False, ab
     flops = 2.0 * B * H * W * 9 * cin * cout
     us = ms.value / reps * 1e3
     names = ["dma_wait", "barrier", "mfma+feed", "cursor", "epilogue", "tile_setup"]
-    print(f"cin {cin:3d} cout {cout:2d}{' xres' if x_residual else ''}{' ALIAS' if alias else ''}{' NO-DMA' if abl & 4 else ''}{' NO-MFMA' if abl & 8 else ''}: {us:7.1f} us  {flops / us / 1e6:7.1f} TFLOP/s   steps/block {steps.mean():.1f}  "
+    print(f"cin {cin:3d} cout {cout:2d}{' xres' if x_residual else ''}: {us:7.1f} us  {flops / us / 1e6:7.1f} TFLOP/s   steps/block {steps.mean():.1f}  "
           f"cycles/step: " + "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, per)) + f"  total {per.sum():6.0f}")
     G.release()
 
@@ -59,6 +59,3 @@ def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3, alias=False, ab
 if __name__ == "__main__":
     for cin, cout, xr in [(64, 32, False), (96, 32, False), (128, 32, False), (160, 32, False), (192, 64, True), (64, 64, False)]:
         run(cin, cout, x_residual=xr)
-        run(cin, cout, x_residual=xr, abl=4)
-        run(cin, cout, x_residual=xr, abl=8)
-        run(cin, cout, x_residual=xr, abl=12)

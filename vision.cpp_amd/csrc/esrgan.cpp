@@ -292,7 +292,7 @@ struct exec {
         a.B = n; a.H = H; a.W = W;
         a.w = wa + g.w; a.bias = reinterpret_cast<const float*>(wa + g.b); a.cout = g.cout;
         a.epi = o.rgb ? VX_DC_RGB_F32 : VX_DC_F16;
-        a.act = o.lrelu | (getenv("VISP_DCONV_DBG") ? atoi(getenv("VISP_DCONV_DBG")) << 4 : 0);
+        a.act = o.lrelu;
         a.s1 = o.s1; a.res1 = o.res1; a.res1_plane = o.res1_plane;
         a.s2 = o.s2; a.res2 = o.res2; a.res2_plane = o.res2_plane;
         a.out = out; a.out_plane = out_plane;

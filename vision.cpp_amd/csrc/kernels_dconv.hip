@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     auto setup_src = [&](const geom& g) {
         const long img_bytes = (long)Hs * Ws * (CK * 2);
         // the descriptor spans image b of plane 0 .. image b of the last plane; chunk c is reached by a scalar offset
-        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + ((p.act & 2) ? 0 : g.b) * img_bytes, 0,
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + g.b * img_bytes, 0,
                                                    (int)((nch - 1) * x_plane_bytes + img_bytes), 0x00020000);
 #pragma unroll
         for (int j = 0; j < HJ; ++j) {
@@ -191,43 +191,48 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         for (int j = 0; j < WJ; ++j) slab_piece(j, c, wslot);
     };
 
-    // ---- fragment addresses: chunk-invariant, depend on the tile shape only
-    int a_addr[9][MT][2];
+    // ---- pixel fragments. A wave owns MT = 2 M-tiles of 32 pixels; M-tile mi and tap row ky read WINDOW mi + ky of
+    // the halo, so the wave needs only MT + 2 = 4 distinct windows per tap column kx instead of 6 fragments (the LDS
+    // read port, not the MFMA pipe, bounds this loop: 54 -> 42 / 72 -> 60 ds_read_b128 per wave and step).
+    //   16x32 tile: window u = halo row 2*wave + u, pixel r -> halo column r + kx
+    //   32x16 tile: window u = halo rows 4*wave + u and 4*wave + u + 2 (lanes r >= 16), halo column (r & 15) + kx
+    // and M-tile mi holds output rows 2*wave + mi, resp. 4*wave + mi (+2).
+    constexpr int NWIN = MT + 2;
+    int a_addr[3][NWIN][2]; // chunk-invariant, depend on the tile shape only
     auto setup_addr = [&](int tws) {
         const int hw = (1 << tws) + 2;
+        const int row0 = tws == 5 ? 2 * wave : 4 * wave + 2 * (r >> 4), col0 = tws == 5 ? r : (r & 15);
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int f = (wave * MT + mi) * 32 + r;
-            const int trow = f >> tws, tcol = f & ((1 << tws) - 1);
+        for (int u = 0; u < NWIN; ++u)
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int pix = (trow + tap / 3) * hw + tcol + tap % 3;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int pix = (row0 + u) * hw + col0 + kx;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) a_addr[tap][mi][ks] = pix * PIXB + (((ks * 2 + h) ^ ((pix >> 2) & 3)) << 4);
+                for (int ks = 0; ks < 2; ++ks) a_addr[kx][u][ks] = pix * PIXB + (((ks * 2 + h) ^ ((pix >> 2) & 3)) << 4);
             }
-        }
     };
+    // output position of lane r in M-tile mi (tile coordinates)
+    auto out_row = [&](int tws, int mi) { return tws == 5 ? 2 * wave + mi : 4 * wave + mi + 2 * (r >> 4); };
+    auto out_col = [&](int tws) { return tws == 5 ? r : (r & 15); };
     int w_addr[2]; // slab slot 0; other slots are + slot * W_BYTES (an immediate for the 2-stage ring)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) w_addr[ks] = W_BASE + r * PIXB + (((ks * 2 + h) ^ ((r >> 2) & 3)) << 4);
 
     f32x16 acc[MT][NI];
 
-    // fragments are prefetched one GROUP of k-steps ahead (register double buffer): a whole tap (2 k-steps) for
-    // COUT = 32, one k-step for COUT = 64 where the accumulators leave fewer registers
-    constexpr int G = COUT == 32 ? 2 : 1;
-    auto load_group = [&](auto hs_c, auto ws_c, int wslot_off, int grp, f16x8 (&af)[G][MT], f16x8 (&wf)[G][NI]) {
+    // fragment groups: one (tap column kx, k-step ks) = 3 weight fragments per N-tile + 4 pixel windows for 6 NI
+    // MFMAs, prefetched one group ahead (register double buffer)
+    constexpr int NGRP = 6;
+    auto load_group = [&](auto hs_c, auto ws_c, int wslot_off, int grp, f16x8 (&af)[NWIN], f16x8 (&wf)[3][NI]) {
         constexpr int HSt = decltype(hs_c)::value, WSt = decltype(ws_c)::value;
+        const int kx = grp >> 1, ks = grp & 1;
 #pragma unroll
-        for (int q = 0; q < G; ++q) {
-            const int step = grp * G + q, tap = step >> 1, ks = step & 1;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                wf[q][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[ks] + wslot_off + (RES ? 0 : WSt * W_BYTES) + (tap * COUT + ni * 32) * PIXB);
+                wf[ky][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[ks] + wslot_off + (RES ? 0 : WSt * W_BYTES) + ((ky * 3 + kx) * COUT + ni * 32) * PIXB);
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                af[q][mi] = *reinterpret_cast<const f16x8*>(smem + a_addr[tap][mi][ks] + HSt * HALO_BYTES);
-        }
+        for (int u = 0; u < NWIN; ++u) af[u] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][u][ks] + HSt * HALO_BYTES);
     };
     // x_residual (COUT = 64): "+ x" of a dense block's last conv (esrgan.cpp:38-40) without reading x again: the
     // centre-tap pixel fragments of chunks 0 and 1 ARE x[0:64], so two extra k-steps per chunk multiply them with
@@ -235,34 +240,35 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     const bool xres = NI == 2 && p.x_residual != 0;
     const f16 inv_s1 = (f16)(1.0f / p.s1);
     auto compute = [&](auto hs_c, auto ws_c, int chunk, auto&& feed) {
-        f16x8 af[2][G][MT], wf[2][G][NI];
+        f16x8 af[2][NWIN], wf[2][3][NI];
         const int wslot_off = RES ? chunk * W_BYTES : 0; // resident slabs: slot = chunk
         load_group(hs_c, ws_c, wslot_off, 0, af[0], wf[0]);
 #pragma unroll
-        for (int grp = 0; grp < 18 / G; ++grp) {
-            if (grp + 1 < 18 / G) load_group(hs_c, ws_c, wslot_off, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
+        for (int grp = 0; grp < NGRP; ++grp) {
+            if (grp + 1 < NGRP) load_group(hs_c, ws_c, wslot_off, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < G; ++q)
+            for (int u = 0; u < NWIN; ++u)
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi) {
+                    const int ky = u - mi;
+                    if (ky < 0 || ky > 2) continue;
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        if (!(p.act & 8)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][q][ni], af[grp & 1][q][mi], acc[mi][ni], 0, 0, 0);
-            feed(grp);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][ky][ni], af[grp & 1][u], acc[mi][ni], 0, 0, 0);
+                }
+            feed(2 * grp);
+            feed(2 * grp + 1);
             if constexpr (NI == 2) {
-                if ((grp * G) >> 1 == 4 && xres && chunk < 2) { // centre tap
+                if ((grp >> 1) == 1 && xres && chunk < 2) { // centre tap column; centre tap of M-tile mi = window mi + 1
+                    const int ks = grp & 1;
+                    f16x8 id;
 #pragma unroll
-                    for (int q = 0; q < G; ++q) {
-                        const int ks = (grp * G + q) & 1;
-                        f16x8 id;
+                    for (int j = 0; j < 8; ++j) id[j] = (r == ks * 16 + h * 8 + j) ? inv_s1 : (f16)0;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) id[j] = (r == ks * 16 + h * 8 + j) ? inv_s1 : (f16)0;
-#pragma unroll
-                        for (int mi = 0; mi < MT; ++mi) {
-                            if (chunk == 0) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id, af[grp & 1][q][mi], acc[mi][0], 0, 0, 0);
-                            else acc[mi][NI - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id, af[grp & 1][q][mi], acc[mi][NI - 1], 0, 0, 0);
-                        }
+                    for (int mi = 0; mi < MT; ++mi) {
+                        if (chunk == 0) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id, af[grp & 1][mi + 1], acc[mi][0], 0, 0, 0);
+                        else acc[mi][NI - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id, af[grp & 1][mi + 1], acc[mi][NI - 1], 0, 0, 0);
                     }
                 }
             }
@@ -364,9 +370,9 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         constexpr int NSLAB = RES ? 0 : WJ;
         compute(hs_c, ws_c, c, [&](int k) {
             if (k < NSLAB) {
-                if (do_slab && !(p.act & 4)) slab_piece(k, slab_c, WSt ^ 1);
+                if (do_slab) slab_piece(k, slab_c, WSt ^ 1);
             } else if (k - NSLAB < HJ) {
-                if (do_halo && !(p.act & 4)) halo_piece(k - NSLAB, halo_c, HNEXT);
+                if (do_halo) halo_piece(k - NSLAB, halo_c, HNEXT);
             }
         });
         stamp(2); // MFMA loop with the DMA pieces of the steps ahead
@@ -376,7 +382,6 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         ++n_steps;
         if (++c < nch) return false;
 
-        const int tw_mask = (1 << cur.tws) - 1;
 
         // ---- epilogue
         if constexpr (EPI == VX_DC_RGB_F32) {
@@ -384,8 +389,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             if (h == 0) {
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
-                    const int f = (wave * MT + mi) * 32 + r;
-                    const int oy = cur.y0 + (f >> cur.tws), ox = cur.x0 + (f & tw_mask);
+                    const int oy = cur.y0 + out_row(cur.tws, mi), ox = cur.x0 + out_col(cur.tws);
                     if (oy < H && ox < W) {
                         float* o = reinterpret_cast<float*>(p.out) + (((long)cur.b * H + oy) * W + ox) * 3;
                         o[0] = acc[mi][0][0] + s_bias[0];
@@ -408,8 +412,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             const float s1 = p.s1, s2 = p.s2;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
-                const int f = (wave * MT + mi) * 32 + r;
-                const int oy = cur.y0 + (f >> cur.tws), ox = cur.x0 + (f & tw_mask);
+                const int oy = cur.y0 + out_row(cur.tws, mi), ox = cur.x0 + out_col(cur.tws);
                 const bool ok = oy < H && ox < W;
                 const long pixel = ((long)cur.b * H + min(oy, H - 1)) * W + min(ox, W - 1);
 #pragma unroll
