@@ -68,7 +68,10 @@ class GemmArgs(ctypes.Structure):  # == vx_gemm_args
 
 EPI_F16, EPI_F16_GELU, EPI_F16_RELU, EPI_RESID_F32, EPI_TOKENS, EPI_QKV, EPI_PIXSHUF, EPI_F16_ADD, EPI_HEAD_OUT = range(9)
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvisioncpp.so"
+import os
+
+# VISP_LIBRARY selects another build of the same ABI (same-box A/B comparisons of kernel variants)
+LIB_PATH = Path(os.environ["VISP_LIBRARY"]).resolve() if os.environ.get("VISP_LIBRARY") else Path(__file__).resolve().parent / "lib" / "libvisioncpp.so"
 
 # every symbol include/visp_c_api.h and include/visp_hip_kernels.h declare
 C_API_SYMBOLS = [

@@ -55,9 +55,7 @@ struct tile_grid {
     __host__ __device__ int total() const { return n_main + n_strip; }
 };
 
-// HS = halo ring stages. RES = number of weight slabs kept RESIDENT in LDS for the whole launch (the conv's cin/32
-// chunks all fit), 0 = slabs stream through a 2-stage ring next to the halos.
-template <int COUT, int EPI, int HS, int RES>
+template <int COUT, int EPI>
 __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     constexpr int MT = 2;                       // M-tiles (32 pixels) per wave
     constexpr int HALO_PIX = 18 * 34;           // both tile shapes
@@ -70,15 +68,14 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     constexpr int NI = COUT / 32;
     constexpr int W_BYTES = 9 * COUT * PIXB, W_INSTR = W_BYTES / 1024;
     constexpr int WJ = (W_INSTR + NW - 1) / NW;
-    // The kernel is bound by the LDS-DMA stream (58/77 KB per 36/72 MFMAs per wave): by bytes in flight per CU --
-    // hence a THIRD halo stage where the LDS has room (halos issued two steps ahead) -- and by the slab stream,
-    // which every CU repeats per tile although it is the same 18/36 KB: where all of a conv's slabs fit (conv1-3 of
-    // a dense block, the 64 -> 64 convs) they are loaded once per block and stay.
-    constexpr int WS = RES ? RES : 2;           // slab slots
-    constexpr int W_BASE = HS * HALO_BYTES;     // LDS: [halo 0 .. HS-1 | slab slots | bias]
-    constexpr int BIAS_BASE = W_BASE + WS * W_BYTES;
-    constexpr int NSTORE = MT * NI * 4;         // 8-byte store instructions per wave and tile
+    // The kernel is bound by the LDS-DMA stream (57/77 KB per 36/72 MFMAs per wave), i.e. by bytes in flight per
+    // CU: with COUT = 32 the LDS has room for a THIRD halo stage, so halos are issued two steps ahead.
+    constexpr int HS = COUT == 32 ? 3 : 2;      // halo stages; slabs always 2
+    constexpr int W_BASE = HS * HALO_BYTES;     // LDS: [halo 0 .. HS-1 | slab 0 | slab 1 | bias]
+    constexpr int BIAS_BASE = W_BASE + 2 * W_BYTES;
+    constexpr int NCH16 = COUT / 8, PITCH = COUT * 2;
     static_assert(BIAS_BASE + COUT * 4 <= 160 * 1024, "LDS ring too large");
+    static_assert(256 * PITCH <= HALO_BYTES && 256 * PITCH <= W_BYTES + (COUT == 32 ? HALO_BYTES : 0), "output staging does not fit a stage");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* const s_bias = reinterpret_cast<float*>(smem + BIAS_BASE);
@@ -132,8 +129,6 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // loop; halo pixels outside the map use an offset beyond the descriptor's size and are zero-filled by the
     // hardware's range check (conv zero padding, nn.cpp:83-97 pad = 1).
     constexpr unsigned OOB = 0x80000000u;
-    // (non-temporal halo loads, aux = 2, to protect the slabs in L2 were measured 4 % slower)
-    constexpr int HALO_AUX = 0;
     unsigned hoff[HJ];  // byte offset of the lane's 16 bytes (chunk 0) inside the image the halo cursor is in
     unsigned hpack[HJ]; // shape-dependent, tile-invariant part: halo row | halo col << 8 | swizzled group << 16 | valid << 24
     auto setup_shape_src = [&](int tws) {
@@ -177,8 +172,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     auto slab_piece = [&](int j, int c, int wslot) {
         const int i = wave + j * NW;
         if (i < W_INSTR) {
-            int ir = i + slab_rot;
-            ir = ir >= W_INSTR ? ir - W_INSTR : ir;
+            int ir = i;
+            if constexpr (COUT == 64) { // (COUT = 32: constant offsets, the rotation bought nothing measurable there)
+                ir += slab_rot;
+                ir = ir >= W_INSTR ? ir - W_INSTR : ir;
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem + W_BASE + wslot * W_BYTES + ir * 1024), 16, lane * 16, c * W_BYTES + ir * 1024, 0, 0);
         }
     };
@@ -214,23 +212,25 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // output position of lane r in M-tile mi (tile coordinates)
     auto out_row = [&](int tws, int mi) { return tws == 5 ? 2 * wave + mi : 4 * wave + mi + 2 * (r >> 4); };
     auto out_col = [&](int tws) { return tws == 5 ? r : (r & 15); };
-    int w_addr[2]; // slab slot 0; other slots are + slot * W_BYTES (an immediate for the 2-stage ring)
+    int w_addr[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) w_addr[ks] = W_BASE + r * PIXB + (((ks * 2 + h) ^ ((r >> 2) & 3)) << 4);
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w_addr[st][ks] = W_BASE + st * W_BYTES + r * PIXB + (((ks * 2 + h) ^ ((r >> 2) & 3)) << 4);
 
     f32x16 acc[MT][NI];
 
     // fragment groups: one (tap column kx, k-step ks) = 3 weight fragments per N-tile + 4 pixel windows for 6 NI
     // MFMAs, prefetched one group ahead (register double buffer)
     constexpr int NGRP = 6;
-    auto load_group = [&](auto hs_c, auto ws_c, int wslot_off, int grp, f16x8 (&af)[NWIN], f16x8 (&wf)[3][NI]) {
+    auto load_group = [&](auto hs_c, auto ws_c, int grp, f16x8 (&af)[NWIN], f16x8 (&wf)[3][NI]) {
         constexpr int HSt = decltype(hs_c)::value, WSt = decltype(ws_c)::value;
         const int kx = grp >> 1, ks = grp & 1;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                wf[ky][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[ks] + wslot_off + (RES ? 0 : WSt * W_BYTES) + ((ky * 3 + kx) * COUT + ni * 32) * PIXB);
+                wf[ky][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[WSt][ks] + ((ky * 3 + kx) * COUT + ni * 32) * PIXB);
 #pragma unroll
         for (int u = 0; u < NWIN; ++u) af[u] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][u][ks] + HSt * HALO_BYTES);
     };
@@ -239,13 +239,12 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // (1/s1) * identity (exact in f16) into the matching channel tile; the epilogue's * s1 makes it "+ x".
     const bool xres = NI == 2 && p.x_residual != 0;
     const f16 inv_s1 = (f16)(1.0f / p.s1);
-    auto compute = [&](auto hs_c, auto ws_c, int chunk, auto&& feed) {
+    auto compute_win = [&](auto hs_c, auto ws_c, int chunk, auto&& feed) {
         f16x8 af[2][NWIN], wf[2][3][NI];
-        const int wslot_off = RES ? chunk * W_BYTES : 0; // resident slabs: slot = chunk
-        load_group(hs_c, ws_c, wslot_off, 0, af[0], wf[0]);
+        load_group(hs_c, ws_c, 0, af[0], wf[0]);
 #pragma unroll
         for (int grp = 0; grp < NGRP; ++grp) {
-            if (grp + 1 < NGRP) load_group(hs_c, ws_c, wslot_off, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
+            if (grp + 1 < NGRP) load_group(hs_c, ws_c, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < NWIN; ++u)
@@ -273,6 +272,61 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                 }
             }
         }
+    };
+    // COUT = 64 keeps the per-tap loop (one k-step of fragments ahead): its 2 x 2 register blocking already reads
+    // one fragment per MFMA, and the wider groups of the window loop cost it 6 % (measured on the same device)
+    // fragments are prefetched one GROUP of k-steps ahead (register double buffer): a whole tap (2 k-steps) for
+    // COUT = 32, one k-step for COUT = 64 where the accumulators leave fewer registers
+    constexpr int G = 1;
+    auto load_group_tap = [&](auto hs_c, auto ws_c, int grp, f16x8 (&af)[G][MT], f16x8 (&wf)[G][NI]) {
+        constexpr int HSt = decltype(hs_c)::value, WSt = decltype(ws_c)::value;
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const int step = grp * G + q, tap = step >> 1, ks = step & 1;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                wf[q][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[WSt][ks] + (tap * COUT + ni * 32) * PIXB);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                af[q][mi] = *reinterpret_cast<const f16x8*>(smem + a_addr[tap % 3][mi + tap / 3][ks] + HSt * HALO_BYTES);
+        }
+    };
+    auto compute_tap = [&](auto hs_c, auto ws_c, int chunk, auto&& feed) {
+        f16x8 af[2][G][MT], wf[2][G][NI];
+        load_group_tap(hs_c, ws_c, 0, af[0], wf[0]);
+#pragma unroll
+        for (int grp = 0; grp < 18 / G; ++grp) {
+            if (grp + 1 < 18 / G) load_group_tap(hs_c, ws_c, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][q][ni], af[grp & 1][q][mi], acc[mi][ni], 0, 0, 0);
+            feed(grp);
+            if constexpr (NI == 2) {
+                if ((grp * G) >> 1 == 4 && xres && chunk < 2) { // centre tap
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {
+                        const int ks = (grp * G + q) & 1;
+                        f16x8 id;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) id[j] = (r == ks * 16 + h * 8 + j) ? inv_s1 : (f16)0;
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) {
+                            if (chunk == 0) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id, af[grp & 1][q][mi], acc[mi][0], 0, 0, 0);
+                            else acc[mi][NI - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id, af[grp & 1][q][mi], acc[mi][NI - 1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    auto compute = [&](auto hs_c, auto ws_c, int chunk, auto&& feed) {
+        if constexpr (COUT == 32) compute_win(hs_c, ws_c, chunk, feed);
+        else compute_tap(hs_c, ws_c, chunk, feed);
     };
     auto zero_acc = [&]() {
 #pragma unroll
@@ -314,11 +368,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         move_cursor();
         return true;
     };
-    if constexpr (RES) {
-        for (int k = 0; k < nch; ++k) issue_slab(k, k); // all slabs, once (older than every halo: the first wait covers them)
-    } else {
-        issue_slab(0, 0);
-    }
+    issue_slab(0, 0);
     bool prev_halo = false; // did the previous step issue a halo (younger than the slab this step waits for)?
 #pragma unroll
     for (int k = 0; k < HS - 1; ++k) prev_halo = advance_halo(k);
@@ -326,17 +376,6 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     zero_acc();
     int c = 0; // chunk of the current tile
     bool stores_in_flight = false;
-    // diagnostics (p.stamps != NULL): shader-clock cycles per phase, summed over the block's steps by wave 0
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
-    unsigned n_steps = 0;
-    const bool stamping = p.stamps != nullptr;
-    auto stamp = [&](int k) {
-        if (!stamping) return;
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        ph[k] += t - t_prev;
-        t_prev = t;
-    };
-    if (stamping) t_prev = __builtin_amdgcn_s_memtime();
     f16* const trash = reinterpret_cast<f16*>(g_dconv_trash + ((blockIdx.x % TRASH_BLOCKS) * 8 + wave) * 1024 + lane * 16);
 
     // One step, computed out of halo stage HSt and slab stage WSt. The HS x 2 instantiations run back to back in
@@ -348,40 +387,47 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         {
             const bool st = EPI == VX_DC_F16 && stores_in_flight;
             if (HS == 3 && prev_halo) {
-                if (st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HJ + NSTORE) : "memory");
+                if (st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HJ + NCH16) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HJ) : "memory");
             } else {
-                if (st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+                if (st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH16) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
         stores_in_flight = false;
-        stamp(0); // waited for the step's DMA
         // raw s_barrier: __syncthreads() carries a fence that drains vmcnt, i.e. the halo prefetched for later steps
         __builtin_amdgcn_s_barrier(); // the step's data is in LDS for everyone; everyone has left the previous step's stages
         asm volatile("" ::: "memory");
-        stamp(1); // barrier
         const bool last_chunk = c + 1 == nch;
-        const bool do_slab = !RES && (!last_chunk || t_cur + t_step < t_end);
+        const bool do_slab = !last_chunk || t_cur + t_step < t_end;
         const int slab_c = last_chunk ? 0 : c + 1;
         const bool do_halo = h_t < t_end;
         const int halo_c = h_c;
         constexpr int HNEXT = (HSt + HS - 1) % HS;
-        constexpr int NSLAB = RES ? 0 : WJ;
-        compute(hs_c, ws_c, c, [&](int k) {
-            if (k < NSLAB) {
-                if (do_slab) slab_piece(k, slab_c, WSt ^ 1);
-            } else if (k - NSLAB < HJ) {
-                if (do_halo) halo_piece(k - NSLAB, halo_c, HNEXT);
+        if constexpr (COUT == 32) {
+            // 36 MFMAs per step: the 8 DMA pieces go out in one burst before the loop (measured 2-3 % faster than
+            // feeding them from inside it)
+            if (do_slab) issue_slab(slab_c, WSt ^ 1);
+            if (do_halo) {
+                issue_halo(halo_c, HNEXT);
+                move_cursor(); // the next tile's halo sources are set up while the pieces are on their way
             }
-        });
-        stamp(2); // MFMA loop with the DMA pieces of the steps ahead
-        if (do_halo) move_cursor();
+            compute(hs_c, ws_c, c, [](int) {});
+        } else {
+            // 72 MFMAs per step: piece k of the ring is issued after the k-th k-step's MFMAs (3 % faster)
+            compute(hs_c, ws_c, c, [&](int k) {
+                if (k < WJ) {
+                    if (do_slab) slab_piece(k, slab_c, WSt ^ 1);
+                } else if (k - WJ < HJ) {
+                    if (do_halo) halo_piece(k - WJ, halo_c, HNEXT);
+                }
+            });
+        }
+        if (COUT == 64 && do_halo) move_cursor();
         prev_halo = do_halo;
-        stamp(3); // next tile's halo sources
-        ++n_steps;
         if (++c < nch) return false;
 
+        constexpr int done = HSt; // the halo stage of the last chunk: free once every wave has left compute()
 
         // ---- epilogue
         if constexpr (EPI == VX_DC_RGB_F32) {
@@ -402,52 +448,92 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             prev_halo = false;
         } else {
-            // straight from the accumulators: a lane owns pixel r and channels 8g+4h..+3 of every 32-channel plane,
-            // lanes h = 0/1 of a pixel write adjacent 8-byte halves. No LDS staging, hence no barrier in front of
-            // the epilogue: a wave that leaves its MFMA loop early stores while the others still compute. Out-of-map
-            // pixels store to the trash page so that every wave issues the same number of stores.
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // every wave is done reading stage `done`: its space stages the f16 tile
+            asm volatile("" ::: "memory");
+            // rows 0..255 (waves 0-3) in the halo space of the stage, rows 256..511 (waves 4-7) in the slab space
+            // of the step (COUT = 32: both halves fit the halo space); each wave stages and drains its own 64 rows
+            unsigned char* st;
+            if constexpr (COUT == 32) st = smem + done * HALO_BYTES + wave * 64 * PITCH;
+            else st = (wave < 4 ? smem + done * HALO_BYTES : smem + W_BASE + WSt * W_BYTES) + (wave & 3) * 64 * PITCH;
             const bool lrelu = (p.act & 1) != 0;
-            const f16* __restrict__ R1 = reinterpret_cast<const f16*>(p.res1);
-            const f16* __restrict__ R2 = reinterpret_cast<const f16*>(p.res2);
-            const float s1 = p.s1, s2 = p.s2;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
-                const int oy = cur.y0 + out_row(cur.tws, mi), ox = cur.x0 + out_col(cur.tws);
-                const bool ok = oy < H && ox < W;
-                const long pixel = ((long)cur.b * H + min(oy, H - 1)) * W + min(ox, W - 1);
+                const int ml = mi * 32 + r; // row inside the wave's staging block
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    f16x4 ra[4], rc[4];
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = ni * 32 + 8 * g + 4 * h;
+                        const float4 bias = *reinterpret_cast<const float4*>(s_bias + nl);
+                        float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
+                                      acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
+                        if (lrelu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.2f * v[j]);
+                        }
+                        if (xres) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= p.s1;
+                        }
+                        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                        const int c8 = nl >> 2;
+                        const int phys16 = (c8 >> 1) ^ (ml & (NCH16 - 1));
+                        *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
+                    }
+            }
+            // drain in batches of NB row groups: residual loads of a batch are issued together (out-of-map pixels
+            // read a clamped, valid address and store to the trash page)
+            const f16* __restrict__ R1 = reinterpret_cast<const f16*>(p.res1);
+            const f16* __restrict__ R2 = reinterpret_cast<const f16*>(p.res2);
+            constexpr int ROWS_PER_IT = 64 / NCH16;
+            constexpr int NB = 4; // iterations whose loads are in flight together
+            const int j = lane % NCH16;
+            const int jp = j >> 2, je = (j & 3) * 8; // plane of the lane's 8 channels, element offset inside the pixel
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-local hand-over of the staged rows: no block barrier
+            const float s1 = p.s1, s2 = p.s2;
+#pragma unroll
+            for (int ib = 0; ib < NCH16; ib += NB) {
+                long pixel[NB];
+                bool ok[NB];
+                f16x8 ra[NB], rc[NB], v[NB];
+#pragma unroll
+                for (int it = 0; it < NB; ++it) {
+                    const int fl = (ib + it) * ROWS_PER_IT + lane / NCH16, fm = fl >> 5, fr = fl & 31; // staged row -> (M-tile, pixel)
+                    const int oy = cur.y0 + (cur.tws == 5 ? 2 * wave + fm : 4 * wave + fm + 2 * (fr >> 4));
+                    const int ox = cur.x0 + (cur.tws == 5 ? fr : (fr & 15));
+                    ok[it] = oy < H && ox < W;
+                    pixel[it] = ((long)cur.b * H + min(oy, H - 1)) * W + min(ox, W - 1);
+                }
+                if (R1) {
+#pragma unroll
+                    for (int it = 0; it < NB; ++it) ra[it] = *reinterpret_cast<const f16x8*>(R1 + jp * p.res1_plane + pixel[it] * CK + je);
+                }
+                if (R2) {
+#pragma unroll
+                    for (int it = 0; it < NB; ++it) rc[it] = *reinterpret_cast<const f16x8*>(R2 + jp * p.res2_plane + pixel[it] * CK + je);
+                }
+#pragma unroll
+                for (int it = 0; it < NB; ++it) {
+                    const int ml = (ib + it) * ROWS_PER_IT + lane / NCH16;
+                    v[it] = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ (ml & (NCH16 - 1))) * 16);
+                }
+#pragma unroll
+                for (int it = 0; it < NB; ++it) {
                     if (R1) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) ra[g] = *reinterpret_cast<const f16x4*>(R1 + ni * p.res1_plane + pixel * CK + 8 * g + 4 * h);
+                        for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s1 + (float)ra[it][q]);
                     }
                     if (R2) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) rc[g] = *reinterpret_cast<const f16x4*>(R2 + ni * p.res2_plane + pixel * CK + 8 * g + 4 * h);
+                        for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s2 + (float)rc[it][q]);
                     }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int nl = 8 * g + 4 * h;
-                        const float4 bias = *reinterpret_cast<const float4*>(s_bias + ni * 32 + nl);
-                        float t[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
-                                      acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (lrelu) t[q] = fmaxf(t[q], 0.2f * t[q]);
-                            if (xres || R1) t[q] *= s1;
-                            if (R1) t[q] += (float)ra[g][q];
-                            if (R2) t[q] = t[q] * s2 + (float)rc[g][q];
-                        }
-                        const f16x4 o = {(f16)t[0], (f16)t[1], (f16)t[2], (f16)t[3]};
-                        f16* dst = ok ? reinterpret_cast<f16*>(p.out) + ni * p.out_plane + pixel * CK + nl : trash;
-                        *reinterpret_cast<f16x4*>(dst) = o;
-                    }
+                    f16* dst = ok[it] ? reinterpret_cast<f16*>(p.out) + jp * p.out_plane + pixel[it] * CK + je : trash;
+                    *reinterpret_cast<f16x8*>(dst) = v[it];
                 }
             }
             stores_in_flight = true;
         }
-        stamp(4); // epilogue
 
         t_cur += t_step;
         if (t_cur >= t_end) return true;
@@ -458,7 +544,6 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         }
         zero_acc();
         c = 0;
-        stamp(5); // next tile's geometry
         return false;
     };
     using std::integral_constant;
@@ -467,22 +552,13 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             if (step(integral_constant<int, 0>{}, integral_constant<int, 0>{})) break;
             if (step(integral_constant<int, 1>{}, integral_constant<int, 1>{})) break;
             if (step(integral_constant<int, 2>{}, integral_constant<int, 0>{})) break;
-            if constexpr (!RES) { // with streamed slabs the pattern repeats after lcm(3, 2) steps
-                if (step(integral_constant<int, 0>{}, integral_constant<int, 1>{})) break;
-                if (step(integral_constant<int, 1>{}, integral_constant<int, 0>{})) break;
-                if (step(integral_constant<int, 2>{}, integral_constant<int, 1>{})) break;
-            }
+            if (step(integral_constant<int, 0>{}, integral_constant<int, 1>{})) break;
+            if (step(integral_constant<int, 1>{}, integral_constant<int, 0>{})) break;
+            if (step(integral_constant<int, 2>{}, integral_constant<int, 1>{})) break;
         } else {
             if (step(integral_constant<int, 0>{}, integral_constant<int, 0>{})) break;
             if (step(integral_constant<int, 1>{}, integral_constant<int, 1>{})) break;
         }
-    }
-    if (stamping && tid == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = ph[k];
-        o[6] = n_steps;
-        o[7] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -495,37 +571,20 @@ int dconv_grid_blocks() {
     return n_cu; // one 8-wave block per CU (its LDS ring takes the whole 160 KB)
 }
 
-template <int COUT, int EPI, int HS, int RES>
-int launch_variant(const vx_dconv_args& a, hipStream_t s) {
+template <int COUT, int EPI>
+int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
     constexpr int HALO_BYTES = 5 * NW * 1024;
-    constexpr int smem = HS * HALO_BYTES + (RES ? RES : 2) * 9 * COUT * PIXB + COUT * 4;
-    static_assert(smem <= 160 * 1024, "variant does not fit the LDS");
+    constexpr int smem = (COUT == 32 ? 3 : 2) * HALO_BYTES + 2 * 9 * COUT * PIXB + COUT * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, HS, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const long tiles = (long)a.B * tile_grid(a.H, a.W).total();
     const int blocks = (int)(tiles < dconv_grid_blocks() ? tiles : dconv_grid_blocks());
-    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, HS, RES>), dim3(blocks), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI>), dim3(blocks), dim3(512), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
-}
-
-// variant choice: all slabs resident where they fit next to the halo ring (3 stages if possible), else streamed
-template <int COUT, int EPI>
-int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
-    const int nch = a.cin / CK;
-    if constexpr (COUT == 32) {
-        if (nch <= 2) return launch_variant<32, EPI, 3, 2>(a, s);      // 120 + 36 KB
-        if constexpr (EPI == VX_DC_F16) {
-            if (nch <= 4) return launch_variant<32, EPI, 2, 4>(a, s);  //  80 + 72 KB
-        }
-        return launch_variant<32, EPI, 3, 0>(a, s);                    // 120 + 36 KB ring
-    } else {
-        if (nch <= 2) return launch_variant<64, EPI, 2, 2>(a, s);      //  80 + 72 KB
-        return launch_variant<64, EPI, 2, 0>(a, s);                    //  80 + 72 KB ring
-    }
 }
 
 // ---- ESRGAN pre/post-processing --------------------------------------------------------------------------------
