@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Depth-Anything-V2-Small f16, 518x518, images/sec (BASELINE.json).
+(`--workload esrgan` measures the next row to the same contract: Real-ESRGAN-4x f16, 256^2 -> 1024^2, batch 16,
+BASELINE.json configs[2].)
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -44,7 +46,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--workload", choices=["depthany", "esrgan"], default="depthany",
+                    help="depthany = the headline metric (BASELINE.json configs[1]); esrgan = configs[2], the next SURVEY section 8 row")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 for depthany, 16 for esrgan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=32, help="bounded CPU-baseline sample (about 10 s at 16 threads)")
@@ -80,9 +84,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    B, W, H = args.batch, 518, 518
-    cfg = synth.SMALL
     api = L.get_lib()
+    if args.workload == "esrgan":
+        run_esrgan(args, torch, dist, rank, world, device_index, barrier, api)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    B, W, H = args.batch or 32, 518, 518
+    cfg = synth.SMALL
 
     # ---- load: rank 0 reads the GGUF and uploads; other ranks allocate and receive the arena over RCCL
     tmp = Path(tempfile.gettempdir()) / f"visp_bench_da_v2_small_f16_{os.environ.get('MASTER_PORT', '0')}.gguf"
@@ -92,18 +102,7 @@ def main():
     dev = vision.Device.init(index=device_index)
     model = vision.Model.load(tmp, dev, vision.Arch.depth_anything, no_upload=(rank != 0))
     if world > 1:
-        ptr, nbytes = model.weights_arena()
-        staging = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            L.vx_check(api.vx_memcpy_d2d(staging.data_ptr(), ptr, nbytes, None))
-            L.vx_check(api.vx_stream_sync(None))
-        dist.broadcast(staging, src=0)
-        torch.cuda.synchronize()
-        if rank != 0:
-            L.vx_check(api.vx_memcpy_d2d(ptr, staging.data_ptr(), nbytes, None))
-            L.vx_check(api.vx_stream_sync(None))
-            model.weights_ready()
-        del staging
+        broadcast_arena(model, torch, dist, rank, api)
 
     # ---- inputs resident in HBM before the timed region
     imgs = synth.images(min(B, 8), W, H, seed=1234 + 100 * rank)
@@ -214,6 +213,129 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def broadcast_arena(model, torch, dist, rank, api):
+    """Rank 0 read the GGUF and uploaded; the other ranks receive the packed weight arena over RCCL."""
+    ptr, nbytes = model.weights_arena()
+    staging = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        L.vx_check(api.vx_memcpy_d2d(staging.data_ptr(), ptr, nbytes, None))
+        L.vx_check(api.vx_stream_sync(None))
+    dist.broadcast(staging, src=0)
+    torch.cuda.synchronize()
+    if rank != 0:
+        L.vx_check(api.vx_memcpy_d2d(ptr, staging.data_ptr(), nbytes, None))
+        L.vx_check(api.vx_stream_sync(None))
+        model.weights_ready()
+
+
+ESRGAN_GFLOP_PER_IMAGE = 2349.7  # SURVEY.md section 8f: RRDBNet 23 blocks, 256^2 -> 1024^2, untiled (2 x MACs)
+
+
+def run_esrgan(args, torch, dist, rank, world, device_index, barrier, api):
+    """A step = esrgan_compute semantics (vision.cpp:220-253: 224/16 tiling, RRDBNet per tile, blend, rgba_u8) for a
+    batch of 16 synthetic 256x256 RGB images resident in HBM; all 64 tiles of the batch go through the network
+    together. Images are independent: ranks take whole images, no data-path collective."""
+    B, W, H = args.batch or 16, 256, 256
+    cfg = synth.ESRGAN_X4
+    tmp = Path(tempfile.gettempdir()) / f"visp_bench_realesrgan_x4_f16_{os.environ.get('MASTER_PORT', '0')}.gguf"
+    if rank == 0:
+        synth.write_esrgan_gguf(tmp, cfg, seed=1)
+    barrier()
+    dev = vision.Device.init(index=device_index)
+    model = vision.Model.load(tmp, dev, vision.Arch.esrgan, no_upload=(rank != 0))
+    if world > 1:
+        broadcast_arena(model, torch, dist, rank, api)
+    imgs = synth.images(B, W, H, seed=4321 + 100 * rank)
+    src = torch.from_numpy(imgs).cuda()
+    s = cfg.scale
+    out = torch.empty((B, H * s, W * s, 4), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream().cuda_stream
+
+    def step():
+        model.upscale_batch_device(src.data_ptr(), B, W, H, out.data_ptr(), vision.ImageFormat.rgb_u8, stream)
+
+    groups = []
+    if rank == 0:
+        step()
+        torch.cuda.synchronize()
+        model.enable_timing(True)
+        step()
+        torch.cuda.synchronize()
+        groups = sorted(model.read_timing(), key=lambda g: -g["ms"])
+        model.enable_timing(False)
+        if args.profile_groups:
+            tot = sum(g["ms"] for g in groups)
+            print(f"{'group':16s} {'ms':>8s} {'%':>6s} {'launch':>6s} {'TFLOP/s':>9s} {'GB/s':>9s}", file=sys.stderr)
+            for g in groups:
+                print(f"{g['name']:16s} {g['ms']:8.3f} {100 * g['ms'] / tot:6.1f} {g['launches']:6d} "
+                      f"{g['flops'] / g['ms'] / 1e9:9.1f} {g['bytes'] / g['ms'] / 1e6:9.1f}", file=sys.stderr)
+            print(f"{'total':16s} {tot:8.3f}", file=sys.stderr)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    o = out.cpu().numpy()
+    assert (o[..., 3] == 255).all() and o[..., :3].std() > 1, "invalid output"
+    if rank != 0:
+        return
+    value = world * B * args.steps / elapsed
+    tiled_gflop = sum(g["flops"] for g in groups) / B / 1e9 if groups else None
+    res = {
+        "metric": "images/sec, Real-ESRGAN-4x (RRDBNet 23 blocks) 256x256 -> 1024x1024 f16",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "Real-ESRGAN-4x f16 (RRDB conv stack) 256x256 -> 1024x1024 batch=16 per MI355X (BASELINE.json configs[2])",
+                   "images_per_gpu_per_step": B, "global_batch": world * B, "weights": "random-init synthetic GGUF (seed 1)",
+                   "tiling": "224 max / overlap 16 / align 16 as the reference: 4 tiles of 144x144 per image, 64 tiles per step",
+                   "parallelism": f"dp{world} (image shards, no data-path collective)"},
+        "model_tflops": round(value * ESRGAN_GFLOP_PER_IMAGE / 1e3, 2),
+        "model_tflops_incl_tile_overlap": round(value * tiled_gflop / 1e3, 2) if tiled_gflop else None,
+        "mfma_frac_whole_model": round(value * (tiled_gflop or ESRGAN_GFLOP_PER_IMAGE) * 1e9 / (world * PEAK_MFMA_F16), 4),
+    }
+    if groups:
+        dom = groups[0]
+        per_launch_ms = dom["ms"] / max(dom["launches"], 1)
+        ach = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+        res["roofline"] = {"kernel": f"dconv3x3_kernel ({dom['name']})", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F16 / 1e12,
+                           "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_MFMA_F16, 4), "traffic": None,
+                           "avg_launch_ms": round(per_launch_ms, 4), "launches_per_step": dom["launches"]}
+        pmc = ROOT / "profiles" / "r01_pmc" / "traffic_esrgan.json"
+        if pmc.exists():
+            k = json.loads(pmc.read_text())["kernels"].get(dom["name"])
+            if k:
+                res["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = "profiles/r01_pmc/traffic_esrgan.json (FETCH_SIZE x2 + WRITE_SIZE)"
+        res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+
+        sd = synth.esrgan_state_dict(cfg, 1)
+        tensors, conv2d = synth.esrgan_gguf_tensors(sd)
+        om = oracle.Model(tensors, conv2d, "whcn")
+        oracle.set_num_threads(args.cpu_threads)
+        n = max(1, min(2, args.cpu_images // 16))
+        t0 = time.perf_counter()
+        diffs = []
+        for i in range(n):
+            want = oracle.esrgan_compute(om, cfg.scale, cfg.num_blocks, imgs[i], oracle.RGB_U8)
+            diffs.append(np.abs(o[i].astype(np.int32) - want.astype(np.int32)))
+        dt = time.perf_counter() - t0
+        d = np.stack(diffs)
+        res["cpu_baseline"] = {"value": round(n / dt, 4), "unit": "images/s", "cores": args.cpu_threads, "kind": "port",
+                               "sample": f"{n} image(s) 256x256 -> 1024x1024 (4 tiles each), OpenMP {args.cpu_threads} threads, oracle/libvisp_oracle.so",
+                               "u8_mean_abs_diff_gpu_vs_cpu": round(float(d.mean()), 4), "u8_max_abs_diff_gpu_vs_cpu": int(d.max())}
+    print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(cfg, imgs, gpu_out, n_images, n_threads):

@@ -135,7 +135,7 @@ typedef struct {
     float s2; const void* res2; int64_t res2_plane;
     void* out; int64_t out_plane;
     int x_residual;
-    void* stamps; /* diagnostics only: u64 [blocks][8] = cycles in {dma wait, barrier, mfma loop + dma feed, halo cursor, epilogue, tile setup}, steps, end clock; NULL in product */
+    void* stamps; /* diagnostics only: u64 [blocks][8] = cycles in {dma wait, barrier, dma issue + halo cursor, mfma loop, epilogue, tile setup}, steps, end clock; NULL in product */
 } vx_dconv_args;
 VX_API int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream);
 

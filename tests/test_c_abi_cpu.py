@@ -117,3 +117,21 @@ def test_converter_matches_reference_contract(tmp_path):
     fam = C.c_int32(-1)
     L.check(L.get_lib().visp_model_detect_family(str(out).encode(), C.byref(fam)))
     assert fam.value == 2
+
+
+def test_esrgan_gguf_is_detected_and_tile_layout_matches_oracle(tmp_path):
+    """Host-only pieces of the ESRGAN row: family detection of the synthetic checkpoint (vision.cpp:7-21) and
+    tile_layout / tile_scale (image.cpp:612-629) of the product against the oracle's restatement."""
+    from oracle import oracle as O
+    from visioncpp_amd.vision import esrgan_tile_layout
+
+    lib = L.get_lib()
+    p = synth.write_esrgan_gguf(tmp_path / "e.gguf", synth.ESRGAN_TINY, 3)
+    fam = C.c_int32(-1)
+    assert lib.visp_model_detect_family(str(p).encode(), C.byref(fam)) == 1 and fam.value == 4
+    f = gguf.GGUFFile(p)
+    assert f.kv["esrgan.scale"] == 2 and f.kv["esrgan.block_count"] == 2 and f.kv["esrgan.tensor_data_layout"] == "whcn"
+    for (w, h, s) in [(256, 256, 4), (1000, 700, 2), (224, 224, 4), (225, 17, 1), (640, 481, 8)]:
+        got = esrgan_tile_layout(w, h, s)
+        t = O.tile_scale(O.tile_layout(w, h, 224, 16, 16), s)
+        assert got == {k: getattr(t, k) for k in got}, (w, h, s)

@@ -50,7 +50,7 @@ def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3):
     per = st[:, :6].sum(0) / steps.sum()
     flops = 2.0 * B * H * W * 9 * cin * cout
     us = ms.value / reps * 1e3
-    names = ["dma_wait", "barrier", "mfma+feed", "cursor", "epilogue", "tile_setup"]
+    names = ["dma_wait", "barrier", "dma_issue+cursor", "mfma_loop", "epilogue", "tile_setup"]
     print(f"cin {cin:3d} cout {cout:2d}{' xres' if x_residual else ''}: {us:7.1f} us  {flops / us / 1e6:7.1f} TFLOP/s   steps/block {steps.mean():.1f}  "
           f"cycles/step: " + "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, per)) + f"  total {per.sum():6.0f}")
     G.release()

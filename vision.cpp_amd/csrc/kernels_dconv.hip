@@ -55,7 +55,9 @@ struct tile_grid {
     __host__ __device__ int total() const { return n_main + n_strip; }
 };
 
-template <int COUT, int EPI>
+// STAMP: diagnostics build (args.stamps != NULL) that sums shader-clock cycles per phase; the product instantiation
+// carries none of it.
+template <int COUT, int EPI, bool STAMP>
 __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     constexpr int MT = 2;                       // M-tiles (32 pixels) per wave
     constexpr int HALO_PIX = 18 * 34;           // both tile shapes
@@ -376,6 +378,16 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     zero_acc();
     int c = 0; // chunk of the current tile
     bool stores_in_flight = false;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    unsigned n_steps = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            ph[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if constexpr (STAMP) t_prev = __builtin_amdgcn_s_memtime();
     f16* const trash = reinterpret_cast<f16*>(g_dconv_trash + ((blockIdx.x % TRASH_BLOCKS) * 8 + wave) * 1024 + lane * 16);
 
     // One step, computed out of halo stage HSt and slab stage WSt. The HS x 2 instantiations run back to back in
@@ -395,9 +407,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             }
         }
         stores_in_flight = false;
+        stamp(0); // waited for the step's DMA
         // raw s_barrier: __syncthreads() carries a fence that drains vmcnt, i.e. the halo prefetched for later steps
         __builtin_amdgcn_s_barrier(); // the step's data is in LDS for everyone; everyone has left the previous step's stages
         asm volatile("" ::: "memory");
+        stamp(1); // barrier
         const bool last_chunk = c + 1 == nch;
         const bool do_slab = !last_chunk || t_cur + t_step < t_end;
         const int slab_c = last_chunk ? 0 : c + 1;
@@ -412,6 +426,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                 issue_halo(halo_c, HNEXT);
                 move_cursor(); // the next tile's halo sources are set up while the pieces are on their way
             }
+            stamp(2); // DMA burst + halo cursor
             compute(hs_c, ws_c, c, [](int) {});
         } else {
             // 72 MFMAs per step: piece k of the ring is issued after the k-th k-step's MFMAs (3 % faster)
@@ -423,8 +438,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                 }
             });
         }
+        stamp(3); // MFMA loop (COUT = 64: with the DMA pieces fed from inside)
         if (COUT == 64 && do_halo) move_cursor();
         prev_halo = do_halo;
+        stamp(2);
+        ++n_steps;
         if (++c < nch) return false;
 
         constexpr int done = HSt; // the halo stage of the last chunk: free once every wave has left compute()
@@ -534,6 +552,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             }
             stores_in_flight = true;
         }
+        stamp(4); // epilogue (its barrier included)
 
         t_cur += t_step;
         if (t_cur >= t_end) return true;
@@ -544,6 +563,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         }
         zero_acc();
         c = 0;
+        stamp(5); // next tile's geometry
         return false;
     };
     using std::integral_constant;
@@ -560,6 +580,15 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             if (step(integral_constant<int, 1>{}, integral_constant<int, 1>{})) break;
         }
     }
+    if constexpr (STAMP) {
+        if (tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = ph[k];
+            o[6] = n_steps;
+            o[7] = __builtin_amdgcn_s_memtime();
+        }
+    }
 }
 
 int dconv_grid_blocks() {
@@ -571,20 +600,28 @@ int dconv_grid_blocks() {
     return n_cu; // one 8-wave block per CU (its LDS ring takes the whole 160 KB)
 }
 
-template <int COUT, int EPI>
-int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
+template <int COUT, int EPI, bool STAMP>
+int launch_variant(const vx_dconv_args& a, hipStream_t s) {
     constexpr int HALO_BYTES = 5 * NW * 1024;
     constexpr int smem = (COUT == 32 ? 3 : 2) * HALO_BYTES + 2 * 9 * COUT * PIXB + COUT * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const long tiles = (long)a.B * tile_grid(a.H, a.W).total();
     const int blocks = (int)(tiles < dconv_grid_blocks() ? tiles : dconv_grid_blocks());
-    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI>), dim3(blocks), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, STAMP>), dim3(blocks), dim3(512), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
+}
+
+template <int COUT, int EPI>
+int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
+    if constexpr (EPI == VX_DC_F16) {
+        if (a.stamps) return launch_variant<COUT, EPI, true>(a, s);
+    }
+    return launch_variant<COUT, EPI, false>(a, s);
 }
 
 // ---- ESRGAN pre/post-processing --------------------------------------------------------------------------------
