@@ -496,7 +496,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                         }
                         f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                         const int c8 = nl >> 2;
-                        const int phys16 = (c8 >> 1) ^ (ml & (NCH16 - 1));
+                        const int phys16 = (c8 >> 1) ^ ((ml ^ (ml / NCH16)) & (NCH16 - 1)); // rows ml, ml + NCH16, ... must not share banks (PMC: 14 % conflict cycles with ml & 3 alone)
                         *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
                     }
             }
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {
                     const int ml = (ib + it) * ROWS_PER_IT + lane / NCH16;
-                    v[it] = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ (ml & (NCH16 - 1))) * 16);
+                    v[it] = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ ((ml ^ (ml / NCH16)) & (NCH16 - 1))) * 16);
                 }
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {
