@@ -330,6 +330,10 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         if constexpr (COUT == 32) compute_win(hs_c, ws_c, chunk, feed);
         else compute_tap(hs_c, ws_c, chunk, feed);
     };
+    // 16-byte group swizzle of the staged output tile. COUT = 32 (64-byte rows): rows ml, ml+4, ml+8, ml+12 of a
+    // ds_write_b64 lane group must not share banks (PMC: 14 % LDS conflict cycles with ml & 3 alone); COUT = 64
+    // keeps ml & 7 (the wider form measured 1 % slower there)
+    auto stage_swz = [](int ml) { return COUT == 32 ? ((ml ^ (ml >> 2)) & 3) : (ml & 7); };
     auto zero_acc = [&]() {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                         }
                         f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                         const int c8 = nl >> 2;
-                        const int phys16 = (c8 >> 1) ^ ((ml ^ (ml / NCH16)) & (NCH16 - 1)); // rows ml, ml + NCH16, ... must not share banks (PMC: 14 % conflict cycles with ml & 3 alone)
+                        const int phys16 = (c8 >> 1) ^ stage_swz(ml);
                         *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
                     }
             }
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {
                     const int ml = (ib + it) * ROWS_PER_IT + lane / NCH16;
-                    v[it] = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ ((ml ^ (ml / NCH16)) & (NCH16 - 1))) * 16);
+                    v[it] = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ stage_swz(ml)) * 16);
                 }
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {

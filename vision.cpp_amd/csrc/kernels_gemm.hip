@@ -13,10 +13,10 @@
 //    the reads of 32 different rows at one k-column bank-conflict free;
 //  * v_mfma_f32_32x32x16_f16, A and B fragments both K-contiguous (lane l: row l&31,
 //    k = 8*(l>>5)..+7); wave tile WM x WN;
-//  * f16-output epilogues run the MFMA with swapped operands (D = W-frag x A-frag, so a lane owns
-//    one output row and 4 consecutive columns per register group), stage the tile through LDS
-//    and write it with coalesced 16-byte stores; f32 read-modify-write epilogues keep the natural
-//    orientation (a wave instruction covers whole 128-byte rows of x).
+//  * every epilogue runs the MFMA with swapped operands (D = W-frag x A-frag, so a lane owns one
+//    output row and 4 consecutive columns per register group): f16 tiles are staged through LDS
+//    and written with coalesced 16-byte stores, the f32 read-modify-write epilogues (residual
+//    stream, token rows) use batched 16-byte loads/stores straight from the registers.
 #include "vx_common.h"
 
 namespace {
