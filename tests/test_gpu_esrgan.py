@@ -257,3 +257,40 @@ def test_esrgan_errors(tiny, device, tmp_path):
     synth.write_esrgan_gguf(bad, synth.EsrganConfig(num_filters=48, num_blocks=1, scale=2, gc=16, name="bad"), 0)
     with pytest.raises(L.Error, match="not built in this backend"):
         Model.load(bad, device, Arch.esrgan)
+
+
+@pytest.mark.parametrize("scale,w,h", [(1, 50, 34), (8, 40, 24), (2, 225, 17), (4, 17, 230)])
+def test_scales_and_odd_extents(tmp_path_factory, device, scale, w, h):
+    """log2(scale) up-sampling stages (esrgan.cpp:69-73: none for x1, three for x8) and extents that are not multiples of
+    anything: tile sizes come out as 64x48, 48x32, 128x32, 32x128 (strip tiles, partial tiles, 1- and 2-tile layouts)."""
+    from visioncpp_amd import synth
+    cfg = synth.EsrganConfig(num_blocks=1, scale=scale, name=f"s{scale}")
+    m, om = _load(tmp_path_factory, device, cfg, 11)
+    img = synth.images(2, w, h, seed=w + h)
+    got = m.upscale_batch(img)
+    assert got.shape == (2, h * scale, w * scale, 4)
+    for i in range(2):
+        ref = O.esrgan_compute(om, scale, 1, img[i], O.RGB_U8)
+        d = np.abs(got[i].astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 2 and (d > 0).mean() < 0.05, (scale, w, h, d.max(), (d > 0).mean())
+
+
+def test_c_api_strided_view(tiny):
+    """visp_model_compute with a row stride larger than width * channels (image_view.stride, image.h:37-41)."""
+    import ctypes as C
+    from visioncpp_amd import _lib as L
+    m, om, cfg = tiny
+    rng = np.random.default_rng(2)
+    w, h, stride = 45, 30, 45 * 3 + 13
+    buf = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    img = np.ascontiguousarray(np.stack([buf[y, :w * 3].reshape(w, 3) for y in range(h)]))
+    view = L.ImageView(w, h, stride, 3, buf.ctypes.data)   # rgb_u8
+    out_view, out_data = L.ImageView(), C.c_void_p()
+    L.check(L.get_lib().visp_model_compute(m._handle, 4, (L.ImageView * 1)(view), 1, (C.c_int32 * 1)(), 0, C.byref(out_view), C.byref(out_data)))
+    try:
+        n = out_view.height * out_view.stride
+        res = np.frombuffer((C.c_uint8 * n).from_address(out_view.data), np.uint8).reshape(out_view.height, out_view.width, 4).copy()
+    finally:
+        L.get_lib().visp_image_destroy(out_data)
+    assert (out_view.width, out_view.height, out_view.format) == (w * cfg.scale, h * cfg.scale, 0)   # rgba_u8
+    assert np.array_equal(res, m.upscale_batch(img[None])[0])

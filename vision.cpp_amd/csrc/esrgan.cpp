@@ -192,12 +192,22 @@ esrgan_model* esrgan_load_model(char const* filepath, backend_device const& dev,
         model->weights_uploaded = true;
     }
     if (const char* e = getenv("VISP_ESRGAN_TILE_GROUP")) model->tile_group = std::max(1, atoi(e));
+    if (const char* e = getenv("VISP_ESRGAN_STREAMS")) model->streams = std::max(1, atoi(e));
+    VX(vx_stream_create(&model->aux_stream));
+    VX(vx_event_create(&model->fork_event));
+    VX(vx_event_create(&model->join_event));
     return model.release();
 }
 
 void esrgan_weights_ready(esrgan_model& m) { m.weights_uploaded = true; }
 
 esrgan_model::~esrgan_model() {
+    if (aux_stream) {
+        vx_stream_sync(aux_stream);
+        vx_stream_destroy(aux_stream);
+    }
+    if (fork_event) vx_event_destroy(fork_event);
+    if (join_event) vx_event_destroy(join_event);
     vx_free(ws.arena.ptr);
     vx_free(weight_arena.ptr);
 }
@@ -209,21 +219,29 @@ namespace {
 
 void reserve(esrgan_model& m, int n_tiles_total, int tw, int th, size_t img_in_bytes, size_t img_out_bytes) {
     esrgan_workspace& ws = m.ws;
-    const int group = std::min(n_tiles_total, m.tile_group);
+    // two concurrent lanes when there is enough work to split (timing runs keep one lane: events on one stream)
+    const int lanes = (m.streams >= 2 && !m.timing && n_tiles_total >= 8) ? 2 : 1;
+    const int group = std::min((n_tiles_total + lanes - 1) / lanes, m.tile_group);
     const int s = m.params.scale;
     const size_t px = (size_t)tw * th;
     struct item { void** p; size_t bytes; };
     const size_t hr_bytes = m.weights.up.empty() ? (size_t)group * px * 64 * 2 : (size_t)group * px * s * s * 64 * 2;
-    item items[] = {
+    std::vector<item> items = {
         {&ws.in_u8, img_in_bytes}, {&ws.out_u8, img_out_bytes},
-        {&ws.x0, (size_t)n_tiles_total * px * 32 * 2}, {&ws.tiles_out, (size_t)n_tiles_total * px * s * s * 3 * 4},
-        {&ws.fea, (size_t)group * px * 64 * 2}, {&ws.d[0], (size_t)group * px * 192 * 2}, {&ws.d[1], (size_t)group * px * 192 * 2},
-        {&ws.d[2], (size_t)group * px * 192 * 2}, {&ws.tr, (size_t)group * px * 64 * 2}, {&ws.hr_a, hr_bytes}, {&ws.hr_b, hr_bytes},
-    };
+        {&ws.x0, (size_t)n_tiles_total * px * 32 * 2}, {&ws.tiles_out, (size_t)n_tiles_total * px * s * s * 3 * 4}};
+    for (int l = 0; l < lanes; ++l) {
+        esrgan_workspace::lane_buffers& L = ws.lane[l];
+        items.push_back({&L.fea, (size_t)group * px * 64 * 2});
+        for (int k = 0; k < 3; ++k) items.push_back({&L.d[k], (size_t)group * px * 192 * 2});
+        items.push_back({&L.tr, (size_t)group * px * 64 * 2});
+        items.push_back({&L.hr_a, hr_bytes});
+        items.push_back({&L.hr_b, hr_bytes});
+    }
     size_t total = 0;
     for (item& it : items) total += round_up<size_t>(it.bytes, 256);
     if (total > ws.arena.bytes) {
         VX(vx_stream_sync(m.backend->stream));
+        if (m.aux_stream) VX(vx_stream_sync(m.aux_stream));
         vx_free(ws.arena.ptr);
         ws.arena = {};
         VX(vx_malloc(&ws.arena.ptr, total));
@@ -234,7 +252,7 @@ void reserve(esrgan_model& m, int n_tiles_total, int tw, int th, size_t img_in_b
         *it.p = p;
         p += round_up<size_t>(it.bytes, 256);
     }
-    ws.group = group; ws.tile_w = tw; ws.tile_h = th; ws.scale = s;
+    ws.group = group; ws.lanes = lanes; ws.tile_w = tw; ws.tile_h = th; ws.scale = s;
     ws.img_in = img_in_bytes; ws.img_out = img_out_bytes;
 }
 
@@ -304,18 +322,18 @@ struct exec {
     }
 
     // esrgan_generate (esrgan.cpp:55-79) on n tiles: x0 [n,h,w,32] f16 -> rgb f32 [n, h*s, w*s, 3]
-    void generate(const void* x0, int n, int w, int h, float* out) {
+    void generate(esrgan_workspace::lane_buffers const& lb, const void* x0, int n, int w, int h, float* out) {
         esrgan_weights const& Wt = m.weights;
-        esrgan_workspace& ws = m.ws;
+        esrgan_workspace const& ws = m.ws;
         // every activation buffer is planar (32 channels per plane); plane strides are those of the full tile group
         const int64_t PL = (int64_t)ws.group * w * h * 32;             // low-resolution plane
         const int64_t PH = PL * ws.scale * ws.scale;                    // plane of the up-sampled maps
         auto plane = [](void* base, int64_t stride, int k) { return static_cast<void*>(static_cast<uint16_t*>(base) + stride * k); };
-        conv(Wt.first, x0, 0, 32, n, h, w, ws.fea, PL, {}, "first");
-        conv(Wt.first, x0, 0, 32, n, h, w, ws.d[0], PL, {}, "first");
+        conv(Wt.first, x0, 0, 32, n, h, w, lb.fea, PL, {}, "first");
+        conv(Wt.first, x0, 0, 32, n, h, w, lb.d[0], PL, {}, "first");
         int a = 0;
         for (auto const& blk : Wt.rdb) { // rrdb, esrgan.cpp:43-51
-            void *A = ws.d[a], *B = ws.d[(a + 1) % 3], *C = ws.d[(a + 2) % 3];
+            void *A = lb.d[a], *B = lb.d[(a + 1) % 3], *C = lb.d[(a + 2) % 3];
             void* src[3] = {A, B, C};
             void* dst[3] = {B, C, B};
             for (int r = 0; r < 3; ++r) { // risidual_dense_block, esrgan.cpp:27-41
@@ -334,12 +352,12 @@ struct exec {
         }
         {
             opts o;
-            o.res1 = ws.fea; o.res1_plane = PL;
-            conv(Wt.trunk, ws.d[a], PL, 64, n, h, w, ws.tr, PL, o, "trunk");
+            o.res1 = lb.fea; o.res1_plane = PL;
+            conv(Wt.trunk, lb.d[a], PL, 64, n, h, w, lb.tr, PL, o, "trunk");
         }
-        const void* cur = ws.tr;
+        const void* cur = lb.tr;
         int64_t cur_plane = PL;
-        void* nxt[2] = {ws.hr_a, ws.hr_b};
+        void* nxt[2] = {lb.hr_a, lb.hr_b};
         int flip = 0, cw = w, ch = h;
         for (packed_dconv const& u : Wt.up) { // esrgan::upsample, esrgan.cpp:13-19
             cw *= 2; ch *= 2;
@@ -364,10 +382,24 @@ struct exec {
 void run_tiles(esrgan_model& m, exec& ex, int n_total, int tw, int th) {
     const int s = m.params.scale;
     const size_t px = (size_t)tw * th;
-    for (int t0 = 0; t0 < n_total; t0 += m.ws.group) {
+    void* const main_stream = ex.stream;
+    const bool two = m.ws.lanes == 2 && n_total > m.ws.group;
+    if (two) { // fork: the second lane starts after what is already queued on the caller's stream (tiles_in)
+        VX(vx_event_record(m.fork_event, main_stream));
+        VX(vx_stream_wait_event(m.aux_stream, m.fork_event));
+    }
+    int gi = 0;
+    for (int t0 = 0; t0 < n_total; t0 += m.ws.group, ++gi) {
         const int n = std::min(m.ws.group, n_total - t0);
-        ex.generate(static_cast<const uint16_t*>(m.ws.x0) + (size_t)t0 * px * 32, n, tw, th,
+        const int lane = two ? gi & 1 : 0;
+        ex.stream = lane ? m.aux_stream : main_stream;
+        ex.generate(m.ws.lane[lane], static_cast<const uint16_t*>(m.ws.x0) + (size_t)t0 * px * 32, n, tw, th,
                     static_cast<float*>(m.ws.tiles_out) + (size_t)t0 * px * s * s * 3);
+    }
+    ex.stream = main_stream;
+    if (two) { // join
+        VX(vx_event_record(m.join_event, m.aux_stream));
+        VX(vx_stream_wait_event(main_stream, m.join_event));
     }
 }
 

@@ -50,8 +50,10 @@ struct esrgan_workspace {
     int group = 0, tile_w = 0, tile_h = 0, scale = 0; // sized for `group` tiles of this extent
     size_t img_in = 0, img_out = 0;                   // bytes reserved for the u8 in/out images
     device_buffer arena;
-    void *in_u8 = nullptr, *out_u8 = nullptr, *x0 = nullptr, *fea = nullptr, *d[3] = {nullptr, nullptr, nullptr}, *tr = nullptr,
-         *hr_a = nullptr, *hr_b = nullptr, *tiles_out = nullptr;
+    void *in_u8 = nullptr, *out_u8 = nullptr, *x0 = nullptr, *tiles_out = nullptr; // whole call
+    // activations of one tile group; two lanes, because two groups run concurrently on two streams
+    struct lane_buffers { void *fea = nullptr, *d[3] = {nullptr, nullptr, nullptr}, *tr = nullptr, *hr_a = nullptr, *hr_b = nullptr; } lane[2];
+    int lanes = 1;
 };
 
 struct esrgan_model : model_base { // vision.h:361-369 counterpart
@@ -62,7 +64,13 @@ struct esrgan_model : model_base { // vision.h:361-369 counterpart
     device_buffer weight_arena;
     bool weights_uploaded = false;
     esrgan_workspace ws;
-    int tile_group = 64;  // tiles pushed through the network together (bounds the workspace; a locality knob)
+    int tile_group = 64;  // upper bound of tiles pushed through the network together (bounds the workspace)
+    // Tile groups are independent, so two of them run concurrently on two streams: a conv launch is 10.25 rounds of
+    // tiles on 256 CUs, and the second group's blocks take the CUs the first one's last round leaves idle
+    // (measured +6 %). 1 = everything on the caller's stream.
+    int streams = 2;
+    void* aux_stream = nullptr;
+    void *fork_event = nullptr, *join_event = nullptr;
     bool timing = false;
     std::vector<timing_entry> last_timing;
     ~esrgan_model();
