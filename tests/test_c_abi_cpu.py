@@ -135,3 +135,33 @@ def test_esrgan_gguf_is_detected_and_tile_layout_matches_oracle(tmp_path):
         got = esrgan_tile_layout(w, h, s)
         t = O.tile_scale(O.tile_layout(w, h, 224, 16, 16), s)
         assert got == {k: getattr(t, k) for k in got}, (w, h, s)
+
+
+def test_esrgan_converter_accepts_both_key_layouts(tmp_path):
+    """convert_esrgan (reference scripts/convert.py:504-527): an old-arch state dict converts to the file the synthetic
+    writer produces; the BasicSR / Real-ESRGAN 'new arch' names give the same file (the renaming spandrel performs)."""
+    from visioncpp_amd import convert
+
+    cfg = synth.EsrganConfig(num_blocks=2, scale=4, name="c")
+    sd = synth.esrgan_state_dict(cfg, 5)
+    ref = gguf.GGUFFile(synth.write_esrgan_gguf(tmp_path / "ref.gguf", cfg, sd=sd))
+    a = gguf.GGUFFile(convert.convert_esrgan(sd, tmp_path / "a.gguf"))
+    # the same weights under the new-arch names, in shuffled order
+    top = {"model.0": "conv_first", "model.1.sub.2": "conv_body", "model.3": "conv_up1", "model.6": "conv_up2", "model.8": "conv_hr", "model.10": "conv_last"}
+    new = {}
+    for k, v in reversed(list(sd.items())):
+        base, _, leaf = k.rpartition(".")
+        if base in top:
+            new[f"{top[base]}.{leaf}"] = v
+        else:
+            p = base.split(".")  # model.1.sub.N.RDBk.convj.0
+            new[f"body.{p[3]}.rdb{p[4][3:]}.{p[5]}.{leaf}"] = v
+    b = gguf.GGUFFile(convert.convert_esrgan(new, tmp_path / "b.gguf"))
+    for f in (a, b):
+        assert f.kv["general.architecture"] == "esrgan" and f.kv["esrgan.scale"] == 4 and f.kv["esrgan.block_count"] == 2
+        assert f.kv["esrgan.filter_count"] == 64 and list(f.kv["esrgan.conv2d_weights"]) == list(ref.kv["esrgan.conv2d_weights"])
+        assert list(f.tensors) == list(ref.tensors)   # same names in the same order (the conv2d index list depends on it)
+        for name, t in f.tensors.items():
+            assert t.dtype == ref.tensors[name].dtype and np.array_equal(t, ref.tensors[name])
+    with pytest.raises(ValueError, match="not an RRDBNet"):
+        convert.convert_esrgan({"foo.weight": np.zeros(3, np.float32)}, tmp_path / "x.gguf")

@@ -58,3 +58,79 @@ def load_safetensors(path: str | Path) -> dict[str, np.ndarray]:
     from safetensors.numpy import load_file  # plain tensor container, nothing is executed from the file
 
     return load_file(str(path))
+
+
+# ---- ESRGAN / Real-ESRGAN (reference scripts/convert.py:504-527, convert_esrgan) ---------------------------------
+#
+# The reference loads any ESRGAN checkpoint through `spandrel`, which normalises the zoo's key layouts to the original
+# ESRGAN ("old arch") names `model.<i>...`, then writes: esrgan.scale, esrgan.block_count, esrgan.filter_count,
+# esrgan.tensor_data_layout = "whcn", every 4-D kernel left OIHW and listed in esrgan.conv2d_weights, floats -> f16.
+# spandrel is not available here; the one renaming it performs for RRDBNet files (the BasicSR / Real-ESRGAN "new arch"
+# names) is restated below, so `RealESRGAN_x4plus`-style state dicts and old-arch ones both convert.
+
+_NEW_ARCH_FIXED = {"conv_first": "model.0", "conv_body": None, "trunk_conv": None, "conv_hr": None, "HRconv": None, "conv_last": None}
+
+
+def esrgan_to_old_arch(sd: dict[str, np.ndarray]) -> dict[str, np.ndarray]:
+    """BasicSR RRDBNet names (conv_first, body.N.rdbK.convJ, conv_body, conv_up1/2, conv_hr, conv_last) or the early
+    'RRDB_trunk' names -> `model.0`, `model.1.sub.N.RDBK.convJ.0`, `model.1.sub.<nb>`, `model.3/6`, `model.8`, `model.10`."""
+    if any(k.startswith("model.0.") for k in sd):
+        return dict(sd)
+    import re
+
+    blocks = set()
+    for k in sd:
+        m = re.match(r"(?:body|RRDB_trunk)\.(\d+)\.", k)
+        if m:
+            blocks.add(int(m.group(1)))
+    if not blocks or not any(k.startswith("conv_first.") for k in sd):
+        raise ValueError("not an RRDBNet (ESRGAN) state dict: neither model.0.* nor conv_first.* / body.* keys")
+    nb = max(blocks) + 1
+    ups = sorted({k.split(".")[0] for k in sd if re.match(r"(conv_up|upconv)\d+\.", k)}, key=lambda s: int(re.sub(r"\D", "", s)))
+    seq = 2 + 3 * len(ups)
+    top = {"conv_first": "model.0", "conv_body": f"model.1.sub.{nb}", "trunk_conv": f"model.1.sub.{nb}",
+           "conv_hr": f"model.{seq}", "HRconv": f"model.{seq}", "conv_last": f"model.{seq + 2}"}
+    for i, u in enumerate(ups):
+        top[u] = f"model.{3 + 3 * i}"
+    out: dict[str, np.ndarray] = {}
+    for k, v in sd.items():
+        head, _, rest = k.partition(".")
+        if head in top:
+            out[f"{top[head]}.{rest}"] = v
+            continue
+        m = re.match(r"(?:body|RRDB_trunk)\.(\d+)\.(?:rdb|RDB)(\d)\.conv(\d)\.(weight|bias)$", k)
+        if not m:
+            raise ValueError(f"unexpected key in RRDBNet state dict: {k}")
+        out[f"model.1.sub.{m.group(1)}.RDB{m.group(2)}.conv{m.group(3)}.0.{m.group(4)}"] = v
+    return out
+
+
+def convert_esrgan(state_dict: dict[str, np.ndarray], out_path: str | Path) -> Path:
+    sd = {k: np.asarray(v) for k, v in esrgan_to_old_arch(state_dict).items()}
+    nb = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("model.1.sub.") and ".RDB" in k)
+    nf = int(sd["model.0.weight"].shape[0])
+    if sd["model.0.weight"].shape[1] != 3:
+        raise ValueError("RealESRGAN models with pixel shuffle are not supported yet.")  # convert.py:513-514
+    tops = sorted({int(k.split(".")[1]) for k in sd if k.count(".") == 2 and k.startswith("model.")})  # 0, 3, 6, 8, 10 for x4
+    n_up = len(tops) - 3  # first, HR and last convs are always there
+    if n_up < 0 or tops[-1] != 2 + 3 * n_up + 2:
+        raise ValueError(f"unexpected top-level layout of the RRDBNet sequence: {tops}")
+    # order tensors as torch's state_dict of the old-arch module does (the conv2d index list depends on it)
+    def order(k):
+        p = k.split(".")
+        return (int(p[1]), int(p[3]) if p[1] == "1" else 0, p[4] if p[1] == "1" and len(p) > 5 else "", k.replace("weight", "0"))
+    from .synth import esrgan_gguf_tensors
+
+    tensors, conv2d = esrgan_gguf_tensors({k: sd[k].astype(np.float32) for k in sorted(sd, key=order)})
+    w = GGUFWriter(out_path, "esrgan")
+    w.add_string("esrgan.tensor_data_layout", "whcn")
+    w.add_int32("esrgan.scale", 1 << n_up)
+    w.add_int32("esrgan.block_count", nb)
+    w.add_int32("esrgan.filter_count", nf)
+    w.add_uint32("general.quantization_version", 2)
+    w.add_uint32("general.file_type", 1)
+    w.add_array_i32("esrgan.conv2d_weights", conv2d)
+    for name, t in tensors.items():
+        w.add_tensor(name, t)
+    w.write()
+    return Path(out_path)
