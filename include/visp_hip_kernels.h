@@ -124,8 +124,12 @@ VX_API int vx_conv3x3_f16(const vx_gemm_args* args, void* stream);
  * up2: the source is [B, H/2, W/2, 32] per plane and is nearest-upsampled on the fly (esrgan.cpp:13-19).
  * w: packed by the host as [cin/32][9 taps][cout][32] f16 with the four 16-byte groups of every (tap, n) row
  *    stored at position g ^ ((n >> 2) & 3)  (see packer::conv in csrc/esrgan.cpp).
- * VX_DC_RGB_F32: cout = 32 (3 real), out = f32 [B, H, W, 3], no activation / residuals. */
-enum { VX_DC_F16 = 0, VX_DC_RGB_F32 = 1 };
+ * VX_DC_RGB_F32: cout = 32 (3 real), out = f32 [B, H, W, 3], no activation / residuals.
+ * VX_DC_HEAD_F32: cout = 32, out = f32 [B, H, W] = head_scale * relu(sum_n relu(v)[n] * head_w[n] + head_bias)
+ *   (head.conv2 + ReLU + head.conv3 1x1 + ReLU of the DPT head, depth-anything.cpp:87-94).
+ * The same kernel serves NHWC maps: *_pix = elements between pixels (0 = 32 = planar), *_plane = elements between
+ *   consecutive 32-channel groups (32 for NHWC). act: 0 none, 1 LeakyReLU 0.2, 2 ReLU. a_relu: convolve relu(x). */
+enum { VX_DC_F16 = 0, VX_DC_RGB_F32 = 1, VX_DC_HEAD_F32 = 2 };
 typedef struct {
     const void* x; int64_t x_plane; int cin; int up2;
     int B, H, W;                 /* output (= conv-space) extent */
@@ -135,9 +139,14 @@ typedef struct {
     float s2; const void* res2; int64_t res2_plane;
     void* out; int64_t out_plane;
     int x_residual;
+    int64_t x_pix, out_pix, res1_pix, res2_pix;
+    int a_relu;
+    const float* head_w; float head_bias, head_scale;
     void* stamps; /* diagnostics only: u64 [blocks][8] = cycles in {dma wait, barrier, dma issue + halo cursor, mfma loop, epilogue, tile setup}, steps, end clock; NULL in product */
 } vx_dconv_args;
 VX_API int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream);
+/* sets the kernels' dynamic-LDS attribute (call once per process before capturing launches into a hipGraph) */
+VX_API int vx_dconv_prepare(void);
 
 /* tile_layout (include/visp/image.h:163-181, src/visp/image.cpp:612-651) */
 typedef struct { int image_w, image_h, overlap_x, overlap_y, n_x, n_y, tile_w, tile_h; } vx_tile_layout;

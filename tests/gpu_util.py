@@ -120,7 +120,7 @@ def from_planes(p: np.ndarray) -> np.ndarray:
 
 
 def dconv(x_dev, n_planes, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=0, out=None, out_planes=None, out_plane0=0,
-          res1=None, s1=1.0, res2=None, s2=1.0, rgb=False, cin_pad=None, x_residual=False):
+          res1=None, s1=1.0, res2=None, s2=1.0, rgb=False, cin_pad=None, x_residual=False, nhwc=None, a_relu=False, head=None):
     """Launches vx_dconv3x3_f16 on planar buffers (x_dev: n_planes planes of [B,H(/2),W(/2),32]); the output goes to
     planes out_plane0.. of `out` (out_planes planes of [B,H,W,32]). Returns all planes of the output buffer as
     [B,H,W,32*planes] f16, or f32 [B,H,W,3] for the rgb head. res1/res2: planar device buffers [cout/32][B,H,W,32]."""
@@ -144,8 +144,23 @@ def dconv(x_dev, n_planes, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=
     a.s2, a.res2, a.res2_plane = s2, (res2.ptr if res2 else None), dst_px
     a.out, a.out_plane = ob.ptr + out_plane0 * dst_px * 2, dst_px
     a.x_residual = int(x_residual)
+    a.a_relu = int(a_relu)
+    if nhwc:  # (channels of the input map, channels of the output/residual maps): NHWC buffers instead of planes
+        cx, co = nhwc
+        a.x_pix, a.x_plane = cx, 32
+        a.out_pix, a.out_plane, a.res1_pix, a.res1_plane, a.res2_pix, a.res2_plane = co, 32, co, 32, co, 32
+    if head is not None:
+        w3, b3, scale = head
+        hw = dev(np.asarray(w3, np.float32))
+        a.epi, a.head_w, a.head_bias, a.head_scale = L.DC_HEAD_F32, hw.ptr, b3, scale
+        ob = empty(B * H * W * 4)
+        a.out = ob.ptr
     L.vx_check(api().vx_dconv3x3_f16(C.byref(a), None))
     sync()
+    if head is not None:
+        return ob.to_numpy(np.float32, (B, H, W))
+    if nhwc:
+        return ob.to_numpy(np.float16, (B, H, W, nhwc[1]))
     if rgb:
         return ob.to_numpy(np.float32, (B, H, W, 3))
     return from_planes(ob.to_numpy(np.float16, (out_planes, B, H, W, 32)))

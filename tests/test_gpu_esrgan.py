@@ -90,6 +90,33 @@ def test_dconv_upsample_and_rgb_head():
     np.testing.assert_allclose(got3, ref3, atol=2e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 74, 74), (64, 32, 40, 100), (32, 32, 33, 70)])
+def test_dconv_nhwc_relu_forms(cin, cout, H, W):
+    """The DPT uses of the kernel (depth-anything.cpp:15-23, 81-94): NHWC maps through pixel / plane strides,
+    conv(relu(x)) + ReLU (residual unit conv 1), conv(x) + two residuals (conv 2), and the fused depth head."""
+    from tests import gpu_util as G
+    rng = np.random.default_rng(cin + cout + H)
+    B = 2
+    x = (rng.standard_normal((B, H, W, cin)) * 0.5).astype(np.float16)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    xd = G.dev(x)
+    got = G.dconv(xd, 0, cin, B, H, W, w, b, act=2, a_relu=True, nhwc=(cin, cout), out=G.empty(B * H * W * cout * 2))
+    ref = np.maximum(_conv_ref(np.maximum(x.astype(np.float32), 0), w, b), 0)
+    np.testing.assert_allclose(got.astype(np.float32), ref, atol=4e-3, rtol=4e-3)
+    r1 = (rng.standard_normal((B, H, W, cout)) * 0.5).astype(np.float16)
+    r2 = (rng.standard_normal((B, H, W, cout)) * 0.5).astype(np.float16)
+    got = G.dconv(xd, 0, cin, B, H, W, w, b, nhwc=(cin, cout), res1=G.dev(r1), res2=G.dev(r2), out=G.empty(B * H * W * cout * 2))
+    ref = _conv_ref(x.astype(np.float32), w, b) + r1.astype(np.float32) + r2.astype(np.float32)
+    np.testing.assert_allclose(got.astype(np.float32), ref, atol=6e-3, rtol=4e-3)
+    if cout == 32:
+        w3, b3 = np.abs(rng.standard_normal(32) * 0.3).astype(np.float32), 0.05
+        got = G.dconv(xd, 0, cin, B, H, W, w, b, nhwc=(cin, cout), head=(w3, b3, 1.5))
+        h2 = np.maximum(_conv_ref(x.astype(np.float32), w, b), 0)
+        want = np.maximum(h2 @ w3 + b3, 0) * 1.5
+        np.testing.assert_allclose(got, want, atol=3e-3, rtol=3e-3)
+
+
 @pytest.mark.parametrize("w,h,fmt", [(256, 256, O.RGB_U8), (300, 260, O.RGBA_U8), (100, 50, O.BGRA_U8), (64, 64, O.ARGB_U8)])
 def test_tiles_in_out(w, h, fmt):
     """vx_esrgan_tiles_in == image_u8_to_f32 per tile (clamped reads); vx_esrgan_tiles_out == tile_merge of all

@@ -39,7 +39,9 @@ class DconvArgs(ctypes.Structure):  # == vx_dconv_args
         ("x", c_void_p), ("x_plane", c_int64), ("cin", c_int), ("up2", c_int), ("B", c_int), ("H", c_int), ("W", c_int),
         ("w", c_void_p), ("bias", c_void_p), ("cout", c_int), ("epi", c_int), ("act", c_int),
         ("s1", c_float), ("res1", c_void_p), ("res1_plane", c_int64), ("s2", c_float), ("res2", c_void_p), ("res2_plane", c_int64),
-        ("out", c_void_p), ("out_plane", c_int64), ("x_residual", c_int), ("stamps", c_void_p),
+        ("out", c_void_p), ("out_plane", c_int64), ("x_residual", c_int),
+        ("x_pix", c_int64), ("out_pix", c_int64), ("res1_pix", c_int64), ("res2_pix", c_int64), ("a_relu", c_int),
+        ("head_w", c_void_p), ("head_bias", c_float), ("head_scale", c_float), ("stamps", c_void_p),
     ]
 
 
@@ -47,7 +49,7 @@ class TileLayout(ctypes.Structure):  # == vx_tile_layout
     _fields_ = [(n, c_int) for n in ("image_w", "image_h", "overlap_x", "overlap_y", "n_x", "n_y", "tile_w", "tile_h")]
 
 
-DC_F16, DC_RGB_F32 = 0, 1
+DC_F16, DC_RGB_F32, DC_HEAD_F32 = 0, 1, 2
 
 
 class GemmArgs(ctypes.Structure):  # == vx_gemm_args
@@ -95,7 +97,7 @@ KERNEL_SYMBOLS = [
     "vx_attention_f16",
     "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
-    "vx_dconv3x3_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
+    "vx_dconv3x3_f16", "vx_dconv_prepare", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
 ]
 
 

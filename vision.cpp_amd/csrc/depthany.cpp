@@ -205,7 +205,22 @@ struct packer {
         if (b && with_data) bf = to_f32(*b);
         if (out_k) *out_k = kh;
         if (out_cin) *out_cin = cin;
-        return matrix(with_data ? w.data() : nullptr, cout, kh * kw * cin, b && with_data ? bf.data() : nullptr, b ? cout : 0, n_align);
+        packed_gemm g = matrix(with_data ? w.data() : nullptr, cout, kh * kw * cin, b && with_data ? bf.data() : nullptr, b ? cout : 0, n_align);
+        if (kh == 3 && kw == 3 && cin % 32 == 0 && (cout == 32 || cout == 64) && g.N == cout && b) {
+            // second packing for the LDS-ring conv kernel (kernels_dconv.hip), used on the large DPT maps
+            g.d_cin = cin;
+            g.dw = ab.alloc((size_t)cin * 9 * cout * 2);
+            if (with_data) {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(ab.data.data() + g.dw);
+                for (int n = 0; n < cout; ++n)
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int c = 0; c < cin; ++c) {
+                            const size_t row = ((size_t)(c / 32) * 9 + tap) * cout + n;
+                            dst[row * 32 + (size_t)(((c % 32) / 8) ^ ((n >> 2) & 3)) * 8 + c % 8] = f32_to_f16(w[((size_t)n * 9 + tap) * cin + c]);
+                        }
+            }
+        }
+        return g;
     }
 
     // conv_transpose_2d with kernel == stride (reference nn.cpp:117-129, weight ne [kw,kh,Cout,Cin] ==
@@ -322,6 +337,7 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
     }
 
     VX(vx_set_device(dev.index));
+    VX(vx_dconv_prepare());
     for (void*& s : model->aux_stream) VX(vx_stream_create(&s));
     VX(vx_event_create(&model->fork_event));
     for (void*& e : model->join_event) VX(vx_event_create(&e));
@@ -576,7 +592,36 @@ struct exec_ctx {
         a.ldo = ldo;
         a.res1 = res1; a.res2 = res2;
         mark(group, 1, 2.0 * M * g.n_real * g.k_real, (double)B * H * W * Cin * 2 + (double)M * g.n_real * 2 + (double)g.N * g.K * 2);
+        if (dconv_ok(g, k, stride, pad, W, Cin, epi) && !relu) {
+            vx_dconv_args d = dconv_base(g, x, B, H, W, Cin);
+            d.epi = VX_DC_F16;
+            d.act = epi == VX_EPI_F16_RELU ? 2 : 0;
+            d.a_relu = a_relu;
+            d.s1 = d.s2 = 1.0f;
+            d.res1 = res1; d.res1_pix = ldo; d.res1_plane = 32;
+            d.res2 = res1 ? res2 : nullptr; d.res2_pix = ldo; d.res2_plane = 32;
+            if (!res1 && res2) { d.res1 = res2; d.res2 = nullptr; }
+            d.out = y; d.out_pix = ldo; d.out_plane = 32;
+            VX(vx_dconv3x3_f16(&d, stream));
+            return;
+        }
         gemm(a);
+    }
+    // 3x3 / stride 1 / pad 1 convs on maps at least 64 wide go to the persistent LDS-ring kernel written for the ESRGAN
+    // row (1.4-1.9x the halo kernel on these shapes, tools/conv_compare.py); it reads and writes the NHWC maps in place
+    // through its pixel / plane strides
+    static bool dconv_ok(packed_gemm const& g, int k, int stride, int pad, int W, int Cin, int epi) {
+        static const bool off = getenv("VISP_NO_DCONV") != nullptr;
+        return !off && g.dw != SIZE_MAX && k == 3 && stride == 1 && pad == 1 && W >= 64 && Cin == g.d_cin &&
+               (epi == VX_EPI_F16 || epi == VX_EPI_F16_RELU || epi == VX_EPI_F16_ADD || epi == VX_EPI_HEAD_OUT);
+    }
+    vx_dconv_args dconv_base(packed_gemm const& g, const void* x, int B, int H, int W, int Cin) {
+        vx_dconv_args d;
+        memset(&d, 0, sizeof d);
+        d.x = x; d.x_pix = Cin; d.x_plane = 32; d.cin = Cin;
+        d.B = B; d.H = H; d.W = W;
+        d.w = wptr(g.dw); d.bias = reinterpret_cast<const float*>(wa + g.b); d.cout = g.N;
+        return d;
     }
 };
 
@@ -792,7 +837,15 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         a.head_bias = Wt.head3_b;
         a.head_scale = P.max_depth;
         c.mark("head_conv2+3", 1, 2.0 * B * H * W * 32 * (Wt.head2.k_real + 1), (double)B * H * W * (HC * 2 + 4));
-        c.gemm(a);
+        if (exec_ctx::dconv_ok(Wt.head2, 3, 1, 1, W, HC, VX_EPI_HEAD_OUT)) {
+            vx_dconv_args d = c.dconv_base(Wt.head2, c.buf("hup"), B, H, W, HC);
+            d.epi = VX_DC_HEAD_F32;
+            d.head_w = c.fptr(Wt.head3_w); d.head_bias = Wt.head3_b; d.head_scale = P.max_depth;
+            d.out = depth;
+            VX(vx_dconv3x3_f16(&d, stream));
+        } else {
+            c.gemm(a);
+        }
     } else {
         c.conv(Wt.head2, c.buf("hup"), B, H, W, HC, 3, 1, 1, c.buf("h2"), Wt.head2.N, VX_EPI_F16_RELU, false, false, nullptr, nullptr, "head_conv2");
         c.mark("head_out", 1, 2.0 * B * H * W * Wt.head2.N, (double)B * H * W * (Wt.head2.N * 2 + 4));

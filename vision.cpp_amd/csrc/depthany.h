@@ -48,6 +48,8 @@ i32x2 depthany_image_extent(i32x2 extent, depthany_params const&);        // dep
 // pads are zero) + optional f32 bias [N].
 struct packed_gemm {
     size_t w = 0, b = SIZE_MAX; // byte offsets into the arena
+    size_t dw = SIZE_MAX;       // 3x3 convs with Cin % 32 == 0, Cout in {32, 64}: the same kernel as vx_dconv3x3_f16 slabs
+    int d_cin = 0;              // [cin/32][9][cout][32] f16 (16-byte groups at g ^ ((n >> 2) & 3)), see kernels_dconv.hip
     int N = 0, K = 0;           // padded
     int n_real = 0, k_real = 0; // for FLOP accounting and n_valid
 };

@@ -184,6 +184,7 @@ esrgan_model* esrgan_load_model(char const* filepath, backend_device const& dev,
         if (g->cin_real != Wt.nf || g->cout_real != Wt.nf) throw except("ESRGAN: trunk/HR conv has shape %d -> %d", g->cin_real, g->cout_real);
 
     VX(vx_set_device(dev.index));
+    VX(vx_dconv_prepare());
     model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256);
     VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
     if (with_data) {

@@ -57,7 +57,9 @@ struct tile_grid {
 
 // STAMP: diagnostics build (args.stamps != NULL) that sums shader-clock cycles per phase; the product instantiation
 // carries none of it.
-template <int COUT, int EPI, bool STAMP>
+// AR: ReLU applied to the input while its fragments are read (the DPT residual units convolve relu(x),
+// depth-anything.cpp:15-23).
+template <int COUT, int EPI, bool AR, bool STAMP>
 __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     constexpr int MT = 2;                       // M-tiles (32 pixels) per wave
     constexpr int HALO_PIX = 18 * 34;           // both tile shapes
@@ -111,6 +113,8 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     const int nch = p.cin / CK;
     const int nch_total_bytes = nch * 9 * COUT * PIXB;
     const long x_plane_bytes = p.x_plane * 2;
+    const int x_pix = p.x_pix ? (int)p.x_pix : CK;           // elements between pixels (32 = planar, C = NHWC)
+    const long out_pix = p.out_pix ? p.out_pix : CK, res1_pix = p.res1_pix ? p.res1_pix : CK, res2_pix = p.res2_pix ? p.res2_pix : CK;
 
     // ---- tile geometry (wave-uniform) and per-lane halo sources
     struct geom { int b, y0, x0, tws; }; // tws = log2(tile width): 5 (16x32) or 4 (32x16)
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     __amdgpu_buffer_rsrc_t x_rsrc;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, nch_total_bytes, 0x00020000);
     auto setup_src = [&](const geom& g) {
-        const long img_bytes = (long)Hs * Ws * (CK * 2);
+        const long img_bytes = (long)Hs * Ws * x_pix * 2;
         // the descriptor spans image b of plane 0 .. image b of the last plane; chunk c is reached by a scalar offset
         x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + g.b * img_bytes, 0,
                                                    (int)((nch - 1) * x_plane_bytes + img_bytes), 0x00020000);
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             asm volatile("" : "+v"(pk)); // keep the unpacked fields out of registers across the tile loop
             const int iy = g.y0 - 1 + (int)(pk & 0xff), ix = g.x0 - 1 + (int)((pk >> 8) & 0xff);
             const bool valid = (pk >> 24) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int e = ((iy >> up) * Ws + (ix >> up)) * CK + (int)(((pk >> 16) & 3) << 3);
+            const int e = ((iy >> up) * Ws + (ix >> up)) * x_pix + (int)(((pk >> 16) & 3) << 3);
             hoff[j] = valid ? (unsigned)(e * 2) : OOB;
         }
     };
@@ -236,6 +240,10 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
 #pragma unroll
         for (int u = 0; u < NWIN; ++u) af[u] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][u][ks] + HSt * HALO_BYTES);
     };
+    auto relu_frag = [](f16x8& a) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = a[j] > (f16)0 ? a[j] : (f16)0;
+    };
     // x_residual (COUT = 64): "+ x" of a dense block's last conv (esrgan.cpp:38-40) without reading x again: the
     // centre-tap pixel fragments of chunks 0 and 1 ARE x[0:64], so two extra k-steps per chunk multiply them with
     // (1/s1) * identity (exact in f16) into the matching channel tile; the epilogue's * s1 makes it "+ x".
@@ -248,6 +256,10 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         for (int grp = 0; grp < NGRP; ++grp) {
             if (grp + 1 < NGRP) load_group(hs_c, ws_c, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AR) {
+#pragma unroll
+                for (int u = 0; u < NWIN; ++u) relu_frag(af[grp & 1][u]);
+            }
 #pragma unroll
             for (int u = 0; u < NWIN; ++u)
 #pragma unroll
@@ -300,6 +312,12 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         for (int grp = 0; grp < 18 / G; ++grp) {
             if (grp + 1 < 18 / G) load_group_tap(hs_c, ws_c, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AR) {
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) relu_frag(af[grp & 1][q][mi]);
+            }
 #pragma unroll
             for (int q = 0; q < G; ++q)
 #pragma unroll
@@ -452,7 +470,27 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         constexpr int done = HSt; // the halo stage of the last chunk: free once every wave has left compute()
 
         // ---- epilogue
-        if constexpr (EPI == VX_DC_RGB_F32) {
+        if constexpr (EPI == VX_DC_HEAD_F32) {
+            // head.conv2 + ReLU + head.conv3 (1x1 -> 1) + ReLU [* max_depth] (depth-anything.cpp:87-94): the 32-channel
+            // map never leaves the registers. A lane holds 16 of pixel r's 32 channels, its partner lane (h ^ 1) the rest.
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                float part = 0.0f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = 8 * g + 4 * h + q;
+                        part += fmaxf(acc[mi][0][4 * g + q] + s_bias[n], 0.0f) * p.head_w[n];
+                    }
+                part += __shfl_xor(part, 32, 64);
+                const int oy = cur.y0 + out_row(cur.tws, mi), ox = cur.x0 + out_col(cur.tws);
+                if (h == 0 && oy < H && ox < W)
+                    reinterpret_cast<float*>(p.out)[((long)cur.b * H + oy) * W + ox] = fmaxf(part + p.head_bias, 0.0f) * p.head_scale;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // data-dependent store count: drain before the next counted wait
+            prev_halo = false;
+        } else if constexpr (EPI == VX_DC_RGB_F32) {
             // channels 0..2 of pixel r sit in acc[mi][0][0..2] of the lanes with h == 0
             if (h == 0) {
 #pragma unroll
@@ -478,7 +516,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             unsigned char* st;
             if constexpr (COUT == 32) st = smem + done * HALO_BYTES + wave * 64 * PITCH;
             else st = (wave < 4 ? smem + done * HALO_BYTES : smem + W_BASE + WSt * W_BYTES) + (wave & 3) * 64 * PITCH;
-            const bool lrelu = (p.act & 1) != 0;
+            const float slope = p.act == 1 ? 0.2f : (p.act == 2 ? 0.0f : 1.0f); // max(v, slope*v): LeakyReLU 0.2 / ReLU / identity
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
                 const int ml = mi * 32 + r; // row inside the wave's staging block
@@ -490,10 +528,8 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                         const float4 bias = *reinterpret_cast<const float4*>(s_bias + nl);
                         float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
                                       acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
-                        if (lrelu) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.2f * v[j]);
-                        }
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], slope * v[j]);
                         if (xres) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] *= p.s1;
@@ -529,11 +565,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                 }
                 if (R1) {
 #pragma unroll
-                    for (int it = 0; it < NB; ++it) ra[it] = *reinterpret_cast<const f16x8*>(R1 + jp * p.res1_plane + pixel[it] * CK + je);
+                    for (int it = 0; it < NB; ++it) ra[it] = *reinterpret_cast<const f16x8*>(R1 + jp * p.res1_plane + pixel[it] * res1_pix + je);
                 }
                 if (R2) {
 #pragma unroll
-                    for (int it = 0; it < NB; ++it) rc[it] = *reinterpret_cast<const f16x8*>(R2 + jp * p.res2_plane + pixel[it] * CK + je);
+                    for (int it = 0; it < NB; ++it) rc[it] = *reinterpret_cast<const f16x8*>(R2 + jp * p.res2_plane + pixel[it] * res2_pix + je);
                 }
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {
@@ -550,7 +586,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s2 + (float)rc[it][q]);
                     }
-                    f16* dst = ok[it] ? reinterpret_cast<f16*>(p.out) + jp * p.out_plane + pixel[it] * CK + je : trash;
+                    f16* dst = ok[it] ? reinterpret_cast<f16*>(p.out) + jp * p.out_plane + pixel[it] * out_pix + je : trash;
                     *reinterpret_cast<f16x8*>(dst) = v[it];
                 }
             }
@@ -604,18 +640,27 @@ int dconv_grid_blocks() {
     return n_cu; // one 8-wave block per CU (its LDS ring takes the whole 160 KB)
 }
 
-template <int COUT, int EPI, bool STAMP>
-int launch_variant(const vx_dconv_args& a, hipStream_t s) {
-    constexpr int HALO_BYTES = 5 * NW * 1024;
-    constexpr int smem = (COUT == 32 ? 3 : 2) * HALO_BYTES + 2 * 9 * COUT * PIXB + COUT * 4;
+template <int COUT>
+constexpr int dconv_smem_bytes() { return (COUT == 32 ? 3 : 2) * (5 * NW * 1024) + 2 * 9 * COUT * PIXB + COUT * 4; }
+
+template <int COUT, int EPI, bool AR, bool STAMP>
+int prepare_variant() { // > 64 KB of dynamic LDS needs the attribute; set once, outside any stream capture
     static bool attr_set = false;
     if (!attr_set) {
-        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, AR, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     dconv_smem_bytes<COUT>()));
         attr_set = true;
     }
+    return 1;
+}
+
+template <int COUT, int EPI, bool AR, bool STAMP>
+int launch_variant(const vx_dconv_args& a, hipStream_t s) {
+    constexpr int smem = dconv_smem_bytes<COUT>();
+    if (!prepare_variant<COUT, EPI, AR, STAMP>()) return 0;
     const long tiles = (long)a.B * tile_grid(a.H, a.W).total();
     const int blocks = (int)(tiles < dconv_grid_blocks() ? tiles : dconv_grid_blocks());
-    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, STAMP>), dim3(blocks), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, AR, STAMP>), dim3(blocks), dim3(512), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
 }
@@ -623,9 +668,10 @@ int launch_variant(const vx_dconv_args& a, hipStream_t s) {
 template <int COUT, int EPI>
 int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
     if constexpr (EPI == VX_DC_F16) {
-        if (a.stamps) return launch_variant<COUT, EPI, true>(a, s);
+        if (a.a_relu) return launch_variant<COUT, EPI, true, false>(a, s);
+        if (a.stamps) return launch_variant<COUT, EPI, false, true>(a, s);
     }
-    return launch_variant<COUT, EPI, false>(a, s);
+    return launch_variant<COUT, EPI, false, false>(a, s);
 }
 
 // ---- ESRGAN pre/post-processing --------------------------------------------------------------------------------
@@ -726,6 +772,12 @@ __global__ void esr_tiles_out_kernel(const float* __restrict__ tiles, int B, vx_
 
 } // namespace
 
+extern "C" int vx_dconv_prepare(void) {
+    return prepare_variant<32, VX_DC_F16, false, false>() && prepare_variant<32, VX_DC_F16, true, false>() &&
+           prepare_variant<64, VX_DC_F16, false, false>() && prepare_variant<64, VX_DC_F16, true, false>() &&
+           prepare_variant<32, VX_DC_RGB_F32, false, false>() && prepare_variant<32, VX_DC_HEAD_F32, false, false>();
+}
+
 extern "C" int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream) {
     const vx_dconv_args& a = *args;
     VX_REQUIRE(a.x && a.w && a.out, "vx_dconv3x3_f16: null operand");
@@ -736,15 +788,21 @@ extern "C" int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream) {
                (reinterpret_cast<uintptr_t>(a.out) & 15) == 0, "vx_dconv3x3_f16: operands must be 16-byte aligned");
     {
         const int64_t src_pixels = (int64_t)(a.H >> (a.up2 ? 1 : 0)) * (a.W >> (a.up2 ? 1 : 0));
-        VX_REQUIRE(a.cin == 32 || (a.x_plane >= (int64_t)a.B * src_pixels * 32 && a.x_plane % 8 == 0), "vx_dconv3x3_f16: bad input plane stride");
+        const int64_t xp = a.x_pix ? a.x_pix : 32;
+        VX_REQUIRE(xp >= 32 && xp % 8 == 0 && a.out_pix % 8 == 0 && a.res1_pix % 8 == 0 && a.res2_pix % 8 == 0, "vx_dconv3x3_f16: pixel strides must be multiples of 8 (input >= 32)");
+        VX_REQUIRE(a.cin == 32 || (a.x_plane % 8 == 0 && (xp > 32 ? a.x_plane >= 32 : a.x_plane >= (int64_t)a.B * src_pixels * 32)), "vx_dconv3x3_f16: bad input plane stride");
         // buffer descriptors address with 32-bit offsets; 2^31 is the zero-fill sentinel
-        VX_REQUIRE((int64_t)(a.cin / 32 - 1) * a.x_plane * 2 + src_pixels * 64 < (int64_t)0x7fffffff,
+        VX_REQUIRE((int64_t)(a.cin / 32 - 1) * a.x_plane * 2 + src_pixels * xp * 2 < (int64_t)0x7fffffff,
                    "vx_dconv3x3_f16: input planes span more than 2 GiB; run fewer images per call");
     }
     hipStream_t s = as_stream(stream);
     if (a.epi == VX_DC_RGB_F32) {
-        VX_REQUIRE(a.cout == 32, "vx_dconv3x3_f16: the rgb head takes weights padded to 32 outputs");
+        VX_REQUIRE(a.cout == 32 && !a.a_relu, "vx_dconv3x3_f16: the rgb head takes weights padded to 32 outputs");
         return launch_dconv<32, VX_DC_RGB_F32>(a, s);
+    }
+    if (a.epi == VX_DC_HEAD_F32) {
+        VX_REQUIRE(a.cout == 32 && a.head_w && !a.a_relu, "vx_dconv3x3_f16: the fused depth head is a 32-channel epilogue with head_w set");
+        return launch_dconv<32, VX_DC_HEAD_F32>(a, s);
     }
     VX_REQUIRE(a.epi == VX_DC_F16, "vx_dconv3x3_f16: unknown epilogue %d", a.epi);
     VX_REQUIRE(a.out_plane % 8 == 0 && a.res1_plane % 8 == 0 && a.res2_plane % 8 == 0, "vx_dconv3x3_f16: plane strides must be multiples of 8");
