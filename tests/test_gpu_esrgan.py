@@ -226,7 +226,8 @@ def test_upscale_batch_vs_oracle_compute(tiny):
     from visioncpp_amd import synth
     from visioncpp_amd.vision import ImageFormat
     m, om, cfg = tiny
-    for (w, h, fmt, ofmt) in ((300, 260, ImageFormat.rgb_u8, O.RGB_U8), (96, 80, ImageFormat.bgra_u8, O.BGRA_U8)):
+    for (w, h, fmt, ofmt) in ((300, 260, ImageFormat.rgb_u8, O.RGB_U8), (96, 80, ImageFormat.bgra_u8, O.BGRA_U8),
+                              (640, 481, ImageFormat.rgb_u8, O.RGB_U8)):   # 3 x 3 tiles of 224 x 176: two lanes, several groups
         ch = 3 if fmt is ImageFormat.rgb_u8 else 4
         rng = np.random.default_rng(w)
         base = synth.images(2, w, h, seed=w)

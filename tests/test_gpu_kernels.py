@@ -210,6 +210,26 @@ def test_attention_online_softmax_rescale_branch():
     assert rel_err(got, want) < 5e-3
 
 
+def test_attention_all_scores_far_below_zero():
+    """Every score of a row is about -40 in the exp2 domain: the running maximum must follow it down (an online
+    softmax anchored at zero would underflow every P in f16 and divide by a zero row sum)."""
+    rng = np.random.default_rng(5)
+    T = 200
+    q = np.zeros((1, T, 64), np.float32)
+    k = np.zeros((1, T, 64), np.float32)
+    q[..., 0], k[..., 0] = 16.0, -14.0          # q.k * 0.125 = -28 -> -40.4 in the exp2 domain
+    q[..., 1:] = _h(_rand(rng, 1, T, 63) * 0.3)
+    k[..., 1:] = _h(_rand(rng, 1, T, 63) * 0.3)
+    v = _h(_rand(rng, 1, T, 64))
+    out = empty(T * 64 * 2)
+    L.vx_check(api().vx_attention_f16(dev(_h(q * 0.125).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr,
+                                      dev(v.astype(np.float16)).ptr, out.ptr, 1, 1, T, None))
+    sync()
+    got = out.to_numpy(np.float16, (1, T, 64)).astype(np.float32)
+    assert np.isfinite(got).all()
+    assert rel_err(got, oracle.attention(q[0], k[0], v[0], 1, 0.125)[None]) < 5e-3
+
+
 @pytest.mark.parametrize("M,Cc", [(1370, 384), (77, 128), (33, 768), (10, 96)])
 def test_layernorm(M, Cc):
     rng = np.random.default_rng(Cc)
