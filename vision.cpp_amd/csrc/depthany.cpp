@@ -206,10 +206,12 @@ struct packer {
         if (out_k) *out_k = kh;
         if (out_cin) *out_cin = cin;
         packed_gemm g = matrix(with_data ? w.data() : nullptr, cout, kh * kw * cin, b && with_data ? bf.data() : nullptr, b ? cout : 0, n_align);
-        if (kh == 3 && kw == 3 && cin % 32 == 0 && (cout == 32 || cout == 64) && g.N == cout && b) {
-            // second packing for the LDS-ring conv kernel (kernels_dconv.hip), used on the large DPT maps
-            g.d_cin = cin;
-            g.dw = ab.alloc((size_t)cin * 9 * cout * 2);
+        if (kh == 3 && kw == 3 && cin % 16 == 0 && (cout == 32 || cout == 64) && g.N == cout) {
+            // second packing for the LDS-ring conv kernel (kernels_dconv.hip), used on the large DPT maps. Cin = 48
+            // (neck conv 0) is padded to 64 with zero weights: the kernel then reads 16 channels of the next pixel
+            // (or the descriptor's zero fill at the end of the map) against zeros.
+            g.d_cin = round_up(cin, 32);
+            g.dw = ab.alloc((size_t)g.d_cin * 9 * cout * 2);
             if (with_data) {
                 uint16_t* dst = reinterpret_cast<uint16_t*>(ab.data.data() + g.dw);
                 for (int n = 0; n < cout; ++n)
@@ -612,15 +614,15 @@ struct exec_ctx {
     // through its pixel / plane strides
     static bool dconv_ok(packed_gemm const& g, int k, int stride, int pad, int W, int Cin, int epi) {
         static const bool off = getenv("VISP_NO_DCONV") != nullptr;
-        return !off && g.dw != SIZE_MAX && k == 3 && stride == 1 && pad == 1 && W >= 64 && Cin == g.d_cin &&
+        return !off && g.dw != SIZE_MAX && k == 3 && stride == 1 && pad == 1 && W >= 64 && round_up(Cin, 32) == g.d_cin &&
                (epi == VX_EPI_F16 || epi == VX_EPI_F16_RELU || epi == VX_EPI_F16_ADD || epi == VX_EPI_HEAD_OUT);
     }
     vx_dconv_args dconv_base(packed_gemm const& g, const void* x, int B, int H, int W, int Cin) {
         vx_dconv_args d;
         memset(&d, 0, sizeof d);
-        d.x = x; d.x_pix = Cin; d.x_plane = 32; d.cin = Cin;
+        d.x = x; d.x_pix = Cin; d.x_plane = 32; d.cin = g.d_cin;
         d.B = B; d.H = H; d.W = W;
-        d.w = wptr(g.dw); d.bias = reinterpret_cast<const float*>(wa + g.b); d.cout = g.N;
+        d.w = wptr(g.dw); d.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b); d.cout = g.N;
         return d;
     }
 };

@@ -152,9 +152,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, nch_total_bytes, 0x00020000);
     auto setup_src = [&](const geom& g) {
         const long img_bytes = (long)Hs * Ws * x_pix * 2;
-        // the descriptor spans image b of plane 0 .. image b of the last plane; chunk c is reached by a scalar offset
-        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + g.b * img_bytes, 0,
-                                                   (int)((nch - 1) * x_plane_bytes + img_bytes), 0x00020000);
+        // planar: the descriptor spans image b of plane 0 .. image b of the last plane, chunk c is reached by a scalar
+        // offset. NHWC (x_pix > 32): chunks sit inside the pixel, the descriptor ends with the image -- channels past
+        // the map's last pixel (a Cin padded up to 32, e.g. 48 -> 64 with zero weights) are zero-filled, not read.
+        const long span = x_pix > CK ? img_bytes : (nch - 1) * x_plane_bytes + img_bytes;
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + g.b * img_bytes, 0, (int)span, 0x00020000);
 #pragma unroll
         for (int j = 0; j < HJ; ++j) {
             unsigned pk = hpack[j];
