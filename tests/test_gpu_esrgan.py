@@ -322,3 +322,19 @@ def test_c_api_strided_view(tiny):
         L.get_lib().visp_image_destroy(out_data)
     assert (out_view.width, out_view.height, out_view.format) == (w * cfg.scale, h * cfg.scale, 0)   # rgba_u8
     assert np.array_equal(res, m.upscale_batch(img[None])[0])
+
+
+def test_cwhn_layout_files_load_identically(tmp_path_factory, device):
+    """--layout nhwc GGUFs (tensor_data_layout = cwhn, kernels OHWI, no conv2d_weights list) of both families pack to
+    the same weight arena as the default files: bit-identical outputs."""
+    from visioncpp_amd import synth
+    from visioncpp_amd.vision import Model
+    d = tmp_path_factory.mktemp("layouts")
+    cfg = synth.ESRGAN_TINY
+    img = synth.images(1, 60, 44, seed=2)
+    outs = [Model.load(synth.write_esrgan_gguf(d / f"e_{lay}.gguf", cfg, 7, layout=lay), device).upscale_batch(img) for lay in ("whcn", "cwhn")]
+    assert np.array_equal(outs[0], outs[1])
+    imgs = synth.images(1, 112, 112, seed=3)
+    outs = [Model.load(synth.write_gguf(d / f"d_{lay}.gguf", synth.MINI, 4, layout=lay) and d / f"d_{lay}.gguf", device).compute_batch(imgs)
+            for lay in ("whcn", "cwhn")]
+    assert np.array_equal(outs[0], outs[1])

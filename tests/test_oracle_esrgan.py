@@ -102,3 +102,17 @@ def test_esrgan_compute_tiles_equal_untiled():
     img2 = synth.images(1, 300, 260, seed=4)[0]
     out2 = O.esrgan_compute(m, cfg.scale, cfg.num_blocks, img2, O.RGB_U8)
     assert out2.shape == (600, 520, 4) or out2.shape == (520, 600, 4)
+
+
+def test_cwhn_layout_file_gives_the_same_network():
+    """A GGUF written with --layout nhwc (kernels OHWI, no conv2d_weights list, tensor_data_layout = cwhn) must load
+    to the same f32 tensors as the default whcn file (model_transfer permutes only listed kernels, ml.cpp:449-516)."""
+    cfg = synth.ESRGAN_TINY
+    sd = synth.esrgan_state_dict(cfg, 7)
+    tw, cw = synth.esrgan_gguf_tensors(sd, "whcn")
+    tc, cc = synth.esrgan_gguf_tensors(sd, "cwhn")
+    assert cc == [] and len(cw) == sum(1 for v in sd.values() if v.ndim == 4)
+    x = synth.images(1, 20, 16, seed=1)[0].astype(np.float32) / np.float32(255.0)
+    a = O.esrgan_generate(O.Model(tw, cw, "whcn"), cfg.scale, cfg.num_blocks, x)
+    b = O.esrgan_generate(O.Model(tc, cc, "cwhn"), cfg.scale, cfg.num_blocks, x)
+    assert np.array_equal(a, b)

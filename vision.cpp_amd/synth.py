@@ -120,8 +120,10 @@ def _is_conv_2d(name: str, t: np.ndarray) -> bool:  # scripts/convert.py:111-117
     return t.ndim == 4 and t.shape[2] == t.shape[3] and t.shape[2] in (1, 3, 4, 7, 14) and name.endswith("weight")
 
 
-def gguf_tensors(sd: dict[str, np.ndarray]):
+def gguf_tensors(sd: dict[str, np.ndarray], layout: str = "whcn"):
     """Applies convert_depth_anything's per-tensor rules (scripts/convert.py:460-475).
+    layout "whcn" = the converter's default (--layout nchw): other conv kernels stay OIHW and are listed in
+    conv2d_weights; "cwhn" (--layout nhwc): Writer.convert_tensor_2d permutes them to OHWI at once, nothing is listed.
 
     Returns (ordered dict name -> array as stored, conv2d_weights index list)."""
     out: dict[str, np.ndarray] = {}
@@ -132,6 +134,8 @@ def gguf_tensors(sd: dict[str, np.ndarray]):
                 t = np.ascontiguousarray(t.transpose(0, 2, 3, 1))  # conv_2d_to_nhwc: Cout H W Cin
             elif "0.resize" in name or "1.resize" in name:
                 pass  # ConvTranspose2d, layout untouched
+            elif layout == "cwhn":
+                t = np.ascontiguousarray(t.transpose(0, 2, 3, 1))
             else:
                 conv2d.append(len(out))  # Writer.convert_tensor_2d with layout nchw
         if "position_embeddings" in name or "cls_token" in name:
@@ -141,11 +145,11 @@ def gguf_tensors(sd: dict[str, np.ndarray]):
     return out, conv2d
 
 
-def write_gguf(path: str | Path, cfg: Config = SMALL, seed: int = 0, sd: dict[str, np.ndarray] | None = None) -> Path:
+def write_gguf(path: str | Path, cfg: Config = SMALL, seed: int = 0, sd: dict[str, np.ndarray] | None = None, layout: str = "whcn") -> Path:
     sd = sd if sd is not None else state_dict(cfg, seed)
-    tensors, conv2d = gguf_tensors(sd)
+    tensors, conv2d = gguf_tensors(sd, layout)
     w = GGUFWriter(path, "depthanything")
-    w.add_string("depthanything.tensor_data_layout", "whcn")  # set_tensor_layout_default(nchw)
+    w.add_string("depthanything.tensor_data_layout", layout)  # set_tensor_layout_default(nchw) unless --layout nhwc
     w.add_int32("dino.patch_size", cfg.patch_size)
     w.add_int32("dino.embed_dim", cfg.embed_dim)
     w.add_int32("depthanything.image_size", cfg.image_size)
@@ -154,7 +158,8 @@ def write_gguf(path: str | Path, cfg: Config = SMALL, seed: int = 0, sd: dict[st
     w.add_array_i32("depthanything.feature_layers", cfg.feature_layers)
     w.add_uint32("general.quantization_version", 2)
     w.add_uint32("general.file_type", 1)  # f16
-    w.add_array_i32("depthanything.conv2d_weights", conv2d)
+    if conv2d:  # Writer.add_conv2d_weight_indices: only when something is listed
+        w.add_array_i32("depthanything.conv2d_weights", conv2d)
     for name, t in tensors.items():
         w.add_tensor(name, t)
     w.write()
@@ -228,29 +233,35 @@ def esrgan_state_dict(cfg: EsrganConfig = ESRGAN_X4, seed: int = 0) -> dict[str,
     return sd
 
 
-def esrgan_gguf_tensors(sd: dict[str, np.ndarray]):
-    """scripts/convert.py:504-527 (convert_esrgan, --quantize f16, default layout): every conv kernel stays OIHW and is
-    listed in esrgan.conv2d_weights; all float tensors -> f16."""
+def esrgan_gguf_tensors(sd: dict[str, np.ndarray], layout: str = "whcn"):
+    """scripts/convert.py:504-527 (convert_esrgan, --quantize f16): with the default layout every conv kernel stays
+    OIHW and is listed in esrgan.conv2d_weights; with --layout nhwc ("cwhn") kernels are stored OHWI and nothing is
+    listed; all float tensors -> f16."""
     out: dict[str, np.ndarray] = {}
     conv2d: list[int] = []
     for name, t in sd.items():
         if _is_conv_2d(name, t):
-            conv2d.append(len(out))
+            if layout == "cwhn":
+                t = np.ascontiguousarray(t.transpose(0, 2, 3, 1))
+            else:
+                conv2d.append(len(out))
         out[name] = t.astype(np.float16)
     return out, conv2d
 
 
-def write_esrgan_gguf(path: str | Path, cfg: EsrganConfig = ESRGAN_X4, seed: int = 0, sd: dict[str, np.ndarray] | None = None) -> Path:
+def write_esrgan_gguf(path: str | Path, cfg: EsrganConfig = ESRGAN_X4, seed: int = 0, sd: dict[str, np.ndarray] | None = None,
+                      layout: str = "whcn") -> Path:
     sd = sd if sd is not None else esrgan_state_dict(cfg, seed)
-    tensors, conv2d = esrgan_gguf_tensors(sd)
+    tensors, conv2d = esrgan_gguf_tensors(sd, layout)
     w = GGUFWriter(path, "esrgan")
-    w.add_string("esrgan.tensor_data_layout", "whcn")
+    w.add_string("esrgan.tensor_data_layout", layout)
     w.add_int32("esrgan.scale", cfg.scale)
     w.add_int32("esrgan.block_count", cfg.num_blocks)
     w.add_int32("esrgan.filter_count", cfg.num_filters)
     w.add_uint32("general.quantization_version", 2)
     w.add_uint32("general.file_type", 1)
-    w.add_array_i32("esrgan.conv2d_weights", conv2d)
+    if conv2d:
+        w.add_array_i32("esrgan.conv2d_weights", conv2d)
     for name, t in tensors.items():
         w.add_tensor(name, t)
     w.write()
