@@ -218,8 +218,11 @@ esrgan_model::~esrgan_model() {
 
 namespace {
 
-void reserve(esrgan_model& m, int n_tiles_total, int tw, int th, size_t img_in_bytes, size_t img_out_bytes) {
+// ws.img_in / ws.img_out (capacity for the host entry point's u8 staging images) are kept, everything else is sized
+// for this call
+void reserve(esrgan_model& m, int n_tiles_total, int tw, int th) {
     esrgan_workspace& ws = m.ws;
+    const size_t img_in_bytes = ws.img_in, img_out_bytes = ws.img_out;
     // two concurrent lanes when there is enough work to split (timing runs keep one lane: events on one stream)
     const int lanes = (m.streams >= 2 && !m.timing && n_tiles_total >= 8) ? 2 : 1;
     const int group = std::min((n_tiles_total + lanes - 1) / lanes, m.tile_group);
@@ -254,7 +257,6 @@ void reserve(esrgan_model& m, int n_tiles_total, int tw, int th, size_t img_in_b
         p += round_up<size_t>(it.bytes, 256);
     }
     ws.group = group; ws.lanes = lanes; ws.tile_w = tw; ws.tile_h = th; ws.scale = s;
-    ws.img_in = img_in_bytes; ws.img_out = img_out_bytes;
 }
 
 struct exec {
@@ -416,8 +418,7 @@ void esrgan_compute_batch_device(esrgan_model& m, void const* img_dev, int batch
     tile_layout tiles({{w, h}}, esrgan_default_tile_size, esrgan_tile_overlap);
     tile_layout tiles_out = tile_scale(tiles, m.params.scale);
     const int n_total = batch * tiles.total();
-    const bool own_io = img_dev == m.ws.in_u8 && img_dev != nullptr;
-    reserve(m, n_total, tiles.tile_size[0], tiles.tile_size[1], own_io ? m.ws.img_in : 0, own_io ? m.ws.img_out : 0);
+    reserve(m, n_total, tiles.tile_size[0], tiles.tile_size[1]);
     exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
     vx_tile_layout tin = to_vx(tiles), tout = to_vx(tiles_out);
     ex.mark("tiles_in", 0, (double)n_total * tiles.tile_size[0] * tiles.tile_size[1] * 67);
@@ -436,7 +437,9 @@ void esrgan_compute_batch_host(esrgan_model& m, uint8_t const* img, int batch, i
     tile_layout tiles({{w, h}}, esrgan_default_tile_size, esrgan_tile_overlap);
     const int sc = m.params.scale;
     const size_t in_bytes = (size_t)batch * w * h * n_channels(format), out_bytes = (size_t)batch * w * sc * h * sc * 4;
-    reserve(m, batch * tiles.total(), tiles.tile_size[0], tiles.tile_size[1], in_bytes, out_bytes);
+    m.ws.img_in = std::max(m.ws.img_in, in_bytes);
+    m.ws.img_out = std::max(m.ws.img_out, out_bytes);
+    reserve(m, batch * tiles.total(), tiles.tile_size[0], tiles.tile_size[1]); // same layout as the call below computes
     void* s = m.backend->stream;
     VX(vx_memcpy_h2d(m.ws.in_u8, img, in_bytes, s));
     esrgan_compute_batch_device(m, m.ws.in_u8, batch, w, h, format, m.ws.out_u8, s);
@@ -466,7 +469,7 @@ void esrgan_generate_host(esrgan_model& m, float const* rgb, int n, int w, int h
     if (!m.weights_uploaded) throw except("esrgan: weights have not been uploaded");
     if (n < 1 || w < 1 || h < 1) throw except("esrgan: empty input");
     VX(vx_set_device(m.backend->index));
-    reserve(m, n, w, h, 0, 0);
+    reserve(m, n, w, h);
     const size_t px = (size_t)n * w * h;
     std::vector<uint16_t> x0(px * 32, 0);
     for (size_t i = 0; i < px; ++i)
