@@ -338,3 +338,18 @@ def test_cwhn_layout_files_load_identically(tmp_path_factory, device):
     outs = [Model.load(synth.write_gguf(d / f"d_{lay}.gguf", synth.MINI, 4, layout=lay) and d / f"d_{lay}.gguf", device).compute_batch(imgs)
             for lay in ("whcn", "cwhn")]
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_large_image_many_tiles(tmp_path_factory, device):
+    """1300 x 1000 at x4: 6 x 5 tiles of 240 x 224 (30 tiles, 860k up-sampled pixels each). The executor must cap the
+    tile group so that a group's planes stay addressable (32-bit buffer descriptors), and the result must not depend on
+    the grouping."""
+    from visioncpp_amd import synth
+    cfg = synth.EsrganConfig(num_blocks=1, scale=4, name="big")
+    m, _ = _load(tmp_path_factory, device, cfg, 3)
+    img = synth.images(1, 1300, 1000, seed=8)
+    a = m.upscale_batch(img)
+    assert a.shape == (1, 4000, 5200, 4) and (a[..., 3] == 255).all() and a[..., :3].std() > 1
+    m.set_tile_group(4)
+    b = m.upscale_batch(img)
+    assert np.array_equal(a, b)

@@ -225,9 +225,12 @@ void reserve(esrgan_model& m, int n_tiles_total, int tw, int th) {
     const size_t img_in_bytes = ws.img_in, img_out_bytes = ws.img_out;
     // two concurrent lanes when there is enough work to split (timing runs keep one lane: events on one stream)
     const int lanes = (m.streams >= 2 && !m.timing && n_tiles_total >= 8) ? 2 : 1;
-    const int group = std::min((n_tiles_total + lanes - 1) / lanes, m.tile_group);
     const int s = m.params.scale;
     const size_t px = (size_t)tw * th;
+    // the conv kernel addresses a map's planes through a 32-bit buffer descriptor: keep two planes of the largest
+    // (up-sampled) map of a group below 2 GiB
+    const int addr_cap = (int)std::max<size_t>(1, ((size_t)1 << 30) / (px * s * s * 64));
+    const int group = std::min({(n_tiles_total + lanes - 1) / lanes, m.tile_group, addr_cap});
     struct item { void** p; size_t bytes; };
     const size_t hr_bytes = m.weights.up.empty() ? (size_t)group * px * 64 * 2 : (size_t)group * px * s * s * 64 * 2;
     std::vector<item> items = {
