@@ -1,24 +1,29 @@
-// Dense-block 3x3 convolution for the ESRGAN / Real-ESRGAN RRDB stack on gfx950
-// (reference src/visp/arch/esrgan.cpp:13-79: conv_block = conv_2d 3x3 s1 p1 + leaky_relu 0.2, dense concat,
-//  x5*0.2 + x, nearest x2 upsample before the up-convs).
+// 3x3 / stride 1 / pad 1 convolution with 32 or 64 output channels on gfx950: the conv engine of the ESRGAN /
+// Real-ESRGAN RRDB stack (reference src/visp/arch/esrgan.cpp:13-79: conv_block = conv_2d 3x3 + leaky_relu 0.2, dense
+// concat, x5*0.2 + x, nearest x2 upsample before the up-convs) and of the large DPT maps of Depth-Anything
+// (src/visp/arch/depth-anything.cpp:15-30, 81-94: residual units on relu(x), head convs).
 //
-// What is different from the DPT halo kernel (kernels_conv.hip):
-//  * activations are PLANAR in groups of 32 channels: a map is [C/32 planes][pixels][32] f16 (plane stride given by
-//    the caller). A residual dense block keeps [x | x1 | x2 | x3 | x4] as six planes of one buffer, every conv reads
-//    the first 2+k planes and writes its 32 outputs as the next plane, so the reference's four concat copies never
-//    happen -- and a chunk's halo row is one contiguous 2 KB run in HBM, a tile's output rows likewise;
-//  * Cin is walked in chunks of 32 channels: a chunk's 18x34 halo (39 KB) and its weight slab 9 x COUT x 32
-//    (18/36 KB, pre-swizzled at load time so the copy is linear) are streamed by LDS-DMA into a 2-stage ring while
-//    the MFMAs of the previous chunk run; ONE barrier per chunk. Weights come from LDS, not from L1: with 8 waves
-//    sharing a slab the L1/TA path carries (halo + slab) once per block instead of one fragment load per wave
-//    per k-step, which is what bounds the DPT kernel at Cout = 32;
-//  * 512 threads = 8 waves, 16 x 32 output pixels per block, a wave owns two rows (two 32-pixel M-tiles) and all
-//    COUT channels; MFMA orientation is swapped (D = W-fragment x pixel-fragment) so a lane owns a pixel and four
-//    consecutive channels per register group;
-//  * the 36 fragment addresses (9 taps x 2 rows x 2 k-steps, XOR-swizzled) are chunk-invariant and live in VGPRs;
-//  * nearest x2 upsampling is folded into the halo source address (esrgan.cpp:13-19), LeakyReLU and the scaled
-//    residuals (v*s1 + res1)*s2 + res2 into the epilogue (esrgan.cpp:38-40, 49-50, 64-65);
-//  * the RGB head (Cout = 3 padded to 32) writes f32 straight from the accumulators.
+//  * Layouts. Activations are f16 in groups of 32 channels; a map is addressed by (pixel stride, group stride):
+//    PLANAR [C/32 planes][pixels][32] for ESRGAN (pixel stride 32, group stride = plane) or NHWC (pixel stride C, group
+//    stride 32) for the DPT maps. In planar form a residual dense block keeps [x | x1 | x2 | x3 | x4] as six planes of
+//    one buffer, every conv reads the first 2+k planes and writes its 32 outputs as the next plane, so the
+//    reference's four concat copies never happen -- and a chunk's halo row is one contiguous 2 KB run in HBM.
+//  * Persistent blocks (one 8-wave block per CU, its ring fills the LDS), XCD-aware contiguous tile runs. A block's
+//    (tile, 32-channel chunk) steps form ONE stream: the next tile's first chunk lands under the current tile's last
+//    chunk and epilogue. A step's 18x34-pixel halo (39 KB) and 9 x COUT x 32 weight slab (18/36 KB, pre-swizzled at
+//    load time so the copy is linear) arrive by `buffer_load ... lds` (descriptor in SGPRs, 32-bit lane offsets,
+//    out-of-map pixels zero-filled by the range check = conv padding). Halo ring: 3 stages for COUT = 32 (issued two
+//    steps ahead), 2 for COUT = 64; slabs: 2 stages. ONE raw s_barrier per step; counted vmcnt waits leave younger
+//    halos and the tile's output stores in flight.
+//  * Tiles are 16x32 pixels; a remainder strip of 1..16 columns is tiled 32x16 (same pixel count, same halo size).
+//  * MFMA 32x32x16 f16 with swapped operands (D = W-fragment x pixel-fragment: a lane owns a pixel and four
+//    consecutive channels per register group). COUT = 32: per (tap column, k-step) 3 weight fragments and 4 pixel
+//    WINDOWS feed 6 MFMAs (M-tile mi and tap row ky read window mi + ky); COUT = 64: per-tap loop with 2x2 register
+//    blocking and the DMA pieces issued from inside the loop. Which form where was decided by same-device A/B runs.
+//  * Epilogues: bias, LeakyReLU 0.2 / ReLU, v*s1 + res1, v*s2 + res2 through a staged f16 tile and 16-byte stores;
+//    "+ x" of a dense block's conv5 without re-reading x (identity fold, see x_residual); nearest x2 upsampling is a
+//    shift in the halo source address; the ESRGAN RGB head and the fused DPT depth head (conv2 + ReLU + 1x1 conv3 +
+//    ReLU) write f32 straight from the accumulators; AR = ReLU on the input fragments.
 #include "vx_common.h"
 
 #include <type_traits>
