@@ -166,6 +166,12 @@ VX_API int vx_attention_f16(const void* q, const void* k, const void* v, void* o
 /* ---- LayerNorm (nn.cpp:14-19): x f32 [M,C] -> y f16 [M,C]; biased variance, eps in sqrt --- */
 VX_API int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y, int M, int C,
                                 float eps, void* stream);
+/* x f32 [M,C] += lambda[C] * y_in f16 [M,C] (stored back), then LayerNorm of the updated row -> y f16 [M,C]
+ * (y == NULL: update only). The residual add of dino.cpp:80-90 fused into the LayerNorm that follows it; the
+ * projection GEMM then writes y_in with a plain f16 epilogue. C in {128, 384, 768, 1024}. */
+VX_API int vx_layernorm_resid_supported(int C);
+VX_API int vx_layernorm_resid_f32_f16(float* x, const void* y_in, const float* lambda, const float* w, const float* b, void* y, int M,
+                                      int C, float eps, void* stream);
 
 /* ---- pre-processing (depth-anything.cpp:130-140, image.cpp:215-255) + im2col of the 14x14
  * stride-14 patch embedding (nn.cpp:166-180): rgb_u8 [B,H,W,3] -> f16 [B*P, Kp],

@@ -95,7 +95,7 @@ KERNEL_SYMBOLS = [
     "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_stream_wait_event", "vx_graph_begin_capture",
     "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_conv3x3_supported", "vx_conv3x3_f16",
     "vx_attention_f16",
-    "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
+    "vx_layernorm_f32_f16", "vx_layernorm_resid_supported", "vx_layernorm_resid_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
     "vx_dconv3x3_f16", "vx_dconv_prepare", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
 ]
@@ -195,6 +195,8 @@ def init() -> ctypes.CDLL:
     lib.vx_head_out_f32.argtypes = [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_int, c_void_p]
     lib.vx_minmax_normalize.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
     lib.vx_f32_to_u8.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    lib.vx_layernorm_resid_supported.argtypes = [c_int]
+    lib.vx_layernorm_resid_f32_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
     lib.vx_dconv3x3_f16.argtypes = [POINTER(DconvArgs), c_void_p]
     lib.vx_esrgan_tiles_in.argtypes = [c_void_p, c_int, c_int, c_int, c_int, POINTER(TileLayout), c_void_p, c_void_p]
     lib.vx_esrgan_tiles_out.argtypes = [c_void_p, c_int, POINTER(TileLayout), c_void_p, c_void_p, c_void_p]
