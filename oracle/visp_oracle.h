@@ -19,6 +19,11 @@
  *   - HuggingFace transformers' DepthAnythingForDepthEstimation (the model whose
  *     state-dict names the reference's GGUF uses verbatim, scripts/convert.py:428-475).
  * Whole-path parity against the reference *binary* stays unpinned (no ggml, no GGUF).
+ *
+ * ESRGAN part (vo_esrgan_*, vo_tile_*): pinned (tests/test_oracle_esrgan.py) against the literal tile_merge
+ * vectors of tests/test-image.cpp:303-360 and against outputs of the reference's own torch modules
+ * (tests/test_esrgan.py:70-212 ResidualDenseBlock_5C / RRDB / RRDBNet, imported in the CPU container by
+ * tests/golden/make_golden_esrgan.py; fixtures tests/golden/esrgan_*.npz).
  */
 #ifndef VISP_ORACLE_H
 #define VISP_ORACLE_H

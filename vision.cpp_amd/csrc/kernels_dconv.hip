@@ -26,6 +26,7 @@
 //    ReLU) write f32 straight from the accumulators; AR = ReLU on the input fragments.
 #include "vx_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -64,7 +65,9 @@ struct tile_grid {
 // carries none of it.
 // AR: ReLU applied to the input while its fragments are read (the DPT residual units convolve relu(x),
 // depth-anything.cpp:15-23).
-template <int COUT, int EPI, bool AR, bool STAMP>
+// RES: number of weight slabs kept RESIDENT in LDS for the whole launch (all cin/32 chunks of the conv fit next to the
+// halo ring), 0 = slabs stream through a 2-stage ring. HSV: halo ring stages of this variant.
+template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2)>
 __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     constexpr int MT = 2;                       // M-tiles (32 pixels) per wave
     constexpr int HALO_PIX = 18 * 34;           // both tile shapes
@@ -79,9 +82,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     constexpr int WJ = (W_INSTR + NW - 1) / NW;
     // The kernel is bound by the LDS-DMA stream (57/77 KB per 36/72 MFMAs per wave), i.e. by bytes in flight per
     // CU: with COUT = 32 the LDS has room for a THIRD halo stage, so halos are issued two steps ahead.
-    constexpr int HS = COUT == 32 ? 3 : 2;      // halo stages; slabs always 2
-    constexpr int W_BASE = HS * HALO_BYTES;     // LDS: [halo 0 .. HS-1 | slab 0 | slab 1 | bias]
-    constexpr int BIAS_BASE = W_BASE + 2 * W_BYTES;
+    constexpr int HS = HSV;                     // halo stages
+    constexpr int WSLOTS = RES ? RES : 2;       // slab slots: the streaming ring has 2
+    static_assert(!RES || COUT == 32, "resident slabs are built for COUT = 32 (the COUT = 64 epilogue stages through slab space)");
+    constexpr int W_BASE = HS * HALO_BYTES;     // LDS: [halo 0 .. HS-1 | slab slots | bias]
+    constexpr int BIAS_BASE = W_BASE + WSLOTS * W_BYTES;
     constexpr int NCH16 = COUT / 8, PITCH = COUT * 2;
     static_assert(BIAS_BASE + COUT * 4 <= 160 * 1024, "LDS ring too large");
     static_assert(256 * PITCH <= HALO_BYTES && 256 * PITCH <= W_BYTES + (COUT == 32 ? HALO_BYTES : 0), "output staging does not fit a stage");
@@ -236,14 +241,14 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // fragment groups: one (tap column kx, k-step ks) = 3 weight fragments per N-tile + 4 pixel windows for 6 NI
     // MFMAs, prefetched one group ahead (register double buffer)
     constexpr int NGRP = 6;
-    auto load_group = [&](auto hs_c, auto ws_c, int grp, f16x8 (&af)[NWIN], f16x8 (&wf)[3][NI]) {
+    auto load_group = [&](auto hs_c, auto ws_c, int wslot_off, int grp, f16x8 (&af)[NWIN], f16x8 (&wf)[3][NI]) {
         constexpr int HSt = decltype(hs_c)::value, WSt = decltype(ws_c)::value;
         const int kx = grp >> 1, ks = grp & 1;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                wf[ky][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[WSt][ks] + ((ky * 3 + kx) * COUT + ni * 32) * PIXB);
+                wf[ky][ni] = *reinterpret_cast<const f16x8*>(smem + w_addr[RES ? 0 : WSt][ks] + wslot_off + ((ky * 3 + kx) * COUT + ni * 32) * PIXB);
 #pragma unroll
         for (int u = 0; u < NWIN; ++u) af[u] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][u][ks] + HSt * HALO_BYTES);
     };
@@ -258,10 +263,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     const f16 inv_s1 = (f16)(1.0f / p.s1);
     auto compute_win = [&](auto hs_c, auto ws_c, int chunk, auto&& feed) {
         f16x8 af[2][NWIN], wf[2][3][NI];
-        load_group(hs_c, ws_c, 0, af[0], wf[0]);
+        const int wslot_off = RES ? chunk * W_BYTES : 0; // resident slabs: slot = chunk
+        load_group(hs_c, ws_c, wslot_off, 0, af[0], wf[0]);
 #pragma unroll
         for (int grp = 0; grp < NGRP; ++grp) {
-            if (grp + 1 < NGRP) load_group(hs_c, ws_c, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
+            if (grp + 1 < NGRP) load_group(hs_c, ws_c, wslot_off, grp + 1, af[(grp + 1) & 1], wf[(grp + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (AR) {
 #pragma unroll
@@ -399,7 +405,11 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         move_cursor();
         return true;
     };
-    issue_slab(0, 0);
+    if constexpr (RES) {
+        for (int k = 0; k < nch; ++k) issue_slab(k, k); // every slab, once per block; older than any halo, so the first wait covers them
+    } else {
+        issue_slab(0, 0);
+    }
     bool prev_halo = false; // did the previous step issue a halo (younger than the slab this step waits for)?
 #pragma unroll
     for (int k = 0; k < HS - 1; ++k) prev_halo = advance_halo(k);
@@ -442,7 +452,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         asm volatile("" ::: "memory");
         stamp(1); // barrier
         const bool last_chunk = c + 1 == nch;
-        const bool do_slab = !last_chunk || t_cur + t_step < t_end;
+        const bool do_slab = !RES && (!last_chunk || t_cur + t_step < t_end);
         const int slab_c = last_chunk ? 0 : c + 1;
         const bool do_halo = h_t < t_end;
         const int halo_c = h_c;
@@ -619,6 +629,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             if (step(integral_constant<int, 0>{}, integral_constant<int, 0>{})) break;
             if (step(integral_constant<int, 1>{}, integral_constant<int, 1>{})) break;
             if (step(integral_constant<int, 2>{}, integral_constant<int, 0>{})) break;
+            if constexpr (RES) continue; // no slab parity to track: the pattern repeats after HS steps
             if (step(integral_constant<int, 0>{}, integral_constant<int, 1>{})) break;
             if (step(integral_constant<int, 1>{}, integral_constant<int, 0>{})) break;
             if (step(integral_constant<int, 2>{}, integral_constant<int, 1>{})) break;
@@ -647,27 +658,28 @@ int dconv_grid_blocks() {
     return n_cu; // one 8-wave block per CU (its LDS ring takes the whole 160 KB)
 }
 
-template <int COUT>
-constexpr int dconv_smem_bytes() { return (COUT == 32 ? 3 : 2) * (5 * NW * 1024) + 2 * 9 * COUT * PIXB + COUT * 4; }
+template <int COUT, int RES, int HSV>
+constexpr int dconv_smem_bytes() { return HSV * (5 * NW * 1024) + (RES ? RES : 2) * 9 * COUT * PIXB + COUT * 4; }
 
-template <int COUT, int EPI, bool AR, bool STAMP>
+template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2)>
 int prepare_variant() { // > 64 KB of dynamic LDS needs the attribute; set once, outside any stream capture
+    static_assert(dconv_smem_bytes<COUT, RES, HSV>() <= 160 * 1024, "variant does not fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, AR, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     dconv_smem_bytes<COUT>()));
+        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, dconv_smem_bytes<COUT, RES, HSV>()));
         attr_set = true;
     }
     return 1;
 }
 
-template <int COUT, int EPI, bool AR, bool STAMP>
+template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2)>
 int launch_variant(const vx_dconv_args& a, hipStream_t s) {
-    constexpr int smem = dconv_smem_bytes<COUT>();
-    if (!prepare_variant<COUT, EPI, AR, STAMP>()) return 0;
+    constexpr int smem = dconv_smem_bytes<COUT, RES, HSV>();
+    if (!prepare_variant<COUT, EPI, AR, STAMP, RES, HSV>()) return 0;
     const long tiles = (long)a.B * tile_grid(a.H, a.W).total();
     const int blocks = (int)(tiles < dconv_grid_blocks() ? tiles : dconv_grid_blocks());
-    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, AR, STAMP>), dim3(blocks), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV>), dim3(blocks), dim3(512), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
 }
@@ -677,6 +689,15 @@ int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
     if constexpr (EPI == VX_DC_F16) {
         if (a.a_relu) return launch_variant<COUT, EPI, true, false>(a, s);
         if (a.stamps) return launch_variant<COUT, EPI, false, true>(a, s);
+        if constexpr (COUT == 32) {
+            // All slabs of a short conv can stay in LDS. Measured per conv of a dense block (same device, ms per 69
+            // launches, streamed -> resident): cin 64 with 3 halo stages 6.62 -> 6.72, cin 96 with 2 stages 7.79 ->
+            // 7.75, cin 128 with 2 stages 9.47 -> 9.04. Default: resident at cin = 128 only. VISP_DCONV_RES: 0 = never,
+            // 1 = cin 64, 2 = cin <= 128, unset = cin 128.
+            static const int res_mode = getenv("VISP_DCONV_RES") ? atoi(getenv("VISP_DCONV_RES")) : -1;
+            if (res_mode >= 1 && a.cin == 64) return launch_variant<32, EPI, false, false, 2, 3>(a, s);   // 120 + 36 KB
+            if ((res_mode >= 2 && a.cin <= 128) || (res_mode < 0 && a.cin == 128)) return launch_variant<32, EPI, false, false, 4, 2>(a, s); // 80 + 72 KB
+        }
     }
     return launch_variant<COUT, EPI, false, false>(a, s);
 }
@@ -781,6 +802,7 @@ __global__ void esr_tiles_out_kernel(const float* __restrict__ tiles, int B, vx_
 
 extern "C" int vx_dconv_prepare(void) {
     return prepare_variant<32, VX_DC_F16, false, false>() && prepare_variant<32, VX_DC_F16, true, false>() &&
+           prepare_variant<32, VX_DC_F16, false, false, 2, 3>() && prepare_variant<32, VX_DC_F16, false, false, 4, 2>() &&
            prepare_variant<64, VX_DC_F16, false, false>() && prepare_variant<64, VX_DC_F16, true, false>() &&
            prepare_variant<32, VX_DC_RGB_F32, false, false>() && prepare_variant<32, VX_DC_HEAD_F32, false, false>();
 }
