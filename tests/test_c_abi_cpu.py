@@ -165,3 +165,29 @@ def test_esrgan_converter_accepts_both_key_layouts(tmp_path):
             assert t.dtype == ref.tensors[name].dtype and np.array_equal(t, ref.tensors[name])
     with pytest.raises(ValueError, match="not an RRDBNet"):
         convert.convert_esrgan({"foo.weight": np.zeros(3, np.float32)}, tmp_path / "x.gguf")
+
+
+def test_ctypes_structs_match_the_c_headers(tmp_path):
+    """The Python mirrors of the argument blocks must have the C layout: compile a probe against include/*.h with gcc
+    and compare sizeof / offsetof of the last field (catches a field added on one side only)."""
+    import subprocess
+
+    root = Path(__file__).resolve().parents[1]
+    probe = tmp_path / "probe.c"
+    probe.write_text('''
+#include <stddef.h>
+#include <stdio.h>
+#include "visp_hip_kernels.h"
+#include "visp_c_api.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vx_gemm_args), offsetof(vx_gemm_args, debug_stamps), sizeof(vx_dconv_args),
+           offsetof(vx_dconv_args, stamps), sizeof(vx_tile_layout), sizeof(visp_image_view), sizeof(visp_timing), sizeof(visp_esrgan_info));
+    return 0;
+}
+''')
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", str(root / "include"), str(probe), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(L.GemmArgs), L.GemmArgs.debug_stamps.offset, C.sizeof(L.DconvArgs), L.DconvArgs.stamps.offset, C.sizeof(L.TileLayout),
+            C.sizeof(L.ImageView), C.sizeof(L.Timing), C.sizeof(L.EsrganInfo)]
+    assert got == want, (got, want)
