@@ -392,3 +392,79 @@ def esrgan_compute(model: "Model", scale: int, n_blocks: int, img_u8: np.ndarray
     _check(_esr_lib().vo_esrgan_compute(model._h, C.byref(p), img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, fmt,
                                         out.ctypes.data_as(C.POINTER(C.c_uint8))))
     return out
+
+
+# ---- TinyViT image encoder of MobileSAM (reference src/visp/arch/mobile-sam.cpp:20-215) --------------------------------
+
+class TinyVitLayer(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("resolution", "embed_dim", "depth", "num_heads", "window_size", "downsample")]
+
+
+class TinyVitParams(C.Structure):
+    _fields_ = [("img_size", C.c_int), ("layers", TinyVitLayer * 4)]
+
+
+def _tv_lib():
+    L = lib()
+    if not getattr(L, "_tv_ready", False):
+        fp = C.POINTER(C.c_float)
+        L.vo_tinyvit_encode.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(TinyVitParams), fp, fp, C.POINTER(Capture), C.c_int]
+        L.vo_tinyvit_block.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.vo_attention_rel_bias.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.vo_conv2d_depthwise_nhwc.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, fp]
+        L.vo_tinyvit_set_gelu_modes.argtypes = [C.c_int, C.c_int]
+        L._tv_ready = True
+    return L
+
+
+def tinyvit_set_gelu_modes(mbconv_mode: int = GELU_GGML_F16_LUT, other_mode: int = GELU_GGML_F16_LUT):
+    _tv_lib().vo_tinyvit_set_gelu_modes(mbconv_mode, other_mode)
+
+
+def tinyvit_params(img_size: int, layers) -> TinyVitParams:
+    p = TinyVitParams()
+    p.img_size = img_size
+    for i, l in enumerate(layers):
+        p.layers[i] = TinyVitLayer(*l)
+    return p
+
+
+def tinyvit_encode(model: "Model", params: TinyVitParams, image: np.ndarray, prefix: str = "enc", captures: dict[str, int] | None = None):
+    """image: normalised rgb f32 [img, img, 3] -> [res, res, 256]"""
+    x = _f32(image)
+    res = params.layers[3].resolution
+    out = np.empty((res, res, 256), np.float32)
+    caps = captures or {}
+    bufs = {k: np.empty(n, np.float32) for k, n in caps.items()}
+    names = [k.encode() for k in caps]
+    carr = (Capture * max(1, len(caps)))(*[Capture(nm, _fp(bufs[k]), bufs[k].size, 0) for nm, k in zip(names, caps)])
+    _check(_tv_lib().vo_tinyvit_encode(model._h, prefix.encode(), C.byref(params), _fp(x), _fp(out), carr, len(caps)))
+    if captures is None:
+        return out
+    return out, {k: bufs[k][: carr[i].written].copy() for i, k in enumerate(caps)}
+
+
+def tinyvit_block(model: "Model", prefix: str, x: np.ndarray, res: int, heads: int, window: int) -> np.ndarray:
+    x = _f32(x).copy()
+    assert x.shape[0] == res * res
+    _check(_tv_lib().vo_tinyvit_block(model._h, prefix.encode(), _fp(x), res, x.shape[1], heads, window))
+    return x
+
+
+def attention_rel_bias(model: "Model", prefix: str, x: np.ndarray, heads: int) -> np.ndarray:
+    x = _f32(x)
+    n_win, N, dim = x.shape
+    y = np.empty_like(x)
+    _check(_tv_lib().vo_attention_rel_bias(model._h, prefix.encode(), _fp(x), n_win, N, dim, heads, _fp(y)))
+    return y
+
+
+def conv2d_depthwise_nhwc(x: np.ndarray, w: np.ndarray, b: np.ndarray | None, stride: int, pad: int) -> np.ndarray:
+    """x [H,W,C]; w [k,k,C] (tap-major, channel contiguous)"""
+    x, w = _f32(x), _f32(w)
+    H, W_, Cc = x.shape
+    k = w.shape[0]
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W_ + 2 * pad - k) // stride + 1
+    y = np.empty((OH, OW, Cc), np.float32)
+    _tv_lib().vo_conv2d_depthwise_nhwc(_fp(x), H, W_, Cc, _fp(w), _fp(_f32(b)) if b is not None else None, k, stride, pad, _fp(y))
+    return y

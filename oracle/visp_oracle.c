@@ -1183,3 +1183,289 @@ int vo_esrgan_compute(const vo_model* m, const vo_esrgan_params* P, const uint8_
     free(in_tile); free(out_tile); free(out_img);
     return ok;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* TinyViT (MobileSAM image encoder): reference src/visp/arch/mobile-sam.cpp:20-215 */
+
+/* ggml_conv_2d_dw_direct + add_bias_2d (nn.cpp:102-115): y[oy][ox][c] = b[c] + sum_{ky,kx} x[..][c] * w[c][ky][kx] */
+void vo_conv2d_depthwise_nhwc(const float* x, int H, int W, int C, const float* w, const float* bias, int k, int stride, int pad, float* y) {
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+#pragma omp parallel for schedule(static)
+    for (int oy = 0; oy < OH; ++oy)
+        for (int ox = 0; ox < OW; ++ox) {
+            float* o = y + ((int64_t)oy * OW + ox) * C;
+            for (int c = 0; c < C; ++c) o[c] = 0.0f;
+            for (int ky = 0; ky < k; ++ky) {
+                const int iy = oy * stride - pad + ky;
+                if (iy < 0 || iy >= H) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    const int ix = ox * stride - pad + kx;
+                    if (ix < 0 || ix >= W) continue;
+                    const float* xi = x + ((int64_t)iy * W + ix) * C;
+                    const float* wk = w + (int64_t)(ky * k + kx) * C; /* [C,1,kw,kh] in ggml order: c contiguous */
+                    for (int c = 0; c < C; ++c) o[c] = __builtin_fmaf(xi[c], wk[c], o[c]);
+                }
+            }
+            if (bias)
+                for (int c = 0; c < C; ++c) o[c] = o[c] + bias[c];
+        }
+}
+
+/* The reference applies ggml_gelu everywhere (tanh form through an f16 table). Its torch twin uses GELU(tanh) in MBConv /
+ * PatchMerging and exact GELU in the transformer Mlp; the pin tests switch the oracle to those exact forms to check the
+ * structure at 1e-4, and back to the reference's form for everything else. (torch: MBConv = GELU(tanh); PatchEmbed,
+ * PatchMerging and Mlp = exact GELU.) */
+static int g_tv_gelu_mbconv = VO_GELU_GGML_F16_LUT, g_tv_gelu_other = VO_GELU_GGML_F16_LUT;
+void vo_tinyvit_set_gelu_modes(int mbconv_mode, int other_mode) { g_tv_gelu_mbconv = mbconv_mode; g_tv_gelu_other = other_mode; }
+static void gelu_inplace(float* x, int64_t n) { vo_gelu(x, x, n, g_tv_gelu_other); }
+static void gelu_mbconv(float* x, int64_t n) { vo_gelu(x, x, n, g_tv_gelu_mbconv); }
+
+/* conv_2d_batch_norm (mobile-sam.cpp:15-18): BatchNorm is fused at conversion, so this is conv_2d(m["c"]) */
+static int tv_conv_bn(const vo_model* m, const char* prefix, const float* x, int H, int Wd, int Cin, int stride, int pad, int* OH, int* OW,
+                      int* Cout, float** y) {
+    char p[200];
+    snprintf(p, sizeof p, "%s.c", prefix);
+    return conv_m(m, p, x, 1, H, Wd, Cin, stride, pad, OH, OW, Cout, y);
+}
+static int tv_dwconv_bn(const vo_model* m, const char* prefix, const float* x, int H, int Wd, int C, int stride, int* OH, int* OW, float** y) {
+    char p[200];
+    snprintf(p, sizeof p, "%s.c", prefix);
+    int64_t ne[4];
+    const float* w = W(m, p, "weight", ne, 1); /* [C,1,kw,kh] */
+    if (!w) return 0;
+    if (ne[0] != C || ne[1] != 1 || ne[2] != ne[3]) VO_FAIL("depthwise conv %s: unexpected shape [%lld,%lld,%lld,%lld]", p, (long long)ne[0], (long long)ne[1], (long long)ne[2], (long long)ne[3]);
+    const int k = (int)ne[2], pad = 1;
+    *OH = (H + 2 * pad - k) / stride + 1; *OW = (Wd + 2 * pad - k) / stride + 1;
+    *y = (float*)malloc((size_t)*OH * *OW * C * 4);
+    vo_conv2d_depthwise_nhwc(x, H, Wd, C, w, W(m, p, "bias", NULL, 0), k, stride, pad, *y);
+    return 1;
+}
+
+/* linear on rows: y [M][N] = x [M][K] w^T + b, weights by name */
+static int tv_linear(const vo_model* m, const char* prefix, const float* x, int64_t M, int K, int* N, float** y) {
+    int64_t ne[4];
+    const float* w = W(m, prefix, "weight", ne, 1); /* ne = [K, N] */
+    if (!w) return 0;
+    if (ne[0] != K) VO_FAIL("linear %s: K mismatch (%lld vs %d)", prefix, (long long)ne[0], K);
+    *N = (int)ne[1];
+    *y = (float*)malloc((size_t)M * *N * 4);
+    vo_linear(x, M, K, w, W(m, prefix, "bias", NULL, 0), *N, *y);
+    return 1;
+}
+static int tv_layer_norm(const vo_model* m, const char* prefix, const float* x, int64_t M, int C, float eps, float* y) {
+    const float* w = W(m, prefix, "weight", NULL, 1);
+    const float* b = W(m, prefix, "bias", NULL, 1);
+    if (!w || !b) return 0;
+    vo_layer_norm(x, M, C, w, b, eps, y);
+    return 1;
+}
+
+/* attention_rel_bias (mobile-sam.cpp:122-131): layer_norm, qkv linear split per head as [q | k | v] (split_qkv dim 1,
+ * nn.cpp:182-208), softmax(q k^T * scale + bias[h]) v (nn.cpp:210-244 with mask), proj */
+int vo_attention_rel_bias(const vo_model* m, const char* prefix, const float* x, int n_win, int N, int dim, int heads, float* y) {
+    char p[200];
+    const int hd = dim / heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    int64_t bne[4];
+    const float* bias = W(m, prefix, "attention_biases_indexed", bne, 1); /* torch [heads][N][N] */
+    if (!bias) return 0;
+    if (bne[0] != N || bne[1] != N || bne[2] != heads) VO_FAIL("%s.attention_biases_indexed: shape [%lld,%lld,%lld], expected [%d,%d,%d]", prefix, (long long)bne[0], (long long)bne[1], (long long)bne[2], N, N, heads);
+    const int64_t M = (int64_t)n_win * N;
+    float* ln = (float*)malloc((size_t)M * dim * 4);
+    snprintf(p, sizeof p, "%s.norm", prefix);
+    if (!tv_layer_norm(m, p, x, M, dim, 1e-5f, ln)) { free(ln); return 0; }
+    float* qkv = NULL;
+    int n3;
+    snprintf(p, sizeof p, "%s.qkv", prefix);
+    if (!tv_linear(m, p, ln, M, dim, &n3, &qkv)) { free(ln); return 0; }
+    free(ln);
+    if (n3 != 3 * dim) { free(qkv); VO_FAIL("%s.qkv: %d outputs, expected %d", prefix, n3, 3 * dim); }
+    float* att = (float*)malloc((size_t)M * dim * 4);
+#pragma omp parallel for schedule(static)
+    for (int wi = 0; wi < n_win; ++wi) {
+        float* s = (float*)malloc((size_t)N * 4);
+        for (int h = 0; h < heads; ++h)
+            for (int i = 0; i < N; ++i) {
+                const float* q = qkv + ((int64_t)wi * N + i) * n3 + h * 3 * hd;
+                float mx = -INFINITY;
+                for (int j = 0; j < N; ++j) {
+                    const float* k = qkv + ((int64_t)wi * N + j) * n3 + h * 3 * hd + hd;
+                    float d = 0.0f;
+                    for (int c = 0; c < hd; ++c) d = __builtin_fmaf(q[c], k[c], d);
+                    d = d * scale + bias[((int64_t)h * N + i) * N + j]; /* ggml_soft_max_ext(x, mask, scale) */
+                    s[j] = d;
+                    if (d > mx) mx = d;
+                }
+                double sum = 0.0;
+                for (int j = 0; j < N; ++j) { float e = expf(s[j] - mx); s[j] = e; sum += (double)e; }
+                const float inv = (float)(1.0 / sum);
+                float* o = att + ((int64_t)wi * N + i) * dim + h * hd;
+                for (int c = 0; c < hd; ++c) o[c] = 0.0f;
+                for (int j = 0; j < N; ++j) {
+                    const float pj = s[j] * inv;
+                    const float* v = qkv + ((int64_t)wi * N + j) * n3 + h * 3 * hd + 2 * hd;
+                    for (int c = 0; c < hd; ++c) o[c] = __builtin_fmaf(pj, v[c], o[c]);
+                }
+            }
+        free(s);
+    }
+    free(qkv);
+    float* pr = NULL;
+    int np;
+    snprintf(p, sizeof p, "%s.proj", prefix);
+    int ok = tv_linear(m, p, att, M, dim, &np, &pr);
+    free(att);
+    if (!ok) return 0;
+    memcpy(y, pr, (size_t)M * dim * 4);
+    free(pr);
+    return 1;
+}
+
+/* tiny_vit_block (mobile-sam.cpp:133-160): window attention (zero padding BEFORE the norm, as window_partition does)
+ * + residual, depthwise 3x3 local conv, mlp + residual */
+int vo_tinyvit_block(const vo_model* m, const char* prefix, float* x, int res, int dim, int heads, int ws) {
+    char p[200];
+    const int pad = (ws - res % ws) % ws, pr = res + pad, nw = pr / ws, N = ws * ws;
+    const int64_t n_win = (int64_t)nw * nw;
+    float* win = (float*)calloc((size_t)n_win * N * dim, 4); /* window_partition: [n_win][ws*ws][dim], zeros where padded */
+    for (int y = 0; y < res; ++y)
+        for (int xx = 0; xx < res; ++xx)
+            memcpy(win + ((((int64_t)(y / ws) * nw + xx / ws) * ws + y % ws) * ws + xx % ws) * dim, x + ((int64_t)y * res + xx) * dim, (size_t)dim * 4);
+    float* aw = (float*)malloc((size_t)n_win * N * dim * 4);
+    snprintf(p, sizeof p, "%s.attn", prefix);
+    int ok = vo_attention_rel_bias(m, p, win, (int)n_win, N, dim, heads, aw);
+    free(win);
+    if (!ok) { free(aw); return 0; }
+    for (int y = 0; y < res; ++y) /* window_reverse + residual */
+        for (int xx = 0; xx < res; ++xx) {
+            const float* a = aw + ((((int64_t)(y / ws) * nw + xx / ws) * ws + y % ws) * ws + xx % ws) * dim;
+            float* o = x + ((int64_t)y * res + xx) * dim;
+            for (int c = 0; c < dim; ++c) o[c] = a[c] + o[c];
+        }
+    free(aw);
+    float* lc = NULL;
+    int oh, ow;
+    snprintf(p, sizeof p, "%s.local_conv", prefix);
+    if (!tv_dwconv_bn(m, p, x, res, res, dim, 1, &oh, &ow, &lc)) return 0;
+    const int64_t T = (int64_t)res * res;
+    /* mlp (mobile-sam.cpp:112-120): norm, fc1, gelu, fc2 */
+    float* ln = (float*)malloc((size_t)T * dim * 4);
+    snprintf(p, sizeof p, "%s.mlp.norm", prefix);
+    if (!tv_layer_norm(m, p, lc, T, dim, 1e-5f, ln)) { free(lc); free(ln); return 0; }
+    float *h1 = NULL, *h2 = NULL;
+    int nh, no;
+    snprintf(p, sizeof p, "%s.mlp.fc1", prefix);
+    ok = tv_linear(m, p, ln, T, dim, &nh, &h1);
+    free(ln);
+    if (!ok) { free(lc); return 0; }
+    gelu_inplace(h1, T * nh);
+    snprintf(p, sizeof p, "%s.mlp.fc2", prefix);
+    ok = tv_linear(m, p, h1, T, nh, &no, &h2);
+    free(h1);
+    if (!ok) { free(lc); return 0; }
+    for (int64_t i = 0; i < T * dim; ++i) x[i] = lc[i] + h2[i];
+    free(lc); free(h2);
+    return 1;
+}
+
+/* mb_conv (mobile-sam.cpp:77-92) */
+static int tv_mb_conv(const vo_model* m, const char* prefix, float** px, int res, int C) {
+    char p[200];
+    float *x = *px, *a = NULL, *b = NULL, *c = NULL;
+    int oh, ow, ch, co;
+    snprintf(p, sizeof p, "%s.conv1", prefix);
+    if (!tv_conv_bn(m, p, x, res, res, C, 1, 0, &oh, &ow, &ch, &a)) return 0;
+    gelu_mbconv(a, (int64_t)res * res * ch);
+    snprintf(p, sizeof p, "%s.conv2", prefix);
+    if (!tv_dwconv_bn(m, p, a, res, res, ch, 1, &oh, &ow, &b)) { free(a); return 0; }
+    free(a);
+    gelu_mbconv(b, (int64_t)res * res * ch);
+    snprintf(p, sizeof p, "%s.conv3", prefix);
+    if (!tv_conv_bn(m, p, b, res, res, ch, 1, 0, &oh, &ow, &co, &c)) { free(b); return 0; }
+    free(b);
+    if (co != C) { free(c); VO_FAIL("%s: conv3 has %d outputs, expected %d", prefix, co, C); }
+    for (int64_t i = 0; i < (int64_t)res * res * C; ++i) c[i] = c[i] + x[i];
+    gelu_mbconv(c, (int64_t)res * res * C);
+    free(x);
+    *px = c;
+    return 1;
+}
+
+/* patch_merging (mobile-sam.cpp:94-110): conv1 1x1 + gelu, depthwise 3x3 (stride 1 if out dim in {320,448,576} else 2) +
+ * gelu, conv3 1x1; returns tokens [ores*ores][cout] */
+static int tv_patch_merging(const vo_model* m, const char* prefix, float** px, int res, int C, int* ores, int* cout) {
+    char p[200];
+    float *a = NULL, *b = NULL, *c = NULL;
+    int oh, ow, co, co3;
+    snprintf(p, sizeof p, "%s.conv1", prefix);
+    if (!tv_conv_bn(m, p, *px, res, res, C, 1, 0, &oh, &ow, &co, &a)) return 0;
+    gelu_inplace(a, (int64_t)res * res * co);
+    const int stride = (co == 320 || co == 448 || co == 576) ? 1 : 2;
+    snprintf(p, sizeof p, "%s.conv2", prefix);
+    if (!tv_dwconv_bn(m, p, a, res, res, co, stride, &oh, &ow, &b)) { free(a); return 0; }
+    free(a);
+    gelu_inplace(b, (int64_t)oh * ow * co);
+    snprintf(p, sizeof p, "%s.conv3", prefix);
+    int oh3, ow3;
+    if (!tv_conv_bn(m, p, b, oh, ow, co, 1, 0, &oh3, &ow3, &co3, &c)) { free(b); return 0; }
+    free(b);
+    free(*px);
+    *px = c; *ores = oh3; *cout = co3;
+    return 1;
+}
+
+/* tiny_vit (mobile-sam.cpp:188-215) */
+int vo_tinyvit_encode(const vo_model* m, const char* prefix, const vo_tinyvit_params* P, const float* image, float* out, vo_capture* caps,
+                      int ncap) {
+    char p[200], cname[64];
+    int oh, ow, co;
+    float *x = NULL, *t = NULL;
+    snprintf(p, sizeof p, "%s.patch_embed.seq.0", prefix); /* patch_embed (mobile-sam.cpp:70-75) */
+    if (!tv_conv_bn(m, p, image, P->img_size, P->img_size, 3, 2, 1, &oh, &ow, &co, &t)) return 0;
+    gelu_inplace(t, (int64_t)oh * ow * co);
+    snprintf(p, sizeof p, "%s.patch_embed.seq.2", prefix);
+    int oh2, ow2, c0;
+    if (!tv_conv_bn(m, p, t, oh, ow, co, 2, 1, &oh2, &ow2, &c0, &x)) { free(t); return 0; }
+    free(t);
+    capture(caps, ncap, "patch_embed", x, (int64_t)oh2 * ow2 * c0);
+    int res = oh2, C = c0;
+    if (res != P->layers[0].resolution || C != P->layers[0].embed_dim) { free(x); VO_FAIL("tinyvit: patch embed gives %dx%dx%d, layer 0 expects %dx%d", res, res, C, P->layers[0].resolution, P->layers[0].embed_dim); }
+    for (int i = 0; i < P->layers[0].depth; ++i) { /* conv_layer (mobile-sam.cpp:162-170) */
+        snprintf(p, sizeof p, "%s.layers.0.blocks.%d", prefix, i);
+        if (!tv_mb_conv(m, p, &x, res, C)) { free(x); return 0; }
+    }
+    snprintf(p, sizeof p, "%s.layers.0.downsample", prefix);
+    if (!tv_patch_merging(m, p, &x, res, C, &res, &C)) { free(x); return 0; }
+    capture(caps, ncap, "layer_0", x, (int64_t)res * res * C);
+    for (int l = 1; l < 4; ++l) { /* basic_layer (mobile-sam.cpp:172-186) */
+        const vo_tinyvit_layer* L = &P->layers[l];
+        if (res != L->resolution || C != L->embed_dim) { free(x); VO_FAIL("tinyvit: layer %d gets %dx%dx%d, expects %dx%d", l, res, res, C, L->resolution, L->embed_dim); }
+        for (int i = 0; i < L->depth; ++i) {
+            snprintf(p, sizeof p, "%s.layers.%d.blocks.%d", prefix, l, i);
+            if (!vo_tinyvit_block(m, p, x, res, C, L->num_heads, L->window_size)) { free(x); return 0; }
+        }
+        if (L->downsample) {
+            snprintf(p, sizeof p, "%s.layers.%d.downsample", prefix, l);
+            if (!tv_patch_merging(m, p, &x, res, C, &res, &C)) { free(x); return 0; }
+        }
+        snprintf(cname, sizeof cname, "layer_%d", l);
+        capture(caps, ncap, cname, x, (int64_t)res * res * C);
+    }
+    /* neck: conv 1x1 (no bias), LayerNorm2d, conv 3x3 (no bias), LayerNorm2d; layer_norm over channels, eps 1e-6? see below */
+    float *n0 = NULL, *n1 = NULL;
+    int c1, c2;
+    snprintf(p, sizeof p, "%s.neck.0", prefix);
+    if (!conv_m(m, p, x, 1, res, res, C, 1, 0, &oh, &ow, &c1, &n0)) { free(x); return 0; }
+    free(x);
+    snprintf(p, sizeof p, "%s.neck.1", prefix);
+    if (!tv_layer_norm(m, p, n0, (int64_t)res * res, c1, 1e-5f, n0)) { free(n0); return 0; }
+    snprintf(p, sizeof p, "%s.neck.2", prefix);
+    if (!conv_m(m, p, n0, 1, res, res, c1, 1, 1, &oh, &ow, &c2, &n1)) { free(n0); return 0; }
+    free(n0);
+    snprintf(p, sizeof p, "%s.neck.3", prefix);
+    if (!tv_layer_norm(m, p, n1, (int64_t)res * res, c2, 1e-5f, n1)) { free(n1); return 0; }
+    memcpy(out, n1, (size_t)res * res * c2 * 4);
+    capture(caps, ncap, "result", n1, (int64_t)res * res * c2);
+    free(n1);
+    return 1;
+}

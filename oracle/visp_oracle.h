@@ -158,6 +158,24 @@ void vo_tile_merge(const float* tile, float* dst, int tile_x, int tile_y, const 
 int vo_esrgan_compute(const vo_model*, const vo_esrgan_params*, const uint8_t* img, int w, int h, int format,
                       uint8_t* out_rgba);
 
+/* ---- TinyViT image encoder of MobileSAM (reference src/visp/arch/mobile-sam.cpp:20-215) ----
+ * GGUF names as scripts/convert.py:204-247 writes them ("enc." prefix, BatchNorm fused into "<conv>.c.weight/.c.bias",
+ * "attn.attention_biases_indexed" [heads][N][N]). Layer table as mobile-sam.h:16-37 (fixed in the reference; a
+ * parameter here so that small instances can be pinned against the reference's torch modules). */
+typedef struct { int resolution, embed_dim, depth, num_heads, window_size, downsample; } vo_tinyvit_layer;
+typedef struct { int img_size; vo_tinyvit_layer layers[4]; } vo_tinyvit_params;
+/* tiny_vit (mobile-sam.cpp:188-215): image = normalised rgb_f32 [img][img][3]; out = [res3][res3][256] (NHWC) */
+int vo_tinyvit_encode(const vo_model*, const char* prefix /* "enc" */, const vo_tinyvit_params*, const float* image, float* out,
+                      vo_capture* captures, int n_captures);
+/* test knob: GELU form inside MBConv / everywhere else (default: ggml's f16-table tanh form for both) */
+void vo_tinyvit_set_gelu_modes(int mbconv_mode, int other_mode);
+/* tiny_vit_block (mobile-sam.cpp:133-160) on tokens x [res*res][dim], in place */
+int vo_tinyvit_block(const vo_model*, const char* prefix, float* x, int res, int dim, int heads, int window);
+/* attention_rel_bias on windows x [n_win][N][dim] -> y same shape (mobile-sam.cpp:122-131, nn.cpp:182-244) */
+int vo_attention_rel_bias(const vo_model*, const char* prefix, const float* x, int n_win, int N, int dim, int heads, float* y);
+/* conv_2d_depthwise + bias on NHWC (nn.cpp:102-115); weight [C][1][kw][kh] after transfer */
+void vo_conv2d_depthwise_nhwc(const float* x, int H, int W, int C, const float* w, const float* bias, int k, int stride, int pad, float* y);
+
 /* dino building blocks, exposed for module-level parity tests */
 int vo_dino_layer(const vo_model*, const char* prefix, int n_heads, int gelu_mode, float* x /*[N][C] in/out*/,
                   int64_t N, int64_t C);

@@ -266,3 +266,127 @@ def write_esrgan_gguf(path: str | Path, cfg: EsrganConfig = ESRGAN_X4, seed: int
         w.add_tensor(name, t)
     w.write()
     return Path(path)
+
+
+# ---- TinyViT image encoder of MobileSAM (reference tests/test_mobile_sam.py:18-765, scripts/convert.py:204-262) -------
+
+@dataclass
+class TinyVitConfig:
+    img_size: int = 1024
+    embed_dims: tuple = (64, 128, 160, 320)
+    depths: tuple = (2, 2, 6, 2)
+    num_heads: tuple = (2, 4, 5, 10)
+    window_sizes: tuple = (7, 7, 14, 7)
+    name: str = "5m"
+
+    def layers(self):
+        """(resolution, embed_dim, depth, num_heads, window_size, downsample) per layer, mobile-sam.h:31-36"""
+        r0 = self.img_size // 4
+        res = [r0, r0 // 2, r0 // 4, r0 // 4]
+        return [(res[i], self.embed_dims[i], self.depths[i], self.num_heads[i], self.window_sizes[i], int(i < 3)) for i in range(4)]
+
+
+TINYVIT_5M = TinyVitConfig()
+
+
+def attention_bias_idxs(ws: int) -> np.ndarray:
+    """build_attention_bias_indices (scripts/convert.py:250-262)"""
+    pts = [(a, b) for a in range(ws) for b in range(ws)]
+    offs: dict = {}
+    idx = []
+    for p1 in pts:
+        for p2 in pts:
+            o = (abs(p1[0] - p2[0]), abs(p1[1] - p2[1]))
+            if o not in offs:
+                offs[o] = len(offs)
+            idx.append(offs[o])
+    return np.array(idx, np.int64).reshape(len(pts), len(pts))
+
+
+def tinyvit_state_dict(cfg: TinyVitConfig = TINYVIT_5M, seed: int = 0) -> dict[str, np.ndarray]:
+    """float32 tensors under the names of the reference's torch TinyViT (BatchNorm NOT fused, as in a checkpoint)."""
+    rng = np.random.default_rng(seed)
+    sd: dict[str, np.ndarray] = {}
+
+    def conv_bn(name, cout, cin, k, groups=1, gain=1.0):
+        fan = (cin // groups) * k * k
+        sd[f"{name}.c.weight"] = (rng.standard_normal((cout, cin // groups, k, k)) * gain / np.sqrt(fan)).astype(np.float32)
+        sd[f"{name}.bn.weight"] = (1 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
+        sd[f"{name}.bn.bias"] = (0.05 * rng.standard_normal(cout)).astype(np.float32)
+        sd[f"{name}.bn.running_mean"] = (0.05 * rng.standard_normal(cout)).astype(np.float32)
+        sd[f"{name}.bn.running_var"] = (1 + 0.2 * rng.random(cout)).astype(np.float32)
+
+    def linear(name, n, k, gain=1.0):
+        sd[f"{name}.weight"] = (rng.standard_normal((n, k)) * gain / np.sqrt(k)).astype(np.float32)
+        sd[f"{name}.bias"] = (0.02 * rng.standard_normal(n)).astype(np.float32)
+
+    def norm(name, c):
+        sd[f"{name}.weight"] = (1 + 0.05 * rng.standard_normal(c)).astype(np.float32)
+        sd[f"{name}.bias"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+
+    def merging(name, dim, out):
+        conv_bn(f"{name}.conv1", out, dim, 1)
+        conv_bn(f"{name}.conv2", out, out, 3, groups=out)
+        conv_bn(f"{name}.conv3", out, out, 1)
+
+    e = cfg.embed_dims
+    conv_bn("patch_embed.seq.0", e[0] // 2, 3, 3, gain=1.5)
+    conv_bn("patch_embed.seq.2", e[0], e[0] // 2, 3, gain=1.5)
+    for i in range(cfg.depths[0]):
+        p = f"layers.0.blocks.{i}"
+        conv_bn(f"{p}.conv1", 4 * e[0], e[0], 1)
+        conv_bn(f"{p}.conv2", 4 * e[0], 4 * e[0], 3, groups=4 * e[0])
+        conv_bn(f"{p}.conv3", e[0], 4 * e[0], 1, gain=0.5)
+    merging("layers.0.downsample", e[0], e[1])
+    for l in range(1, 4):
+        dim, heads, ws = e[l], cfg.num_heads[l], cfg.window_sizes[l]
+        for i in range(cfg.depths[l]):
+            p = f"layers.{l}.blocks.{i}"
+            sd[f"{p}.attn.attention_biases"] = (0.5 * rng.standard_normal((heads, ws * ws))).astype(np.float32)
+            norm(f"{p}.attn.norm", dim)
+            linear(f"{p}.attn.qkv", 3 * dim, dim)
+            linear(f"{p}.attn.proj", dim, dim, gain=0.4)
+            norm(f"{p}.mlp.norm", dim)
+            linear(f"{p}.mlp.fc1", 4 * dim, dim)
+            linear(f"{p}.mlp.fc2", dim, 4 * dim, gain=0.4)
+            conv_bn(f"{p}.local_conv", dim, dim, 3, groups=dim, gain=0.9)
+        if l < 3:
+            merging(f"layers.{l}.downsample", dim, e[l + 1])
+    sd["neck.0.weight"] = (rng.standard_normal((256, e[3], 1, 1)) / np.sqrt(e[3])).astype(np.float32)
+    norm("neck.1", 256)
+    sd["neck.2.weight"] = (rng.standard_normal((256, 256, 3, 3)) / np.sqrt(256 * 9)).astype(np.float32)
+    norm("neck.3", 256)
+    return sd
+
+
+def tinyvit_gguf_tensors(sd: dict[str, np.ndarray], prefix: str = "enc."):
+    """convert_sam's per-tensor rules for the image encoder (scripts/convert.py:204-247, 157-188), default whcn layout:
+    BatchNorm fused into '<conv>.c.weight' / '.c.bias' (eps 1e-5); fused kernels stay OIHW and are listed in
+    conv2d_weights -- except `local_conv`, always written NHWC (depthwise: H W 1 C) and not listed; attention_biases
+    gathered to [heads, N, N] as 'attention_biases_indexed'; neck convs listed; floats -> f16."""
+    out: dict[str, np.ndarray] = {}
+    conv2d: list[int] = []
+    for key, t in sd.items():
+        name = prefix + key
+        if key.endswith("attention_biases"):
+            ws = int(round(np.sqrt(t.shape[1])))
+            out[name + "_indexed"] = np.ascontiguousarray(t[:, attention_bias_idxs(ws)]).astype(np.float16)
+            continue
+        if key.endswith(".c.weight"):
+            base = key[: -len("c.weight")]
+            g = sd[base + "bn.weight"] / np.sqrt(sd[base + "bn.running_var"] + np.float32(1e-5))
+            w = (t * g[:, None, None, None]).astype(np.float32)
+            b = ((0 - sd[base + "bn.running_mean"]) * g + sd[base + "bn.bias"]).astype(np.float32)
+            if "local_conv" in key:
+                w = np.ascontiguousarray(w.transpose(2, 3, 1, 0))  # conv_2d_to_nhwc, depthwise: H W 1 C
+            else:
+                conv2d.append(len(out))
+            out[name] = w.astype(np.float16)
+            out[name.replace("weight", "bias")] = b.astype(np.float16)
+            continue
+        if ".bn." in key:
+            continue
+        if key in ("neck.0.weight", "neck.2.weight"):
+            conv2d.append(len(out))
+        out[name] = t.astype(np.float16)
+    return out, conv2d
