@@ -157,6 +157,23 @@ VX_API int vx_esrgan_tiles_in(const uint8_t* img, int B, int w, int h, int forma
  * tiles: f32 [B, n_y, n_x, tile_h, tile_w, 3] (t = the SCALED layout); out_f32 [B,h,w,3] and/or out_rgba [B,h,w,4]. */
 VX_API int vx_esrgan_tiles_out(const float* tiles, int B, const vx_tile_layout* t, float* out_f32, uint8_t* out_rgba, void* stream);
 
+/* ---- TinyViT (MobileSAM image encoder) helpers, kernels_tinyvit.hip -------------------------------------------------
+ * u8 rgb -> f16 [pixels][8]: (v/255 - mean)/std (sam_process_input, mobile-sam.cpp:533-547) as value + f16 residue */
+VX_API int vx_tv_preprocess(const uint8_t* rgb, void* out, int64_t n_pixels, void* stream);
+/* depthwise 3x3 pad 1 (+ bias, optional GELU) on NHWC f16: conv_2d_depthwise, nn.cpp:102-115; w f16 [9][C], bias f32 [C] */
+VX_API int vx_dwconv3x3_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int stride, int gelu, void* stream);
+/* LayerNorm of f16 rows (nn.cpp:14-19). ws > 0: output rows in window order of a res x res map (window_partition,
+ * mobile-sam.cpp:25-46; padded positions = norm of zero = bias). out_f32: f32 output. C <= 512. */
+VX_API int vx_layernorm_f16(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int res, int ws,
+                            int out_f32, void* stream);
+/* window attention with relative position bias, head_dim 32 (mobile-sam.cpp:122-131): qkv f16 [n_windows*N][heads*96]
+ * (per head q|k|v), bias f32 [heads][N][N], out f16 [n_windows*N][heads*32]; N <= 256 */
+VX_API int vx_window_attention_f16(const void* qkv, const float* bias, void* out, int n_windows, int N, int heads, void* stream);
+/* window_reverse + residual: y[b,py,px,:] = x[b,py,px,:] + a[window row of (py,px),:] (mobile-sam.cpp:48-64, 146-149) */
+VX_API int vx_window_reverse_add_f16(const void* a, const void* x, void* y, int B, int res, int ws, int C, void* stream);
+/* y = gelu(a + b), b nullable (mb_conv tail, mobile-sam.cpp:88-90) */
+VX_API int vx_add_gelu_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
+
 /* ---- fused multi-head attention, head_dim 64 (nn.cpp:210-244, dino.cpp:59-74) ------------
  * q,k,v: f16 [B,H,T,64] (q pre-scaled by 1/sqrt(64)); out: f16 [B*T, H*64].
  * softmax in f32, S never leaves registers; V is transposed on the fly by ds_read_b64_tr_b16. */

@@ -1,0 +1,285 @@
+// Non-GEMM kernels of the TinyViT image encoder (MobileSAM; reference src/visp/arch/mobile-sam.cpp:20-215): depthwise
+// 3x3 convolution, LayerNorm with the window partition folded into its row order, window attention with relative
+// position bias, window reverse + residual, and two elementwise helpers. The 1x1 convolutions, linears and the strided
+// 3x3 convolutions run on the GEMM family (kernels_gemm.hip). First version of this row: written for parity and
+// coalesced memory access; the attention core still runs on the VALU (one lane per query).
+#include "vx_common.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_tanh_f(float x) { // ggml_gelu (tanh form), the reference's activation everywhere
+    const float u = 0.7978845608028654f * x * (1.0f + 0.044715f * x * x);
+    const float e = __expf(2.0f * u);
+    return 0.5f * x * (1.0f + (e - 1.0f) / (e + 1.0f)); // tanh(u) without overflow issues for |u| < 40
+}
+
+// ---- u8 rgb -> f16 [pixels][8]: (v/255 - mean) / std as value (channels 0..2) + f16 rounding residue (3..5), 6..7 zero
+// (sam_process_input, mobile-sam.cpp:533-547; the first conv's weights are duplicated on channels 3..5)
+__global__ void tv_preprocess_kernel(const uint8_t* __restrict__ rgb, f16* __restrict__ out, long n_pix) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = ((float)rgb[i * 3 + c] / 255.0f + (0.0f - mean[c])) * (1.0f / stdv[c]); // image_u8_to_f32(img, -mean, 1/std)
+        const f16 hi = (f16)v;
+        o[c] = hi;
+        o[3 + c] = (f16)(v - (float)hi);
+    }
+    reinterpret_cast<f16x8*>(out)[i] = o;
+}
+
+// ---- depthwise 3x3, pad 1, stride 1 or 2, NHWC f16, weights [9][C] f16 (tap-major), bias f32 [C]; optional GELU
+// (conv_2d_depthwise + add_bias_2d, nn.cpp:102-115). One thread = one output pixel x 8 channels.
+__global__ void tv_dwconv3x3_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const float* __restrict__ bias,
+                                    f16* __restrict__ y, int B, int H, int W, int C, int stride, int gelu) {
+    const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+    const int c8n = C >> 3;
+    const long n = (long)B * OH * OW * c8n;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % c8n);
+    long q = i / c8n;
+    const int ox = (int)(q % OW);
+    q /= OW;
+    const int oy = (int)(q % OH), b = (int)(q / OH);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * stride - 1 + ky;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * stride - 1 + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const f16x8 xv = *reinterpret_cast<const f16x8*>(x + (((long)b * H + iy) * W + ix) * C + c8 * 8);
+            const f16x8 wv = *reinterpret_cast<const f16x8*>(w + (long)(ky * 3 + kx) * C + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)xv[j], (float)wv[j], acc[j]);
+        }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = acc[j] + bias[c8 * 8 + j];
+        if (gelu) v = gelu_tanh_f(v);
+        o[j] = (f16)v;
+    }
+    *reinterpret_cast<f16x8*>(y + i * 8) = o;
+}
+
+// ---- LayerNorm over channels of f16 rows (layer_norm, nn.cpp:14-19), one wave per OUTPUT row, C <= 512.
+// ws > 0: the output rows are in window order (window_partition, mobile-sam.cpp:25-46): row = ((b*nw + wy)*nw + wx)*ws*ws
+// + iy*ws + ix reads pixel (wy*ws+iy, wx*ws+ix); pixels beyond res are the zero padding, whose norm is the bias vector.
+// out_f32: write f32 instead of f16 (the encoder's final LayerNorm2d).
+__global__ __launch_bounds__(256) void tv_layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                           void* __restrict__ y, long rows_out, int C, float eps, int res, int ws, int nw,
+                                                           int out_f32) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_out) return;
+    long src = row;
+    bool padded = false;
+    if (ws > 0) {
+        const int N = ws * ws;
+        const int in = (int)(row % N);
+        long wq = row / N;
+        const int wx = (int)(wq % nw);
+        wq /= nw;
+        const int wy = (int)(wq % nw), bb = (int)(wq / nw);
+        const int py = wy * ws + in / ws, px = wx * ws + in % ws;
+        padded = py >= res || px >= res;
+        src = ((long)bb * res + py) * res + px;
+    }
+    float v[8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (!padded && c < C) ? (float)x[src * C + c] : 0.0f;
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < C ? v[i] - mean : 0.0f;
+        v[i] = d;
+        sq += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= C) continue;
+        const float o = v[i] * rstd * w[c] + b[c];
+        if (out_f32) reinterpret_cast<float*>(y)[row * C + c] = o;
+        else reinterpret_cast<f16*>(y)[row * C + c] = (f16)o;
+    }
+}
+
+// ---- window attention with relative position bias (attention_rel_bias, mobile-sam.cpp:122-131; nn.cpp:182-244):
+// qkv f16 [rows][3*dim] in window order, head h = columns h*3*32 + {0..31 q, 32..63 k, 64..95 v}; bias f32 [heads][N][N];
+// out f16 [rows][dim], head h at columns h*32. One block per (window, head), one lane per query, K and V of the window's
+// head staged in LDS as f32; softmax(q k^T * scale + bias) v in f32 with an online maximum.
+constexpr int TV_HD = 32;
+__global__ void tv_window_attention_kernel(const f16* __restrict__ qkv, const float* __restrict__ bias, f16* __restrict__ out, int N, int heads,
+                                           float scale) {
+    extern __shared__ float tv_smem[];
+    float* sk = tv_smem;               // [N][32]
+    float* sv = tv_smem + N * TV_HD;   // [N][32]
+    const int win = blockIdx.x / heads, h = blockIdx.x - win * heads;
+    const int dim3x = heads * 3 * TV_HD;
+    const f16* base = qkv + (long)win * N * dim3x + h * 3 * TV_HD;
+    for (int i = threadIdx.x; i < N * (TV_HD / 8); i += blockDim.x) { // 8 channels per thread and step
+        const int j = i / (TV_HD / 8), c8 = i % (TV_HD / 8);
+        const f16x8 kv = *reinterpret_cast<const f16x8*>(base + (long)j * dim3x + TV_HD + c8 * 8);
+        const f16x8 vv = *reinterpret_cast<const f16x8*>(base + (long)j * dim3x + 2 * TV_HD + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sk[j * TV_HD + c8 * 8 + e] = (float)kv[e];
+            sv[j * TV_HD + c8 * 8 + e] = (float)vv[e];
+        }
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i >= N) return;
+    float q[TV_HD], acc[TV_HD];
+#pragma unroll
+    for (int c8 = 0; c8 < TV_HD / 8; ++c8) {
+        const f16x8 qv = *reinterpret_cast<const f16x8*>(base + (long)i * dim3x + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[c8 * 8 + e] = (float)qv[e] * scale;
+    }
+#pragma unroll
+    for (int c = 0; c < TV_HD; ++c) acc[c] = 0.0f;
+    const float* brow = bias + ((long)h * N + i) * N;
+    float m = -INFINITY, l = 0.0f;
+    for (int j = 0; j < N; ++j) {
+        float s = brow[j];
+#pragma unroll
+        for (int c = 0; c < TV_HD; ++c) s = fmaf(q[c], sk[j * TV_HD + c], s);
+        const float m_new = fmaxf(m, s);
+        const float alpha = __expf(m - m_new), p = __expf(s - m_new);
+        l = l * alpha + p;
+#pragma unroll
+        for (int c = 0; c < TV_HD; ++c) acc[c] = fmaf(p, sv[j * TV_HD + c], acc[c] * alpha);
+        m = m_new;
+    }
+    const float inv = 1.0f / l;
+    f16* o = out + ((long)win * N + i) * (heads * TV_HD) + h * TV_HD;
+#pragma unroll
+    for (int c8 = 0; c8 < TV_HD / 8; ++c8) {
+        f16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (f16)(acc[c8 * 8 + e] * inv);
+        *reinterpret_cast<f16x8*>(o + c8 * 8) = ov;
+    }
+}
+
+// ---- window_reverse + residual (mobile-sam.cpp:48-64, 146-149): y[b, py, px, :] = x[b, py, px, :] + a[window row of (py, px), :]
+__global__ void tv_window_reverse_add_kernel(const f16* __restrict__ a, const f16* __restrict__ x, f16* __restrict__ y, int B, int res, int ws,
+                                             int nw, int C) {
+    const int c8n = C >> 3;
+    const long n = (long)B * res * res * c8n;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % c8n);
+    long q = i / c8n;
+    const int px = (int)(q % res);
+    q /= res;
+    const int py = (int)(q % res), b = (int)(q / res);
+    const long row = (((long)b * nw + py / ws) * nw + px / ws) * ws * ws + (py % ws) * ws + px % ws;
+    const f16x8 av = *reinterpret_cast<const f16x8*>(a + row * C + c8 * 8);
+    const f16x8 xv = *reinterpret_cast<const f16x8*>(x + i * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)((float)av[j] + (float)xv[j]);
+    *reinterpret_cast<f16x8*>(y + i * 8) = o;
+}
+
+// ---- y = gelu(a + b) on f16 (tail of mb_conv, mobile-sam.cpp:88-90); b may be NULL (plain GELU)
+__global__ void tv_add_gelu_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ y, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const f16x8 av = reinterpret_cast<const f16x8*>(a)[i];
+    f16x8 o;
+    if (b) {
+        const f16x8 bv = reinterpret_cast<const f16x8*>(b)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)gelu_tanh_f((float)av[j] + (float)bv[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)gelu_tanh_f((float)av[j]);
+    }
+    reinterpret_cast<f16x8*>(y)[i] = o;
+}
+
+unsigned blocks_for(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+} // namespace
+
+extern "C" {
+
+int vx_tv_preprocess(const uint8_t* rgb, void* out, int64_t n_pixels, void* stream) {
+    VX_REQUIRE(rgb && out && n_pixels > 0, "vx_tv_preprocess: bad operands");
+    hipLaunchKernelGGL(tv_preprocess_kernel, dim3(blocks_for(n_pixels)), dim3(256), 0, as_stream(stream), rgb, reinterpret_cast<f16*>(out), (long)n_pixels);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_dwconv3x3_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int stride, int gelu, void* stream) {
+    VX_REQUIRE(x && w && bias && y && B > 0 && H > 0 && W > 0, "vx_dwconv3x3_f16: bad operands");
+    VX_REQUIRE(C % 8 == 0 && (stride == 1 || stride == 2), "vx_dwconv3x3_f16: C %% 8 == 0 and stride 1 or 2 only (C = %d, stride = %d)", C, stride);
+    const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+    const long n = (long)B * OH * OW * (C / 8);
+    hipLaunchKernelGGL(tv_dwconv3x3_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(x),
+                       reinterpret_cast<const f16*>(w), bias, reinterpret_cast<f16*>(y), B, H, W, C, stride, gelu);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_layernorm_f16(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int res, int ws, int out_f32,
+                     void* stream) {
+    VX_REQUIRE(x && w && b && y && rows_out > 0 && C > 0 && C <= 512, "vx_layernorm_f16: bad operands (C = %d, at most 512)", C);
+    const int nw = ws > 0 ? (res + ws - 1) / ws : 0;
+    VX_REQUIRE(ws == 0 || rows_out % ((int64_t)nw * nw * ws * ws) == 0, "vx_layernorm_f16: rows do not form whole images of %d x %d windows", nw, nw);
+    hipLaunchKernelGGL(tv_layernorm_kernel, dim3(blocks_for(rows_out, 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(x), w, b, y,
+                       (long)rows_out, C, eps, res, ws, nw, out_f32);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_window_attention_f16(const void* qkv, const float* bias, void* out, int n_windows, int N, int heads, void* stream) {
+    VX_REQUIRE(qkv && bias && out && n_windows > 0 && heads > 0, "vx_window_attention_f16: bad operands");
+    VX_REQUIRE(N > 0 && N <= 256, "vx_window_attention_f16: %d tokens per window (at most 256)", N);
+    const int threads = (N + 63) / 64 * 64;
+    const size_t smem = (size_t)2 * N * TV_HD * sizeof(float);
+    hipLaunchKernelGGL(tv_window_attention_kernel, dim3((unsigned)n_windows * heads), dim3(threads), smem, as_stream(stream),
+                       reinterpret_cast<const f16*>(qkv), bias, reinterpret_cast<f16*>(out), N, heads, 1.0f / sqrtf((float)TV_HD));
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_window_reverse_add_f16(const void* a, const void* x, void* y, int B, int res, int ws, int C, void* stream) {
+    VX_REQUIRE(a && x && y && B > 0 && res > 0 && ws > 0 && C % 8 == 0, "vx_window_reverse_add_f16: bad operands");
+    const long n = (long)B * res * res * (C / 8);
+    hipLaunchKernelGGL(tv_window_reverse_add_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(a),
+                       reinterpret_cast<const f16*>(x), reinterpret_cast<f16*>(y), B, res, ws, (res + ws - 1) / ws, C);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_add_gelu_f16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+    VX_REQUIRE(a && y && n > 0 && n % 8 == 0, "vx_add_gelu_f16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(tv_add_gelu_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(a),
+                       reinterpret_cast<const f16*>(b), reinterpret_cast<f16*>(y), (long)(n / 8));
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,55 @@
+// TinyViT image encoder of MobileSAM on the MI355X backend (BASELINE.json configs[4]): model
+// load (mobile-sam GGUF -> packed f16 weights), static schedule, batched executor. Mirrors sam_load_model / sam_encode
+// (reference src/visp/vision.cpp:26-52; graph src/visp/arch/mobile-sam.cpp:20-215, sam_process_input :533-547). The prompt
+// encoder / mask decoder (sam_compute) are not built yet: this row ends at the image embedding [256, 64, 64].
+#pragma once
+#include <vector>
+
+#include "depthany.h"
+
+namespace visp {
+
+struct tiny_vit_layer { int resolution, embed_dim, depth, num_heads, window_size; bool downsample; };
+struct tiny_vit_params { // mobile-sam.h:16-37
+    int img_size = 1024;
+    tiny_vit_layer layers[4] = {{256, 64, 2, 2, 7, true}, {128, 128, 2, 4, 7, true}, {64, 160, 6, 5, 14, true}, {64, 320, 2, 10, 7, false}};
+};
+
+struct packed_dw { size_t w = 0, b = 0; int C = 0; };   // depthwise 3x3: f16 [9][C] + f32 bias [C]
+struct tv_mbconv_weights { packed_gemm conv1, conv3; packed_dw conv2; };
+struct tv_merge_weights { packed_gemm conv1, conv3; packed_dw conv2; int stride = 2; };
+struct tv_block_weights {
+    packed_vec attn_ln_w, attn_ln_b, bias; // bias: attention_biases_indexed f32 [heads][N][N]
+    packed_gemm qkv, proj, fc1, fc2;
+    packed_dw local_conv;
+    packed_vec mlp_ln_w, mlp_ln_b;
+};
+struct tinyvit_weights {
+    packed_gemm pe0, pe2; // patch_embed.seq.0 (3 -> 32, input channels 3..5 repeat 0..2), seq.2
+    std::vector<tv_mbconv_weights> mbconv;
+    tv_merge_weights merge[3];
+    std::vector<tv_block_weights> blocks[4];
+    packed_gemm neck0, neck2;
+    packed_vec neck1_w, neck1_b, neck3_w, neck3_b;
+};
+
+struct sam_model : model_base { // vision.h sam_model counterpart (encoder part)
+    sam_model() : model_base(family_sam) {}
+    backend_device const* backend = nullptr;
+    tiny_vit_params params;
+    tinyvit_weights weights;
+    device_buffer weight_arena;
+    bool weights_uploaded = false;
+    device_buffer ws;
+    bool timing = false;
+    std::vector<timing_entry> last_timing;
+    ~sam_model();
+};
+
+sam_model* sam_load_model(char const* filepath, backend_device const& dev, int flags = load_default);
+void sam_weights_ready(sam_model&);
+// B images rgb_u8 [B, 1024, 1024, 3] already at the model extent, on the device -> image embeddings f32 [B, 64, 64, 256] (NHWC)
+void sam_encode_batch_device(sam_model&, void const* rgb_dev, int batch, void* out_dev, void* stream);
+void sam_encode_batch_host(sam_model&, uint8_t const* rgb, int batch, float* out);
+
+} // namespace visp
