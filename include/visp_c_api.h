@@ -140,6 +140,25 @@ VISP_API int32_t visp_esrgan_generate_host(visp_model* m, float const* rgb, int3
 VISP_API int32_t visp_esrgan_enable_timing(visp_model* m, int32_t enable);
 VISP_API int32_t visp_esrgan_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
 
+/* ---- MobileSAM image encoder extension (family 0; reference vision.h:186-222, vision.cpp:26-52, mobile-sam.cpp:20-215) ----
+ * visp_model_load reads the `enc.*` tensors of a mobile-sam GGUF. sam_compute (prompt encoder + mask decoder) is not
+ * built yet: visp_model_compute fails for this family. */
+/* sam_encode: any extent / u8 colour format; the embedding is kept on the device with the model */
+VISP_API int32_t visp_sam_encode(visp_model* m, visp_image_view const* image);
+/* embedding of the last visp_sam_encode: f32 [64, 64, 256] (rows, columns, channels), shape returned via shape[3] */
+VISP_API int32_t visp_sam_read_embedding(visp_model* m, float* host_out, int64_t capacity, int64_t shape[3]);
+/* rgb: u8 [B, 1024, 1024, 3] already at the model extent -> out f32 [B, 64, 64, 256]; device pointers;
+ * stream = hipStream_t or NULL (NULL: the device's stream, synchronised before returning) */
+VISP_API int32_t visp_sam_encode_batch_device(visp_model* m, void const* rgb, int32_t batch, void* out, void* stream);
+VISP_API int32_t visp_sam_encode_batch_host(visp_model* m, uint8_t const* rgb, int32_t batch, float* out);
+VISP_API int32_t visp_sam_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes);
+VISP_API int32_t visp_sam_weights_ready(visp_model* m);
+/* test hook as for depth_anything: "patch_embed", "layer_0" .. "layer_3" = the stage outputs of the last batch, f16 -> f32 */
+VISP_API int32_t visp_sam_enable_captures(visp_model* m, int32_t enable);
+VISP_API int32_t visp_sam_read_capture(visp_model* m, char const* name, float* host_out, int64_t capacity, int64_t* n_written, int64_t shape[4]);
+VISP_API int32_t visp_sam_enable_timing(visp_model* m, int32_t enable);
+VISP_API int32_t visp_sam_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
+
 #ifdef __cplusplus
 }
 #endif

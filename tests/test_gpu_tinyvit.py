@@ -114,3 +114,121 @@ def test_window_reverse_add_and_add_gelu_and_preprocess():
     want = (img.astype(np.float32) / np.float32(255.0) - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)
     np.testing.assert_allclose(got[..., :3] + got[..., 3:6], want, atol=2e-6)
     assert (got[..., 6:] == 0).all()
+
+
+def test_gelu_is_finite_for_large_arguments():
+    """tanh-GELU written as x * sigmoid(2u): |x| > 10 must give x / -0, never inf / inf."""
+    from tests import gpu_util as G
+    from visioncpp_amd import _lib as L
+    x = np.array([-60000, -300, -40, -11, -1, 0, 1, 11, 40, 300, 60000] + [0] * 5, np.float16)
+    out = G.empty(x.size * 2)
+    L.vx_check(G.api().vx_add_gelu_f16(G.dev(x).ptr, None, out.ptr, x.size, None))
+    G.sync()
+    got = out.to_numpy(np.float16, (x.size,)).astype(np.float32)
+    np.testing.assert_allclose(got, O.gelu(x.astype(np.float32), O.GELU_TANH_F32), atol=2e-3, rtol=1e-3)
+
+
+# ---- the whole encoder through the C ABI ---------------------------------------------------------------------------
+
+GOLD = __import__("pathlib").Path(__file__).parent / "golden"
+MEAN, STD = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+
+
+@pytest.fixture(scope="module")
+def sam(tmp_path_factory):
+    from visioncpp_amd import synth, vision
+    g = np.load(GOLD / "tinyvit_5m.npz")
+    cfg = synth.TINYVIT_5M
+    sd = synth.tinyvit_state_dict(cfg, int(g["weights_seed"]))
+    path = synth.write_tinyvit_gguf(tmp_path_factory.mktemp("sam") / "tinyvit.gguf", cfg, sd=sd)
+    dev = vision.Device.init(vision.Backend.gpu)
+    model = vision.Model.load(path, dev)
+    assert model.arch is vision.Arch.sam
+    tensors, conv2d = synth.tinyvit_gguf_tensors(sd)
+    imgs = np.concatenate([synth.images(1, 1024, 1024, seed=int(g["image_seed"])), synth.images(1, 1024, 1024, seed=77)])
+    model.enable_captures(True)
+    got = model.sam_encode_batch(imgs)
+    caps = {k: model.read_capture(k) for k in ["patch_embed", "layer_0", "layer_1", "layer_2", "layer_3"]}
+    model.enable_captures(False)
+    yield dict(g=g, cfg=cfg, model=model, om=O.Model(tensors, conv2d, "whcn"), imgs=imgs, got=got, caps=caps)
+    del model, dev
+
+
+def _oracle_encode(s, i):
+    cfg = s["cfg"]
+    layers = cfg.layers()
+    sizes = {"patch_embed": 256 * 256 * 64, **{f"layer_{k}": layers[min(k + 1, 3)][0] ** 2 * layers[min(k + 1, 3)][1] for k in range(4)}}
+    x = (s["imgs"][i].astype(np.float32) / np.float32(255.0) - MEAN) / STD
+    return O.tinyvit_encode(s["om"], O.tinyvit_params(cfg.img_size, layers), x, captures=sizes)
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_encoder_matches_oracle_at_every_stage(sam, i):
+    """f16 activations / f32 accumulation against the f32 oracle (ggml forms: tanh GELU everywhere, neck eps 1e-5) for both
+    images of a batch: the error budget is the f16 storage of ~60 chained maps, checked per stage so that an indexing slip
+    cannot hide behind the final LayerNorm."""
+    y, c = _oracle_encode(sam, i)
+    for k in ["patch_embed", "layer_0", "layer_1", "layer_2", "layer_3"]:
+        got = sam["caps"][k][i].reshape(-1)
+        want = c[k]
+        assert got.shape == want.shape, k
+        err = np.abs(got - want)
+        scale = np.abs(want).mean()
+        assert err.mean() < 6e-3 * max(1.0, scale) and err.max() < 0.08 * max(1.0, np.abs(want).max()), (k, err.mean(), err.max(), scale)
+    err = np.abs(sam["got"][i] - y)
+    assert err.mean() < 6e-3 and err.max() < 0.1, (err.mean(), err.max())
+
+
+def test_encoder_matches_reference_torch_fixture(sam):
+    """Against samples of the reference's torch TinyViT output (tests/golden/make_golden_tinyvit.py), with the bounds the
+    oracle's ggml-form run is held to in test_oracle_tinyvit.py (tanh-vs-erf GELU drift over 12 blocks) plus f16 storage."""
+    g = sam["g"]
+    got = sam["caps"]["patch_embed"][0].reshape(256, 256, 64)[::16, ::16]
+    np.testing.assert_allclose(got, g["patch_embed_sample"], rtol=2e-3, atol=0.02)
+    for k in range(4):
+        s = g[f"layer_{k}_sample"]
+        err = np.abs(sam["caps"][f"layer_{k}"][0].reshape(-1, s.shape[1])[::37] - s)
+        assert err.mean() < 8e-3 and err.max() < 0.12, (k, err.mean(), err.max())
+    err = np.abs(sam["got"][0][::4, ::4] - g["result_sample"])
+    assert err.mean() < 0.015 and err.max() < 0.2, (err.mean(), err.max())
+
+
+def test_batch_is_independent_of_position_and_size(sam):
+    """image 1 encoded alone and as part of a batch of 3 (different workspace offsets) gives identical bits."""
+    m = sam["model"]
+    alone = m.sam_encode_batch(sam["imgs"][1:2])
+    three = m.sam_encode_batch(np.concatenate([sam["imgs"], sam["imgs"][1:2]]))
+    assert np.array_equal(alone[0], sam["got"][1]) and np.array_equal(three[2], alone[0]) and np.array_equal(three[0], sam["got"][0])
+
+
+def test_sam_encode_pads_by_edge_replication(sam):
+    """sam_process_input (mobile-sam.cpp:533-547): longest side already 1024 -> no resize, the square is filled with
+    clamped source coordinates. Also exercises the bgra channel map."""
+    from visioncpp_amd import vision
+    m = sam["model"]
+    img = sam["imgs"][0][:768, :, :]
+    square = np.pad(img, ((0, 256), (0, 0), (0, 0)), mode="edge")
+    want = m.sam_encode_batch(square[None])[0]
+    assert np.array_equal(m.sam_encode(img), want)
+    bgra = np.concatenate([img[..., ::-1], np.full(img.shape[:2] + (1,), 255, np.uint8)], axis=-1)
+    assert np.array_equal(m.sam_encode(bgra, vision.ImageFormat.bgra_u8), want)
+    tall = np.ascontiguousarray(sam["imgs"][1][:, :600, :])
+    want = m.sam_encode_batch(np.pad(tall, ((0, 0), (0, 424), (0, 0)), mode="edge")[None])[0]
+    assert np.array_equal(m.sam_encode(tall), want)
+
+
+def test_sam_errors(sam, tmp_path):
+    from visioncpp_amd import _lib as L, synth, vision
+    m = sam["model"]
+    with pytest.raises(L.Error, match="sam_compute"):
+        m.compute(sam["imgs"][0][:64, :64])
+    fresh = vision.Model.load(synth.write_tinyvit_gguf(tmp_path / "t.gguf", sam["cfg"], seed=1), m._device)
+    with pytest.raises(L.Error, match="call sam_encode"):
+        out = np.empty((64, 64, 256), np.float32)
+        L.check(L.get_lib().visp_sam_read_embedding(fresh._handle, out.ctypes.data, out.size, (C.c_int64 * 3)()))
+    with pytest.raises(L.Error, match="format"):
+        fresh.sam_encode(np.zeros((32, 32), np.uint8), vision.ImageFormat.alpha_u8)
+    sd = synth.tinyvit_state_dict(sam["cfg"], 1)
+    del sd["layers.2.blocks.3.mlp.fc1.weight"]
+    with pytest.raises(L.Error, match="fc1"):
+        vision.Model.load(synth.write_tinyvit_gguf(tmp_path / "broken.gguf", sam["cfg"], sd=sd), m._device)

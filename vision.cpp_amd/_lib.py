@@ -88,6 +88,9 @@ C_API_SYMBOLS = [
     "visp_esrgan_get_info", "visp_esrgan_set_tile_group", "visp_esrgan_weights_arena", "visp_esrgan_weights_ready",
     "visp_esrgan_tile_layout", "visp_esrgan_compute_batch_device", "visp_esrgan_compute_batch_host",
     "visp_esrgan_generate_host", "visp_esrgan_enable_timing", "visp_esrgan_read_timing",
+    "visp_sam_encode", "visp_sam_read_embedding", "visp_sam_encode_batch_device", "visp_sam_encode_batch_host",
+    "visp_sam_weights_arena", "visp_sam_weights_ready", "visp_sam_enable_timing", "visp_sam_read_timing",
+    "visp_sam_enable_captures", "visp_sam_read_capture",
 ]
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
@@ -161,6 +164,16 @@ def init() -> ctypes.CDLL:
     lib.visp_esrgan_generate_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
     lib.visp_esrgan_enable_timing.argtypes = [c_void_p, c_int32]
     lib.visp_esrgan_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
+    lib.visp_sam_encode.argtypes = [c_void_p, POINTER(ImageView)]
+    lib.visp_sam_read_embedding.argtypes = [c_void_p, c_void_p, c_int64, POINTER(c_int64)]
+    lib.visp_sam_encode_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
+    lib.visp_sam_encode_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_void_p]
+    lib.visp_sam_weights_arena.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]
+    lib.visp_sam_weights_ready.argtypes = [c_void_p]
+    lib.visp_sam_enable_captures.argtypes = [c_void_p, c_int32]
+    lib.visp_sam_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
+    lib.visp_sam_enable_timing.argtypes = [c_void_p, c_int32]
+    lib.visp_sam_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
     for name in C_API_SYMBOLS[15:]:
         getattr(lib, name).restype = c_int32
 

@@ -6,11 +6,13 @@
 
 #include <cstring>
 #include <exception>
+#include <map>
 #include <memory>
 
 #include "../../include/visp_hip_kernels.h"
 #include "depthany.h"
 #include "esrgan.h"
+#include "tinyvit.h"
 #include "visp_util.h"
 
 using namespace visp;
@@ -55,6 +57,10 @@ esrgan_model& as_esrgan(visp_model* m) {
     if (family_of(m) != VISP_ESRGAN) throw except("model handle is not an esrgan model (family %d)", family_of(m));
     return *static_cast<esrgan_model*>(reinterpret_cast<model_base*>(m));
 }
+sam_model& as_sam(visp_model* m) {
+    if (family_of(m) != VISP_SAM) throw except("model handle is not a sam model (family %d)", family_of(m));
+    return *static_cast<sam_model*>(reinterpret_cast<model_base*>(m));
+}
 visp_model* handle_of(model_base* m) { return reinterpret_cast<visp_model*>(m); }
 
 int32_t detect_family(model_file const& file) { // reference vision.cpp:7-21
@@ -69,8 +75,27 @@ int32_t detect_family(model_file const& file) { // reference vision.cpp:7-21
 
 void require_built(int32_t family) {
     if (family < 0 || family >= VISP_FAMILY_COUNT) throw except("Unsupported model family");
-    if (family != VISP_DEPTH_ANYTHING && family != VISP_ESRGAN)
-        throw except("Model family %d is not built in this backend (MI355X backend implements depth_anything and esrgan)", family);
+    if (family != VISP_DEPTH_ANYTHING && family != VISP_ESRGAN && family != VISP_SAM)
+        throw except("Model family %d is not built in this backend (MI355X backend implements depth_anything, esrgan and the sam image encoder)", family);
+}
+
+void read_capture(backend_device const& dev, std::map<std::string, capture_entry> const& bufs, char const* name, float* host_out,
+                  int64_t capacity, int64_t* n_written, int64_t shape[4]) {
+    auto it = bufs.find(name);
+    if (it == bufs.end()) throw except("capture '%s' not available (enable captures before compute)", name);
+    capture_entry const& c = it->second;
+    int64_t n = c.shape[0] * c.shape[1] * c.shape[2] * c.shape[3];
+    *n_written = n;
+    if (shape) memcpy(shape, c.shape, sizeof(int64_t) * 4);
+    if (n > capacity) return; // caller learns the size and retries
+    if (!vx_set_device(dev.index)) throw except("%s", vx_last_error());
+    if (c.f16) {
+        std::unique_ptr<uint16_t[]> tmp(new uint16_t[(size_t)n]);
+        if (!vx_memcpy_d2h(tmp.get(), c.dev, (size_t)n * 2, dev.stream)) throw except("%s", vx_last_error());
+        for (int64_t i = 0; i < n; ++i) host_out[i] = f16_to_f32(tmp[(size_t)i]);
+    } else {
+        if (!vx_memcpy_d2h(host_out, c.dev, (size_t)n * 4, dev.stream)) throw except("%s", vx_last_error());
+    }
 }
 
 void return_image(image_data&& img, visp_image_view* out_image, visp_image_data** out_data) {
@@ -131,6 +156,7 @@ int32_t visp_model_load_ex(char const* filepath, visp_device const* dev, int32_t
         }
         require_built(family);
         if (family == VISP_ESRGAN) *out = handle_of(esrgan_load_model(filepath, *dev, flags));
+        else if (family == VISP_SAM) *out = handle_of(sam_load_model(filepath, *dev, flags));
         else *out = handle_of(depthany_load_model(filepath, *dev, flags));
     });
 }
@@ -146,6 +172,7 @@ void visp_model_destroy(visp_model* model, int32_t arch) {
     (void)arch;
     if (base->family == VISP_DEPTH_ANYTHING) delete static_cast<depthany_model*>(base);
     else if (base->family == VISP_ESRGAN) delete static_cast<esrgan_model*>(base);
+    else if (base->family == VISP_SAM) delete static_cast<sam_model*>(base);
 }
 
 int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* inputs, int32_t n_inputs, int32_t*, int32_t,
@@ -153,6 +180,9 @@ int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* i
     return handle_errors([&]() {
         require_built(family);
         if (family_of(model) != family) throw except("model handle belongs to family %d, not %d", family_of(model), family);
+        if (family == VISP_SAM) // model_funcs<sam>::compute = sam_encode + sam_compute (reference c-api.cpp:34-52)
+            throw except("sam: the prompt encoder / mask decoder (sam_compute) are not built in this backend; the image encoder is "
+                         "available through visp_sam_encode / visp_sam_encode_batch_*");
         if (n_inputs != 1) throw except("Expected %d input images, but got %d.", 1, n_inputs);
         image_view in;
         in.extent = {{inputs[0].width, inputs[0].height}};
@@ -246,21 +276,7 @@ int32_t visp_depthany_read_capture(visp_model* m, char const* name, float* host_
                                    int64_t shape[4]) {
     return handle_errors([&]() {
         depthany_model& dm = as_depthany(m);
-        auto it = dm.capture_bufs.find(name);
-        if (it == dm.capture_bufs.end()) throw except("capture '%s' not available (enable captures before compute)", name);
-        capture_entry const& c = it->second;
-        int64_t n = c.shape[0] * c.shape[1] * c.shape[2] * c.shape[3];
-        *n_written = n;
-        if (shape) memcpy(shape, c.shape, sizeof(int64_t) * 4);
-        if (n > capacity) return; // caller learns the size and retries
-        if (!vx_set_device(dm.backend->index)) throw except("%s", vx_last_error());
-        if (c.f16) {
-            std::unique_ptr<uint16_t[]> tmp(new uint16_t[(size_t)n]);
-            if (!vx_memcpy_d2h(tmp.get(), c.dev, (size_t)n * 2, dm.backend->stream)) throw except("%s", vx_last_error());
-            for (int64_t i = 0; i < n; ++i) host_out[i] = f16_to_f32(tmp[(size_t)i]);
-        } else {
-            if (!vx_memcpy_d2h(host_out, c.dev, (size_t)n * 4, dm.backend->stream)) throw except("%s", vx_last_error());
-        }
+        read_capture(*dm.backend, dm.capture_bufs, name, host_out, capacity, n_written, shape);
     });
 }
 
@@ -356,6 +372,84 @@ int32_t visp_esrgan_read_timing(visp_model* m, visp_timing* out, int32_t cap, in
         esrgan_model& em = as_esrgan(m);
         int32_t count = 0;
         for (timing_entry const& t : em.last_timing) {
+            if (count >= cap) break;
+            snprintf(out[count].name, sizeof out[count].name, "%s", t.name.c_str());
+            out[count].ms = t.ms;
+            out[count].launches = t.launches;
+            out[count].flops = t.flops;
+            out[count].bytes = t.bytes;
+            ++count;
+        }
+        *n = count;
+    });
+}
+
+// ---- MobileSAM image encoder (TinyViT) ----
+
+int32_t visp_sam_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes) {
+    return handle_errors([&]() {
+        sam_model& sm = as_sam(m);
+        *device_ptr = sm.weight_arena.ptr;
+        *n_bytes = sm.weight_arena.bytes;
+    });
+}
+
+int32_t visp_sam_weights_ready(visp_model* m) {
+    return handle_errors([&]() { sam_weights_ready(as_sam(m)); });
+}
+
+int32_t visp_sam_encode(visp_model* m, visp_image_view const* image) {
+    return handle_errors([&]() {
+        if (!image) throw except("sam: null image");
+        image_view in;
+        in.extent = {{image->width, image->height}};
+        in.stride = image->stride;
+        in.format = image_format(image->format);
+        in.data = image->data;
+        sam_encode(as_sam(m), in);
+    });
+}
+
+int32_t visp_sam_read_embedding(visp_model* m, float* host_out, int64_t capacity, int64_t shape[3]) {
+    return handle_errors([&]() {
+        sam_model& sm = as_sam(m);
+        if (!sm.embed.ptr || sm.image_extent[0] <= 0) throw except("Missing image embeds, call sam_encode() first");
+        const int R = sm.params.layers[3].resolution;
+        shape[0] = R; shape[1] = R; shape[2] = 256;
+        if (capacity < (int64_t)R * R * 256) throw except("sam: embedding buffer too small (%lld < %d)", (long long)capacity, R * R * 256);
+        if (!vx_memcpy_d2h(host_out, sm.embed.ptr, (size_t)R * R * 256 * 4, sm.backend->stream) || !vx_stream_sync(sm.backend->stream))
+            throw except("%s", vx_last_error());
+    });
+}
+
+int32_t visp_sam_encode_batch_device(visp_model* m, void const* rgb, int32_t batch, void* out, void* stream) {
+    return handle_errors([&]() { sam_encode_batch_device(as_sam(m), rgb, batch, out, stream); });
+}
+
+int32_t visp_sam_encode_batch_host(visp_model* m, uint8_t const* rgb, int32_t batch, float* out) {
+    return handle_errors([&]() { sam_encode_batch_host(as_sam(m), rgb, batch, out); });
+}
+
+int32_t visp_sam_enable_captures(visp_model* m, int32_t enable) {
+    return handle_errors([&]() { as_sam(m).captures = enable != 0; });
+}
+
+int32_t visp_sam_read_capture(visp_model* m, char const* name, float* host_out, int64_t capacity, int64_t* n_written, int64_t shape[4]) {
+    return handle_errors([&]() {
+        sam_model& sm = as_sam(m);
+        read_capture(*sm.backend, sm.capture_bufs, name, host_out, capacity, n_written, shape);
+    });
+}
+
+int32_t visp_sam_enable_timing(visp_model* m, int32_t enable) {
+    return handle_errors([&]() { as_sam(m).timing = enable != 0; });
+}
+
+int32_t visp_sam_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n) {
+    return handle_errors([&]() {
+        sam_model& sm = as_sam(m);
+        int32_t count = 0;
+        for (timing_entry const& t : sm.last_timing) {
             if (count >= cap) break;
             snprintf(out[count].name, sizeof out[count].name, "%s", t.name.c_str());
             out[count].ms = t.ms;

@@ -8,9 +8,9 @@
 namespace {
 
 __device__ __forceinline__ float gelu_tanh_f(float x) { // ggml_gelu (tanh form), the reference's activation everywhere
+    // 0.5 x (1 + tanh(u)) = x * sigmoid(2u) = x / (1 + exp(-2u)): exp -> inf gives -0, exp -> 0 gives x (no inf/inf)
     const float u = 0.7978845608028654f * x * (1.0f + 0.044715f * x * x);
-    const float e = __expf(2.0f * u);
-    return 0.5f * x * (1.0f + (e - 1.0f) / (e + 1.0f)); // tanh(u) without overflow issues for |u| < 40
+    return x / (1.0f + __expf(-2.0f * u));
 }
 
 // ---- u8 rgb -> f16 [pixels][8]: (v/255 - mean) / std as value (channels 0..2) + f16 rounding residue (3..5), 6..7 zero

@@ -1,0 +1,486 @@
+#include "tinyvit.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+
+#include "../../include/visp_hip_kernels.h"
+#include "visp_util.h"
+
+namespace visp {
+
+#define VX(call)                                        \
+    do {                                                \
+        if (!(call)) throw except("%s", vx_last_error()); \
+    } while (0)
+
+namespace {
+
+template <typename T>
+T round_up(T x, T m) { return (x + m - 1) / m * m; }
+
+struct arena_builder {
+    std::vector<uint8_t> data;
+    size_t alloc(size_t bytes) {
+        size_t off = round_up<size_t>(data.size(), 256);
+        data.resize(off + bytes, 0);
+        return off;
+    }
+};
+
+float tensor_at(gguf_tensor const& t, size_t i) {
+    if (t.type == GGML_F32) return reinterpret_cast<const float*>(t.data)[i];
+    return f16_to_f32(reinterpret_cast<const uint16_t*>(t.data)[i]);
+}
+
+// GGUF -> packed operands. Layout rules of the mobile-sam file (scripts/convert.py:204-247): BatchNorm fused into
+// "<conv>.c.weight/.c.bias"; fused kernels are torch OIHW and listed in conv2d_weights when the file is whcn (otherwise
+// already OHWI); local_conv kernels are always stored H W 1 C and never listed.
+struct packer {
+    model_file const& file;
+    arena_builder& ab;
+    bool with_data;
+    bool file_whcn;
+    std::vector<int32_t> conv2d;
+
+    bool listed(std::string const& name) const {
+        auto it = file.index.find(name);
+        return it != file.index.end() && std::binary_search(conv2d.begin(), conv2d.end(), it->second);
+    }
+    gguf_tensor const& get(std::string const& name) const {
+        gguf_tensor const& t = file.tensor(name);
+        if (t.type != GGML_F32 && t.type != GGML_F16) throw except("tensor %s: unsupported type %d", name.c_str(), t.type);
+        if (with_data && !t.data) throw except("tensor %s has no data", name.c_str());
+        return t;
+    }
+
+    packed_vec vec(std::string const& name) {
+        gguf_tensor const& t = get(name);
+        packed_vec v;
+        v.n = (int)t.n_elements();
+        v.off = ab.alloc((size_t)v.n * 4);
+        if (with_data) {
+            float* d = reinterpret_cast<float*>(ab.data.data() + v.off);
+            for (int i = 0; i < v.n; ++i) d[i] = tensor_at(t, i);
+        }
+        return v;
+    }
+
+    // rows [n][k] -> f16 [N pad 32][K pad 64] + f32 bias [N]
+    packed_gemm matrix(int n, int k, std::function<float(int, int)> at, gguf_tensor const* bias) {
+        packed_gemm g;
+        g.n_real = n; g.k_real = k;
+        g.N = round_up(n, 32); g.K = round_up(k, 64);
+        g.w = ab.alloc((size_t)g.N * g.K * 2);
+        if (with_data) {
+            uint16_t* w = reinterpret_cast<uint16_t*>(ab.data.data() + g.w);
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c < k; ++c) w[(size_t)r * g.K + c] = f32_to_f16(at(r, c));
+        }
+        if (bias) {
+            if ((int)bias->n_elements() != n) throw except("tensor %s: %d elements, expected %d", bias->name.c_str(), (int)bias->n_elements(), n);
+            g.b = ab.alloc((size_t)g.N * 4);
+            if (with_data) {
+                float* b = reinterpret_cast<float*>(ab.data.data() + g.b);
+                for (int r = 0; r < n; ++r) b[r] = tensor_at(*bias, r);
+            }
+        }
+        return g;
+    }
+
+    packed_gemm linear(std::string const& prefix) { // weight ne [K, N] == torch [N][K]
+        gguf_tensor const& w = get(prefix + ".weight");
+        const int K = (int)w.ne[0], N = (int)w.ne[1];
+        return matrix(N, K, [&](int n, int k) { return tensor_at(w, (size_t)n * K + k); }, file.find(prefix + ".bias"));
+    }
+
+    // dense conv as GEMM rows k = (ky, kx, c); dup_in: the 3 input channels are read as value + residue (channels 3..5
+    // repeat 0..2, the rest of the 8-channel pixel is zero)
+    packed_gemm conv(std::string const& prefix, int* ksize = nullptr, int* cin_out = nullptr, bool dup_in = false) {
+        std::string name = prefix + ".weight";
+        gguf_tensor const& w = get(name);
+        const bool oihw = file_whcn && listed(name);
+        int kw, kh, cin, cout = (int)w.ne[3];
+        if (oihw) { kw = (int)w.ne[0]; kh = (int)w.ne[1]; cin = (int)w.ne[2]; }
+        else { cin = (int)w.ne[0]; kw = (int)w.ne[1]; kh = (int)w.ne[2]; }
+        if (kw != kh) throw except("tensor %s: non-square kernel", name.c_str());
+        if (ksize) *ksize = kw;
+        if (cin_out) *cin_out = cin;
+        const int cpix = dup_in ? 8 : cin;
+        if (dup_in && cin != 3) throw except("tensor %s: expected 3 input channels", name.c_str());
+        auto at = [&](int n, int k) -> float {
+            const int tap = k / cpix, c = k % cpix;
+            int cs = c;
+            if (dup_in) {
+                if (c >= 6) return 0.0f;
+                cs = c % 3;
+            }
+            const int ky = tap / kw, kx = tap % kw;
+            const size_t src = oihw ? (((size_t)n * cin + cs) * kh + ky) * kw + kx : (((size_t)n * kh + ky) * kw + kx) * cin + cs;
+            return tensor_at(w, src);
+        };
+        return matrix(cout, kh * kw * cpix, at, file.find(prefix + ".bias"));
+    }
+
+    // depthwise 3x3 -> f16 [9][C] (tap-major) + f32 bias; OIHW-listed: ne = [kw, kh, 1, C]; otherwise [C, 1, kw, kh]
+    packed_dw depthwise(std::string const& prefix) {
+        std::string name = prefix + ".weight";
+        gguf_tensor const& w = get(name);
+        const bool oihw = file_whcn && listed(name);
+        packed_dw d;
+        int kw, kh;
+        if (oihw) { kw = (int)w.ne[0]; kh = (int)w.ne[1]; d.C = (int)w.ne[3]; if (w.ne[2] != 1) throw except("tensor %s is not depthwise", name.c_str()); }
+        else { d.C = (int)w.ne[0]; kw = (int)w.ne[2]; kh = (int)w.ne[3]; if (w.ne[1] != 1) throw except("tensor %s is not depthwise", name.c_str()); }
+        if (kw != 3 || kh != 3) throw except("tensor %s: expected a 3x3 depthwise kernel", name.c_str());
+        d.w = ab.alloc((size_t)9 * d.C * 2);
+        d.b = ab.alloc((size_t)d.C * 4);
+        if (with_data) {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(ab.data.data() + d.w);
+            for (int c = 0; c < d.C; ++c)
+                for (int tap = 0; tap < 9; ++tap) {
+                    const size_t src = oihw ? (size_t)c * 9 + tap : (size_t)tap * d.C + c;
+                    dst[(size_t)tap * d.C + c] = f32_to_f16(tensor_at(w, src));
+                }
+            gguf_tensor const& b = get(prefix + ".bias");
+            float* bd = reinterpret_cast<float*>(ab.data.data() + d.b);
+            for (int c = 0; c < d.C; ++c) bd[c] = tensor_at(b, c);
+        }
+        return d;
+    }
+};
+
+} // namespace
+
+sam_model* sam_load_model(char const* filepath, backend_device const& dev, int flags) {
+    const bool with_data = !(flags & load_no_upload);
+    model_file file = model_load(filepath, /*header_only=*/!with_data);
+    if (file.arch() != "mobile-sam")
+        throw except("Model %s has architecture '%.*s', expected 'mobile-sam'", filepath, (int)file.arch().size(), file.arch().data());
+    auto model = std::make_unique<sam_model>();
+    model->backend = &dev;
+    tiny_vit_params const& P = model->params;
+    arena_builder ab;
+    packer pk{file, ab, with_data, file.tensor_layout() != layout_cwhn, file.conv2d_weights()};
+    tinyvit_weights& Wt = model->weights;
+    const std::string e = "enc.";
+    int k, cin;
+    Wt.pe0 = pk.conv(e + "patch_embed.seq.0.c", &k, &cin, /*dup_in=*/true);
+    if (k != 3) throw except("mobile-sam: patch embedding kernel is %dx%d, expected 3x3", k, k);
+    Wt.pe2 = pk.conv(e + "patch_embed.seq.2.c", &k, &cin);
+    if (Wt.pe2.n_real != P.layers[0].embed_dim) throw except("mobile-sam: patch embedding width %d, expected %d", Wt.pe2.n_real, P.layers[0].embed_dim);
+    auto merge = [&](std::string const& p) {
+        tv_merge_weights m;
+        m.conv1 = pk.conv(p + ".conv1.c");
+        m.conv2 = pk.depthwise(p + ".conv2.c");
+        m.conv3 = pk.conv(p + ".conv3.c");
+        const int co = m.conv1.n_real;
+        m.stride = (co == 320 || co == 448 || co == 576) ? 1 : 2; // mobile-sam.cpp:98-100
+        return m;
+    };
+    for (int i = 0; i < P.layers[0].depth; ++i) {
+        std::string p = e + "layers.0.blocks." + std::to_string(i);
+        tv_mbconv_weights mb;
+        mb.conv1 = pk.conv(p + ".conv1.c");
+        mb.conv2 = pk.depthwise(p + ".conv2.c");
+        mb.conv3 = pk.conv(p + ".conv3.c");
+        Wt.mbconv.push_back(mb);
+    }
+    Wt.merge[0] = merge(e + "layers.0.downsample");
+    for (int l = 1; l < 4; ++l) {
+        tiny_vit_layer const& L = P.layers[l];
+        for (int i = 0; i < L.depth; ++i) {
+            std::string p = e + "layers." + std::to_string(l) + ".blocks." + std::to_string(i);
+            tv_block_weights b;
+            b.attn_ln_w = pk.vec(p + ".attn.norm.weight");
+            b.attn_ln_b = pk.vec(p + ".attn.norm.bias");
+            b.qkv = pk.linear(p + ".attn.qkv");
+            b.proj = pk.linear(p + ".attn.proj");
+            b.bias = pk.vec(p + ".attn.attention_biases_indexed");
+            const int N = L.window_size * L.window_size;
+            if (b.bias.n != L.num_heads * N * N) throw except("mobile-sam: %s.attn.attention_biases_indexed has %d elements, expected %d", p.c_str(), b.bias.n, L.num_heads * N * N);
+            if (b.qkv.n_real != 3 * L.embed_dim || b.qkv.k_real != L.embed_dim || L.embed_dim != 32 * L.num_heads)
+                throw except("mobile-sam: %s.attn.qkv is %d x %d (this backend implements head_dim 32)", p.c_str(), b.qkv.n_real, b.qkv.k_real);
+            b.local_conv = pk.depthwise(p + ".local_conv.c");
+            b.mlp_ln_w = pk.vec(p + ".mlp.norm.weight");
+            b.mlp_ln_b = pk.vec(p + ".mlp.norm.bias");
+            b.fc1 = pk.linear(p + ".mlp.fc1");
+            b.fc2 = pk.linear(p + ".mlp.fc2");
+            Wt.blocks[l].push_back(b);
+        }
+        if (L.downsample) Wt.merge[l] = merge(e + "layers." + std::to_string(l) + ".downsample");
+    }
+    Wt.neck0 = pk.conv(e + "neck.0");
+    Wt.neck1_w = pk.vec(e + "neck.1.weight");
+    Wt.neck1_b = pk.vec(e + "neck.1.bias");
+    Wt.neck2 = pk.conv(e + "neck.2");
+    Wt.neck3_w = pk.vec(e + "neck.3.weight");
+    Wt.neck3_b = pk.vec(e + "neck.3.bias");
+
+    VX(vx_set_device(dev.index));
+    model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256) + 4096;
+    VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
+    if (with_data) {
+        VX(vx_memcpy_h2d(model->weight_arena.ptr, ab.data.data(), ab.data.size(), dev.stream));
+        VX(vx_stream_sync(dev.stream));
+        model->weights_uploaded = true;
+    }
+    return model.release();
+}
+
+void sam_weights_ready(sam_model& m) { m.weights_uploaded = true; }
+
+sam_model::~sam_model() {
+    vx_free(ws.ptr);
+    vx_free(embed.ptr);
+    for (auto& c : capture_bufs) vx_free(c.second.dev);
+    vx_free(weight_arena.ptr);
+}
+
+namespace {
+
+struct tv_exec {
+    sam_model& m;
+    void* stream;
+    const uint8_t* wa;
+    std::vector<std::pair<std::string, void*>> marks;
+    std::vector<timing_entry> acc;
+
+    const float* fptr(packed_vec const& v) const { return reinterpret_cast<const float*>(wa + v.off); }
+    void mark(const char* name, double flops, double bytes) {
+        if (!m.timing) return;
+        void* ev = nullptr;
+        VX(vx_event_create(&ev));
+        VX(vx_event_record(ev, stream));
+        marks.push_back({name, ev});
+        acc.push_back({name, 0, 1, flops, bytes});
+    }
+    void finish_timing() {
+        if (!m.timing) return;
+        void* ev = nullptr;
+        VX(vx_event_create(&ev));
+        VX(vx_event_record(ev, stream));
+        marks.push_back({"end", ev});
+        std::map<std::string, timing_entry> by;
+        std::vector<std::string> order;
+        for (size_t i = 0; i + 1 < marks.size(); ++i) {
+            float ms = 0;
+            VX(vx_event_elapsed_ms(marks[i].second, marks[i + 1].second, &ms));
+            auto it = by.find(marks[i].first);
+            if (it == by.end()) { order.push_back(marks[i].first); it = by.emplace(marks[i].first, timing_entry{marks[i].first, 0, 0, 0, 0}).first; }
+            it->second.ms += ms;
+            it->second.launches += acc[i].launches;
+            it->second.flops += acc[i].flops;
+            it->second.bytes += acc[i].bytes;
+        }
+        m.last_timing.clear();
+        for (auto& n : order) m.last_timing.push_back(by[n]);
+        for (auto& mk : marks) vx_event_destroy(mk.second);
+        marks.clear();
+    }
+
+    // C[M, N] = A[M, lda] * W^T (+bias) with the epilogues of the GEMM family
+    void gemm(packed_gemm const& g, const void* A, long M, int lda, void* out, int epi, const void* res1, const char* group) {
+        vx_gemm_args a;
+        memset(&a, 0, sizeof a);
+        a.A = A; a.lda = lda;
+        a.W = wa + g.w; a.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b);
+        a.M = (int)M; a.N = g.N; a.K = g.K; a.n_valid = g.n_real;
+        a.epi = epi; a.out = out; a.ldo = g.n_real; a.res1 = res1;
+        mark(group, 2.0 * M * g.n_real * g.k_real, (double)M * (g.k_real + g.n_real) * 2);
+        VX(vx_gemm_f16(&a, stream));
+    }
+    // k x k conv as implicit GEMM on NHWC f16
+    void conv(packed_gemm const& g, const void* x, int B, int H, int W, int Cpix, int k, int stride, int pad, void* out, int epi, const char* group) {
+        const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+        vx_gemm_args a;
+        memset(&a, 0, sizeof a);
+        a.A = x;
+        a.conv_kh = a.conv_kw = k; a.conv_stride = stride; a.conv_pad = pad;
+        a.conv_H = H; a.conv_W = W; a.conv_Cin = Cpix; a.conv_OH = OH; a.conv_OW = OW;
+        a.W = wa + g.w; a.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b);
+        a.M = B * OH * OW; a.N = g.N; a.K = g.K; a.n_valid = g.n_real;
+        a.epi = epi; a.out = out; a.ldo = g.n_real;
+        mark(group, 2.0 * a.M * g.n_real * g.k_real, (double)B * H * W * Cpix * 2 + (double)a.M * g.n_real * 2);
+        VX(vx_gemm_f16(&a, stream));
+    }
+    void capture(const char* name, const void* src, int B, int res, int C) {
+        if (!m.captures) return;
+        capture_entry& c = m.capture_bufs[name];
+        const size_t bytes = (size_t)B * res * res * C * 2;
+        vx_free(c.dev);
+        c.dev = nullptr;
+        VX(vx_malloc(&c.dev, bytes));
+        c.shape[0] = B; c.shape[1] = res; c.shape[2] = res; c.shape[3] = C;
+        c.f16 = true;
+        VX(vx_memcpy_d2d(c.dev, src, bytes, stream));
+    }
+    void dw(packed_dw const& d, const void* x, void* y, int B, int H, int W, int stride, bool gelu, const char* group) {
+        mark(group, 2.0 * B * (H / stride) * (W / stride) * 9 * d.C, (double)B * H * W * d.C * 2 * (1.0 + 1.0 / (stride * stride)));
+        VX(vx_dwconv3x3_f16(x, wa + d.w, reinterpret_cast<const float*>(wa + d.b), y, B, H, W, d.C, stride, gelu, stream));
+    }
+};
+
+} // namespace
+
+void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out_dev, void* stream) {
+    if (!m.weights_uploaded) throw except("sam: weights have not been uploaded (load_no_upload without weights_ready)");
+    if (B < 1 || !rgb_dev || !out_dev) throw except("sam: empty batch or null pointer");
+    VX(vx_set_device(m.backend->index));
+    void* s = stream ? stream : m.backend->stream;
+    tiny_vit_params const& P = m.params;
+    tinyvit_weights const& Wt = m.weights;
+    const int S = P.img_size;
+    // scratch: three rotating activation buffers (largest map: 256 x 256 x 256 f16 of an MBConv) + input / patch-embed buffers
+    const size_t big = (size_t)B * 256 * 256 * 256 * 2 + 4096;
+    const size_t in_bytes = (size_t)B * S * S * 8 * 2 + 4096, pe_bytes = (size_t)B * (S / 2) * (S / 2) * 32 * 2 + 4096;
+    const size_t need = 4 * big + in_bytes + pe_bytes;
+    if (m.ws.bytes < need) {
+        VX(vx_stream_sync(m.backend->stream));
+        VX(vx_stream_sync(s));
+        vx_free(m.ws.ptr);
+        m.ws = {};
+        VX(vx_malloc(&m.ws.ptr, need));
+        m.ws.bytes = need;
+        VX(vx_memset(m.ws.ptr, 0, need, s)); // GEMM rows are read up to K padded to 64: stale bytes must be finite (pads of W are 0)
+    }
+    uint8_t* base = static_cast<uint8_t*>(m.ws.ptr);
+    void* buf[4] = {base, base + big, base + 2 * big, base + 3 * big};
+    void* in8 = base + 4 * big;
+    void* pe = base + 4 * big + in_bytes;
+
+    tv_exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
+    ex.mark("preprocess", 0, (double)B * S * S * 19);
+    VX(vx_tv_preprocess(static_cast<const uint8_t*>(rgb_dev), in8, (int64_t)B * S * S, s));
+    // patch_embed (mobile-sam.cpp:70-75)
+    ex.conv(Wt.pe0, in8, B, S, S, 8, 3, 2, 1, pe, VX_EPI_F16_GELU, "patch_embed");
+    void *x = buf[0], *t1 = buf[1], *t2 = buf[2], *t3 = buf[3];
+    ex.conv(Wt.pe2, pe, B, S / 2, S / 2, Wt.pe0.n_real, 3, 2, 1, x, VX_EPI_F16, "patch_embed");
+    int res = P.layers[0].resolution, C = P.layers[0].embed_dim;
+    ex.capture("patch_embed", x, B, res, C);
+    // conv_layer (mobile-sam.cpp:162-170): mb_conv x depth
+    for (tv_mbconv_weights const& mb : Wt.mbconv) {
+        const long M = (long)B * res * res;
+        ex.gemm(mb.conv1, x, M, C, t1, VX_EPI_F16_GELU, nullptr, "mbconv_1x1");
+        ex.dw(mb.conv2, t1, t2, B, res, res, 1, true, "depthwise");
+        ex.gemm(mb.conv3, t2, M, mb.conv1.n_real, t1, VX_EPI_F16, nullptr, "mbconv_1x1");
+        ex.mark("elementwise", 0, (double)M * C * 6);
+        VX(vx_add_gelu_f16(t1, x, t3, M * C, s));
+        std::swap(x, t3);
+    }
+    auto patch_merging = [&](tv_merge_weights const& mg) { // mobile-sam.cpp:94-110
+        const long M = (long)B * res * res;
+        ex.gemm(mg.conv1, x, M, C, t1, VX_EPI_F16_GELU, nullptr, "merge_1x1");
+        const int co = mg.conv1.n_real;
+        ex.dw(mg.conv2, t1, t2, B, res, res, mg.stride, true, "depthwise");
+        res = (res + 2 - 3) / mg.stride + 1;
+        ex.gemm(mg.conv3, t2, (long)B * res * res, co, t1, VX_EPI_F16, nullptr, "merge_1x1");
+        std::swap(x, t1);
+        C = mg.conv3.n_real;
+    };
+    patch_merging(Wt.merge[0]);
+    ex.capture("layer_0", x, B, res, C);
+    for (int l = 1; l < 4; ++l) { // basic_layer (mobile-sam.cpp:172-186)
+        tiny_vit_layer const& L = P.layers[l];
+        if (res != L.resolution || C != L.embed_dim) throw except("sam: layer %d gets %dx%dx%d, expects %dx%d", l, res, res, C, L.resolution, L.embed_dim);
+        const int ws = L.window_size, nw = (res + ws - 1) / ws, N = ws * ws;
+        const long T = (long)B * res * res, rows = (long)B * nw * nw * N;
+        for (tv_block_weights const& b : Wt.blocks[l]) { // tiny_vit_block (mobile-sam.cpp:133-160)
+            ex.mark("layernorm", 0, (double)(T + rows) * C * 2);
+            VX(vx_layernorm_f16(x, ex.fptr(b.attn_ln_w), ex.fptr(b.attn_ln_b), t1, rows, C, 1e-5f, res, ws, 0, s));
+            ex.gemm(b.qkv, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_qkv");
+            ex.mark("window_attention", 4.0 * rows * N * C, (double)rows * C * 8);
+            VX(vx_window_attention_f16(t2, ex.fptr(b.bias), t1, (int)(rows / N), N, L.num_heads, s));
+            ex.gemm(b.proj, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_proj");
+            ex.mark("elementwise", 0, (double)T * C * 6);
+            VX(vx_window_reverse_add_f16(t2, x, t1, B, res, ws, C, s));
+            ex.dw(b.local_conv, t1, t3, B, res, res, 1, false, "depthwise");
+            ex.mark("layernorm", 0, (double)T * C * 4);
+            VX(vx_layernorm_f16(t3, ex.fptr(b.mlp_ln_w), ex.fptr(b.mlp_ln_b), t1, T, C, 1e-5f, 0, 0, 0, s));
+            ex.gemm(b.fc1, t1, T, C, t2, VX_EPI_F16_GELU, nullptr, "gemm_fc1");
+            ex.gemm(b.fc2, t2, T, b.fc1.n_real, x, VX_EPI_F16_ADD, t3, "gemm_fc2");
+        }
+        if (L.downsample) patch_merging(Wt.merge[l]);
+        ex.capture(("layer_" + std::to_string(l)).c_str(), x, B, res, C);
+    }
+    // neck (mobile-sam.cpp:197-205): conv 1x1, LayerNorm over channels, conv 3x3, LayerNorm -> f32 [B, res, res, 256]
+    const long T = (long)B * res * res;
+    ex.gemm(Wt.neck0, x, T, C, t1, VX_EPI_F16, nullptr, "neck");
+    const int NC = Wt.neck0.n_real;
+    ex.mark("layernorm", 0, (double)T * NC * 4);
+    VX(vx_layernorm_f16(t1, ex.fptr(Wt.neck1_w), ex.fptr(Wt.neck1_b), t2, T, NC, 1e-5f, 0, 0, 0, s));
+    ex.conv(Wt.neck2, t2, B, res, res, NC, 3, 1, 1, t1, VX_EPI_F16, "neck");
+    ex.mark("layernorm", 0, (double)T * NC * 6);
+    VX(vx_layernorm_f16(t1, ex.fptr(Wt.neck3_w), ex.fptr(Wt.neck3_b), out_dev, T, Wt.neck2.n_real, 1e-5f, 0, 0, 1, s));
+    ex.finish_timing();
+    if (!stream) VX(vx_stream_sync(s));
+}
+
+void sam_encode_batch_host(sam_model& m, uint8_t const* rgb, int B, float* out) {
+    if (B < 1 || !rgb || !out) throw except("sam: empty batch or null pointer");
+    VX(vx_set_device(m.backend->index));
+    const int S = m.params.img_size, R = m.params.layers[3].resolution;
+    const size_t in_bytes = (size_t)B * S * S * 3, out_bytes = (size_t)B * R * R * 256 * 4;
+    void *din = nullptr, *dout = nullptr;
+    VX(vx_malloc(&din, in_bytes));
+    VX(vx_malloc(&dout, out_bytes));
+    void* s = m.backend->stream;
+    try {
+        VX(vx_memcpy_h2d(din, rgb, in_bytes, s));
+        sam_encode_batch_device(m, din, B, dout, s);
+        VX(vx_memcpy_d2h(out, dout, out_bytes, s));
+        VX(vx_stream_sync(s));
+    } catch (...) {
+        vx_free(din);
+        vx_free(dout);
+        throw;
+    }
+    vx_free(din);
+    vx_free(dout);
+}
+
+void sam_encode(sam_model& m, image_view image) {
+    if (is_float(image.format) || n_channels(image.format) < 3)
+        throw except("sam: unsupported input image format [%d], expected an 8-bit colour image", int(image.format));
+    if (image.extent[0] < 1 || image.extent[1] < 1) throw except("sam: empty image");
+    const int S = m.params.img_size;
+    image_data rgb = image_to_rgb_u8(image);
+    image_view v = view_of(rgb);
+    image_data resized;
+    // sam_process_input (mobile-sam.cpp:533-547): resize_longest_side, then u8 -> f32 with source coordinates clamped
+    const float scale = float(S) / float(std::max(image.extent[0], image.extent[1]));
+    if (scale != 1) {
+        resized = image_scale(v, i32x2{{int(image.extent[0] * scale + 0.5f), int(image.extent[1] * scale + 0.5f)}});
+        v = view_of(resized);
+    }
+    std::vector<uint8_t> square((size_t)S * S * 3);
+    const uint8_t* src = static_cast<const uint8_t*>(v.data);
+    for (int y = 0; y < S; ++y) {
+        const uint8_t* row = src + (size_t)std::min(y, v.extent[1] - 1) * v.stride;
+        for (int x = 0; x < S; ++x) memcpy(&square[((size_t)y * S + x) * 3], row + (size_t)std::min(x, v.extent[0] - 1) * 3, 3);
+    }
+    VX(vx_set_device(m.backend->index));
+    const int R = m.params.layers[3].resolution;
+    const size_t out_bytes = (size_t)R * R * 256 * 4;
+    if (!m.embed.ptr) {
+        VX(vx_malloc(&m.embed.ptr, out_bytes));
+        m.embed.bytes = out_bytes;
+    }
+    void* din = nullptr;
+    VX(vx_malloc(&din, square.size()));
+    void* s = m.backend->stream;
+    try {
+        VX(vx_memcpy_h2d(din, square.data(), square.size(), s));
+        sam_encode_batch_device(m, din, 1, m.embed.ptr, s);
+        VX(vx_stream_sync(s));
+    } catch (...) {
+        vx_free(din);
+        throw;
+    }
+    vx_free(din);
+    m.image_extent = image.extent;
+}
+
+} // namespace visp

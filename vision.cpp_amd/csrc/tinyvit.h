@@ -41,8 +41,11 @@ struct sam_model : model_base { // vision.h sam_model counterpart (encoder part)
     device_buffer weight_arena;
     bool weights_uploaded = false;
     device_buffer ws;
-    bool timing = false;
+    device_buffer embed;          // image embedding of the last sam_encode: f32 [64, 64, 256] (NHWC)
+    i32x2 image_extent = {{0, 0}}; // extent of the image passed to sam_encode (vision.h sam_model::image_extent)
+    bool timing = false, captures = false;
     std::vector<timing_entry> last_timing;
+    std::map<std::string, capture_entry> capture_bufs;
     ~sam_model();
 };
 
@@ -51,5 +54,8 @@ void sam_weights_ready(sam_model&);
 // B images rgb_u8 [B, 1024, 1024, 3] already at the model extent, on the device -> image embeddings f32 [B, 64, 64, 256] (NHWC)
 void sam_encode_batch_device(sam_model&, void const* rgb_dev, int batch, void* out_dev, void* stream);
 void sam_encode_batch_host(sam_model&, uint8_t const* rgb, int batch, float* out);
+// reference API (vision.cpp:36-52): any extent, any u8 colour format; longest side scaled to 1024, edge-replicated to the
+// square (sam_process_input); the embedding stays on the device in model.embed
+void sam_encode(sam_model&, image_view image);
 
 } // namespace visp

@@ -390,3 +390,19 @@ def tinyvit_gguf_tensors(sd: dict[str, np.ndarray], prefix: str = "enc."):
             conv2d.append(len(out))
         out[name] = t.astype(np.float16)
     return out, conv2d
+
+
+def write_tinyvit_gguf(path: str | Path, cfg: TinyVitConfig = TINYVIT_5M, seed: int = 0, sd: dict[str, np.ndarray] | None = None) -> Path:
+    """A 'mobile-sam' GGUF holding the image encoder only (scripts/convert.py:204-247, 593-596 for the metadata)."""
+    sd = sd if sd is not None else tinyvit_state_dict(cfg, seed)
+    tensors, conv2d = tinyvit_gguf_tensors(sd)
+    w = GGUFWriter(path, "mobile-sam")
+    w.add_string("mobile-sam.tensor_data_layout", "whcn")
+    w.add_uint32("general.quantization_version", 2)
+    w.add_uint32("general.file_type", 1)
+    if conv2d:
+        w.add_array_i32("mobile-sam.conv2d_weights", conv2d)
+    for name, t in tensors.items():
+        w.add_tensor(name, t)
+    w.write()
+    return Path(path)

@@ -116,6 +116,10 @@ class Model:
             self._api.visp_image_destroy(out_data)
         return res
 
+    def _family_fn(self, name: str):
+        prefix = {Arch.esrgan: "visp_esrgan_", Arch.sam: "visp_sam_"}.get(self.arch, "visp_depthany_")
+        return getattr(self._api, prefix + name)
+
     # ---- batched extension
     @property
     def info(self) -> lib.DepthAnyInfo:
@@ -130,13 +134,11 @@ class Model:
 
     def weights_arena(self):
         p, n = c_void_p(), c_size_t()
-        f = self._api.visp_esrgan_weights_arena if self.arch is Arch.esrgan else self._api.visp_depthany_weights_arena
-        check(f(self._handle, byref(p), byref(n)))
+        check(self._family_fn("weights_arena")(self._handle, byref(p), byref(n)))
         return p.value, n.value
 
     def weights_ready(self):
-        f = self._api.visp_esrgan_weights_ready if self.arch is Arch.esrgan else self._api.visp_depthany_weights_ready
-        check(f(self._handle))
+        check(self._family_fn("weights_ready")(self._handle))
 
     def reserve(self, batch: int, w: int, h: int):
         check(self._api.visp_depthany_reserve(self._handle, batch, w, h))
@@ -160,26 +162,25 @@ class Model:
         check(self._api.visp_depthany_compute_batch_device(self._handle, rgb_dev, batch, w, h, out_dev, raw_dev, stream))
 
     def enable_captures(self, enable: bool = True):
-        check(self._api.visp_depthany_enable_captures(self._handle, int(enable)))
+        check(self._family_fn("enable_captures")(self._handle, int(enable)))
 
     def read_capture(self, name: str) -> np.ndarray:
         n, shape = c_int64(), (c_int64 * 4)()
-        check(self._api.visp_depthany_read_capture(self._handle, name.encode(), None, 0, byref(n), shape))
+        f = self._family_fn("read_capture")
+        check(f(self._handle, name.encode(), None, 0, byref(n), shape))
         out = np.empty(n.value, np.float32)
-        check(self._api.visp_depthany_read_capture(self._handle, name.encode(), out.ctypes.data, n.value, byref(n), shape))
+        check(f(self._handle, name.encode(), out.ctypes.data, n.value, byref(n), shape))
         dims = [int(d) for d in shape]
         while len(dims) > 1 and dims[-1] == 1:
             dims.pop()
         return out.reshape(dims)
 
     def enable_timing(self, enable: bool = True):
-        f = self._api.visp_esrgan_enable_timing if self.arch is Arch.esrgan else self._api.visp_depthany_enable_timing
-        check(f(self._handle, int(enable)))
+        check(self._family_fn("enable_timing")(self._handle, int(enable)))
 
     def read_timing(self):
         arr, n = (lib.Timing * 64)(), c_int32()
-        f = self._api.visp_esrgan_read_timing if self.arch is Arch.esrgan else self._api.visp_depthany_read_timing
-        check(f(self._handle, arr, 64, byref(n)))
+        check(self._family_fn("read_timing")(self._handle, arr, 64, byref(n)))
         return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches, flops=arr[i].flops, bytes=arr[i].bytes)
                 for i in range(n.value)]
 
@@ -217,6 +218,30 @@ class Model:
         out = np.empty((n, h * s, w * s, 3), np.float32)
         check(self._api.visp_esrgan_generate_host(self._handle, t.ctypes.data, n, w, h, out.ctypes.data))
         return out
+
+    # ---- MobileSAM image encoder (family 0)
+    def sam_encode(self, image: np.ndarray, format: ImageFormat = ImageFormat.rgb_u8) -> np.ndarray:
+        """sam_encode (reference vision.cpp:36-52): one u8 colour image of any extent -> embedding float32 [64, 64, 256]."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = img.shape[:2]
+        view = lib.ImageView(w, h, w * _CHANNELS[format.value], format.value, img.ctypes.data)
+        check(self._api.visp_sam_encode(self._handle, byref(view)))
+        shape = (c_int64 * 3)()
+        out = np.empty((64, 64, 256), np.float32)
+        check(self._api.visp_sam_read_embedding(self._handle, out.ctypes.data, out.size, shape))
+        return out.reshape([int(d) for d in shape])
+
+    def sam_encode_batch(self, images: np.ndarray) -> np.ndarray:
+        """images: uint8 [B, 1024, 1024, 3] on the host -> image embeddings float32 [B, 64, 64, 256]."""
+        imgs = np.ascontiguousarray(images, dtype=np.uint8)
+        b, h, w, c = imgs.shape
+        assert (h, w, c) == (1024, 1024, 3)
+        out = np.empty((b, 64, 64, 256), np.float32)
+        check(self._api.visp_sam_encode_batch_host(self._handle, imgs.ctypes.data, b, out.ctypes.data))
+        return out
+
+    def sam_encode_batch_device(self, rgb_dev: int, batch: int, out_dev: int, stream: int | None = None):
+        check(self._api.visp_sam_encode_batch_device(self._handle, rgb_dev, batch, out_dev, stream))
 
 
 def esrgan_tile_layout(w: int, h: int, scale: int = 1) -> dict:
