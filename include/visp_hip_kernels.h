@@ -166,9 +166,13 @@ VX_API int vx_dwconv3x3_f16(const void* x, const void* w, const float* bias, voi
  * mobile-sam.cpp:25-46; padded positions = norm of zero = bias). out_f32: f32 output. C <= 512. */
 VX_API int vx_layernorm_f16(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int res, int ws,
                             int out_f32, void* stream);
-/* window attention with relative position bias, head_dim 32 (mobile-sam.cpp:122-131): qkv f16 [n_windows*N][heads*96]
- * (per head q|k|v), bias f32 [heads][N][N], out f16 [n_windows*N][heads*32]; N <= 256 */
-VX_API int vx_window_attention_f16(const void* qkv, const float* bias, void* out, int n_windows, int N, int heads, void* stream);
+/* window attention with relative position bias, head_dim 32, on MFMA (mobile-sam.cpp:112-131; kernels_winattn.hip): qkv f16
+ * [n_windows*N][heads*96] (per head q|k|v), out f16 [n_windows*N][heads*32]; N <= 256. bias_packed: the f16 image that
+ * vx_window_attention_pack_bias (host code) makes of attention_biases_indexed f32 [heads][N][N] -- accumulator order,
+ * padded keys = -inf -- vx_window_attention_bias_bytes(N, heads) bytes, uploaded by the caller. */
+VX_API size_t vx_window_attention_bias_bytes(int N, int heads);
+VX_API int vx_window_attention_pack_bias(const float* bias_host, int N, int heads, void* packed_host);
+VX_API int vx_window_attention_f16(const void* qkv, const void* bias_packed, void* out, int n_windows, int N, int heads, void* stream);
 /* window_reverse + residual: y[b,py,px,:] = x[b,py,px,:] + a[window row of (py,px),:] (mobile-sam.cpp:48-64, 146-149) */
 VX_API int vx_window_reverse_add_f16(const void* a, const void* x, void* y, int B, int res, int ws, int C, void* stream);
 /* y = gelu(a + b), b nullable (mb_conv tail, mobile-sam.cpp:88-90) */

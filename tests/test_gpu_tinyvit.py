@@ -68,16 +68,18 @@ def test_layernorm_window_partition(res, ws, Cc):
     np.testing.assert_allclose(out32.to_numpy(np.float32, (B * res * res, Cc)), O.layer_norm(x.reshape(-1, Cc), w, b, 1e-5), atol=2e-5, rtol=2e-5)
 
 
-@pytest.mark.parametrize("N,heads,nwin", [(49, 4, 5), (196, 5, 3), (16, 2, 7)])
+@pytest.mark.parametrize("N,heads,nwin", [(49, 4, 5), (196, 5, 3), (16, 2, 7), (49, 10, 9), (100, 2, 3), (256, 1, 2), (33, 3, 2)])
 def test_window_attention(N, heads, nwin):
     from tests import gpu_util as G
     from visioncpp_amd import _lib as L
     rng = np.random.default_rng(N + heads)
     dim = heads * 32
     qkv = _h(rng.standard_normal((nwin, N, 3 * dim)))
-    bias = (rng.standard_normal((heads, N, N)) * 0.5).astype(np.float32)
+    bias = _h(rng.standard_normal((heads, N, N)) * 0.5)  # GGUF stores the indexed biases as f16
+    packed = np.zeros(G.api().vx_window_attention_bias_bytes(N, heads) // 2, np.uint16)
+    L.vx_check(G.api().vx_window_attention_pack_bias(bias.ctypes.data, N, heads, packed.ctypes.data))
     out = G.empty(nwin * N * dim * 2)
-    L.vx_check(G.api().vx_window_attention_f16(G.dev(qkv.astype(np.float16)).ptr, G.dev(bias).ptr, out.ptr, nwin, N, heads, None))
+    L.vx_check(G.api().vx_window_attention_f16(G.dev(qkv.astype(np.float16)).ptr, G.dev(packed).ptr, out.ptr, nwin, N, heads, None))
     G.sync()
     got = out.to_numpy(np.float16, (nwin, N, dim)).astype(np.float32)
     q4 = qkv.reshape(nwin, N, heads, 3, 32)

@@ -122,65 +122,6 @@ __global__ __launch_bounds__(256) void tv_layernorm_kernel(const f16* __restrict
     }
 }
 
-// ---- window attention with relative position bias (attention_rel_bias, mobile-sam.cpp:122-131; nn.cpp:182-244):
-// qkv f16 [rows][3*dim] in window order, head h = columns h*3*32 + {0..31 q, 32..63 k, 64..95 v}; bias f32 [heads][N][N];
-// out f16 [rows][dim], head h at columns h*32. One block per (window, head), one lane per query, K and V of the window's
-// head staged in LDS as f32; softmax(q k^T * scale + bias) v in f32 with an online maximum.
-constexpr int TV_HD = 32;
-__global__ void tv_window_attention_kernel(const f16* __restrict__ qkv, const float* __restrict__ bias, f16* __restrict__ out, int N, int heads,
-                                           float scale) {
-    extern __shared__ float tv_smem[];
-    float* sk = tv_smem;               // [N][32]
-    float* sv = tv_smem + N * TV_HD;   // [N][32]
-    const int win = blockIdx.x / heads, h = blockIdx.x - win * heads;
-    const int dim3x = heads * 3 * TV_HD;
-    const f16* base = qkv + (long)win * N * dim3x + h * 3 * TV_HD;
-    for (int i = threadIdx.x; i < N * (TV_HD / 8); i += blockDim.x) { // 8 channels per thread and step
-        const int j = i / (TV_HD / 8), c8 = i % (TV_HD / 8);
-        const f16x8 kv = *reinterpret_cast<const f16x8*>(base + (long)j * dim3x + TV_HD + c8 * 8);
-        const f16x8 vv = *reinterpret_cast<const f16x8*>(base + (long)j * dim3x + 2 * TV_HD + c8 * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sk[j * TV_HD + c8 * 8 + e] = (float)kv[e];
-            sv[j * TV_HD + c8 * 8 + e] = (float)vv[e];
-        }
-    }
-    __syncthreads();
-    const int i = threadIdx.x;
-    if (i >= N) return;
-    float q[TV_HD], acc[TV_HD];
-#pragma unroll
-    for (int c8 = 0; c8 < TV_HD / 8; ++c8) {
-        const f16x8 qv = *reinterpret_cast<const f16x8*>(base + (long)i * dim3x + c8 * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q[c8 * 8 + e] = (float)qv[e] * scale;
-    }
-#pragma unroll
-    for (int c = 0; c < TV_HD; ++c) acc[c] = 0.0f;
-    const float* brow = bias + ((long)h * N + i) * N;
-    float m = -INFINITY, l = 0.0f;
-    for (int j = 0; j < N; ++j) {
-        float s = brow[j];
-#pragma unroll
-        for (int c = 0; c < TV_HD; ++c) s = fmaf(q[c], sk[j * TV_HD + c], s);
-        const float m_new = fmaxf(m, s);
-        const float alpha = __expf(m - m_new), p = __expf(s - m_new);
-        l = l * alpha + p;
-#pragma unroll
-        for (int c = 0; c < TV_HD; ++c) acc[c] = fmaf(p, sv[j * TV_HD + c], acc[c] * alpha);
-        m = m_new;
-    }
-    const float inv = 1.0f / l;
-    f16* o = out + ((long)win * N + i) * (heads * TV_HD) + h * TV_HD;
-#pragma unroll
-    for (int c8 = 0; c8 < TV_HD / 8; ++c8) {
-        f16x8 ov;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = (f16)(acc[c8 * 8 + e] * inv);
-        *reinterpret_cast<f16x8*>(o + c8 * 8) = ov;
-    }
-}
-
 // ---- window_reverse + residual (mobile-sam.cpp:48-64, 146-149): y[b, py, px, :] = x[b, py, px, :] + a[window row of (py, px), :]
 __global__ void tv_window_reverse_add_kernel(const f16* __restrict__ a, const f16* __restrict__ x, f16* __restrict__ y, int B, int res, int ws,
                                              int nw, int C) {
@@ -250,17 +191,6 @@ int vx_layernorm_f16(const void* x, const float* w, const float* b, void* y, int
     VX_REQUIRE(ws == 0 || rows_out % ((int64_t)nw * nw * ws * ws) == 0, "vx_layernorm_f16: rows do not form whole images of %d x %d windows", nw, nw);
     hipLaunchKernelGGL(tv_layernorm_kernel, dim3(blocks_for(rows_out, 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(x), w, b, y,
                        (long)rows_out, C, eps, res, ws, nw, out_f32);
-    VX_LAUNCH_CHECK();
-    return 1;
-}
-
-int vx_window_attention_f16(const void* qkv, const float* bias, void* out, int n_windows, int N, int heads, void* stream) {
-    VX_REQUIRE(qkv && bias && out && n_windows > 0 && heads > 0, "vx_window_attention_f16: bad operands");
-    VX_REQUIRE(N > 0 && N <= 256, "vx_window_attention_f16: %d tokens per window (at most 256)", N);
-    const int threads = (N + 63) / 64 * 64;
-    const size_t smem = (size_t)2 * N * TV_HD * sizeof(float);
-    hipLaunchKernelGGL(tv_window_attention_kernel, dim3((unsigned)n_windows * heads), dim3(threads), smem, as_stream(stream),
-                       reinterpret_cast<const f16*>(qkv), bias, reinterpret_cast<f16*>(out), N, heads, 1.0f / sqrtf((float)TV_HD));
     VX_LAUNCH_CHECK();
     return 1;
 }

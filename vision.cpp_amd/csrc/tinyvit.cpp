@@ -69,6 +69,22 @@ struct packer {
         return v;
     }
 
+    // attention_biases_indexed [heads][N][N] -> the accumulator-order f16 image of kernels_winattn.hip
+    packed_vec attention_bias(std::string const& name, int N, int heads) {
+        gguf_tensor const& t = get(name);
+        if (t.n_elements() != (int64_t)heads * N * N)
+            throw except("mobile-sam: %s has %lld elements, expected %d", name.c_str(), (long long)t.n_elements(), heads * N * N);
+        packed_vec v;
+        v.n = (int)(vx_window_attention_bias_bytes(N, heads) / 2);
+        v.off = ab.alloc((size_t)v.n * 2);
+        if (with_data) {
+            std::vector<float> f((size_t)heads * N * N);
+            for (size_t i = 0; i < f.size(); ++i) f[i] = tensor_at(t, i);
+            VX(vx_window_attention_pack_bias(f.data(), N, heads, ab.data.data() + v.off));
+        }
+        return v;
+    }
+
     // rows [n][k] -> f16 [N pad 32][K pad 64] + f32 bias [N]
     packed_gemm matrix(int n, int k, std::function<float(int, int)> at, gguf_tensor const* bias) {
         packed_gemm g;
@@ -198,9 +214,7 @@ sam_model* sam_load_model(char const* filepath, backend_device const& dev, int f
             b.attn_ln_b = pk.vec(p + ".attn.norm.bias");
             b.qkv = pk.linear(p + ".attn.qkv");
             b.proj = pk.linear(p + ".attn.proj");
-            b.bias = pk.vec(p + ".attn.attention_biases_indexed");
-            const int N = L.window_size * L.window_size;
-            if (b.bias.n != L.num_heads * N * N) throw except("mobile-sam: %s.attn.attention_biases_indexed has %d elements, expected %d", p.c_str(), b.bias.n, L.num_heads * N * N);
+            b.bias = pk.attention_bias(p + ".attn.attention_biases_indexed", L.window_size * L.window_size, L.num_heads);
             if (b.qkv.n_real != 3 * L.embed_dim || b.qkv.k_real != L.embed_dim || L.embed_dim != 32 * L.num_heads)
                 throw except("mobile-sam: %s.attn.qkv is %d x %d (this backend implements head_dim 32)", p.c_str(), b.qkv.n_real, b.qkv.k_real);
             b.local_conv = pk.depthwise(p + ".local_conv.c");
@@ -392,7 +406,7 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
             VX(vx_layernorm_f16(x, ex.fptr(b.attn_ln_w), ex.fptr(b.attn_ln_b), t1, rows, C, 1e-5f, res, ws, 0, s));
             ex.gemm(b.qkv, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_qkv");
             ex.mark("window_attention", 4.0 * rows * N * C, (double)rows * C * 8);
-            VX(vx_window_attention_f16(t2, ex.fptr(b.bias), t1, (int)(rows / N), N, L.num_heads, s));
+            VX(vx_window_attention_f16(t2, ex.wa + b.bias.off, t1, (int)(rows / N), N, L.num_heads, s));
             ex.gemm(b.proj, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_proj");
             ex.mark("elementwise", 0, (double)T * C * 6);
             VX(vx_window_reverse_add_f16(t2, x, t1, B, res, ws, C, s));

@@ -19,7 +19,7 @@ struct packed_dw { size_t w = 0, b = 0; int C = 0; };   // depthwise 3x3: f16 [9
 struct tv_mbconv_weights { packed_gemm conv1, conv3; packed_dw conv2; };
 struct tv_merge_weights { packed_gemm conv1, conv3; packed_dw conv2; int stride = 2; };
 struct tv_block_weights {
-    packed_vec attn_ln_w, attn_ln_b, bias; // bias: attention_biases_indexed f32 [heads][N][N]
+    packed_vec attn_ln_w, attn_ln_b, bias; // bias: attention_biases_indexed packed f16 (vx_window_attention_pack_bias), n = f16 count
     packed_gemm qkv, proj, fc1, fc2;
     packed_dw local_conv;
     packed_vec mlp_ln_w, mlp_ln_b;
