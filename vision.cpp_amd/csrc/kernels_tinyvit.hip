@@ -31,59 +31,85 @@ __global__ void tv_preprocess_kernel(const uint8_t* __restrict__ rgb, f16* __res
 }
 
 // ---- depthwise 3x3, pad 1, stride 1 or 2, NHWC f16, weights [9][C] f16 (tap-major), bias f32 [C]; optional GELU
-// (conv_2d_depthwise + add_bias_2d, nn.cpp:102-115). One thread = one output pixel x 8 channels.
-__global__ void tv_dwconv3x3_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const float* __restrict__ bias,
-                                    f16* __restrict__ y, int B, int H, int W, int C, int stride, int gelu) {
-    const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
-    const int c8n = C >> 3;
-    const long n = (long)B * OH * OW * c8n;
+// (conv_2d_depthwise + add_bias_2d, nn.cpp:102-115). One thread = P consecutive output pixels of one row x 8 channels: an
+// input row segment of (P-1)*S+3 pixels is loaded once and feeds all P outputs (3.75 loads per output at P = 8 instead
+// of 9), the nine weight vectors stay packed f16 in registers (v_fma_mix reads them directly). Lanes run over the
+// channel groups first, so every load / store instruction covers whole pixels (C * 2 contiguous bytes).
+template <int S, int P>
+__global__ __launch_bounds__(256) void tv_dwconv3x3_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const float* __restrict__ bias,
+                                                           f16* __restrict__ y, int B, int H, int W, int C, int OH, int OW, int gelu) {
+    constexpr int NC = (P - 1) * S + 3;
+    const int c8n = C >> 3, strips = (OW + P - 1) / P;
+    const long n = (long)B * OH * strips * c8n;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c8 = (int)(i % c8n);
     long q = i / c8n;
-    const int ox = (int)(q % OW);
-    q /= OW;
+    const int ox0 = (int)(q % strips) * P;
+    q /= strips;
     const int oy = (int)(q % OH), b = (int)(q / OH);
-    float acc[8];
+    f16x8 wv[9];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f16x8*>(w + (long)t * C + c8 * 8);
+    float acc[P][8];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[p][j] = 0.0f;
+    const int ix0 = ox0 * S - 1;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * stride - 1 + ky;
+        const int iy = oy * S - 1 + ky;
         if ((unsigned)iy >= (unsigned)H) continue;
+        const f16* row = x + ((long)b * H + iy) * W * C + c8 * 8;
+        f16x8 col[NC];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * stride - 1 + kx;
-            if ((unsigned)ix >= (unsigned)W) continue;
-            const f16x8 xv = *reinterpret_cast<const f16x8*>(x + (((long)b * H + iy) * W + ix) * C + c8 * 8);
-            const f16x8 wv = *reinterpret_cast<const f16x8*>(w + (long)(ky * 3 + kx) * C + c8 * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)xv[j], (float)wv[j], acc[j]);
+        for (int t = 0; t < NC; ++t) {
+            const int ix = ix0 + t;
+            if ((unsigned)ix < (unsigned)W) col[t] = *reinterpret_cast<const f16x8*>(row + (long)ix * C);
+            else col[t] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
-    }
-    f16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float v = acc[j] + bias[c8 * 8 + j];
-        if (gelu) v = gelu_tanh_f(v);
-        o[j] = (f16)v;
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[p][j] = fmaf((float)col[p * S + kx][j], (float)wv[ky * 3 + kx][j], acc[p][j]);
     }
-    *reinterpret_cast<f16x8*>(y + i * 8) = o;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = bias[c8 * 8 + j];
+    f16* out = y + (((long)b * OH + oy) * OW + ox0) * C + c8 * 8;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (ox0 + p >= OW) break;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[p][j] + bv[j];
+            if (gelu) v = gelu_tanh_f(v);
+            o[j] = (f16)v;
+        }
+        *reinterpret_cast<f16x8*>(out + (long)p * C) = o;
+    }
 }
 
-// ---- LayerNorm over channels of f16 rows (layer_norm, nn.cpp:14-19), one wave per OUTPUT row, C <= 512.
+// ---- LayerNorm over channels of f16 rows (layer_norm, nn.cpp:14-19). A row is handled by a group of G lanes (G = 16, 32
+// or 64, the smallest with 8 G >= C), each lane holding 8 consecutive channels (one 16-byte load), so a wave normalises
+// 64 / G rows per pass; two-pass statistics in f32 by xor shuffles inside the group.
 // ws > 0: the output rows are in window order (window_partition, mobile-sam.cpp:25-46): row = ((b*nw + wy)*nw + wx)*ws*ws
 // + iy*ws + ix reads pixel (wy*ws+iy, wx*ws+ix); pixels beyond res are the zero padding, whose norm is the bias vector.
 // out_f32: write f32 instead of f16 (the encoder's final LayerNorm2d).
+template <int G>
 __global__ __launch_bounds__(256) void tv_layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                            void* __restrict__ y, long rows_out, int C, float eps, int res, int ws, int nw,
                                                            int out_f32) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows_out) return;
+    const int gl = threadIdx.x & (G - 1);
+    const long row = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+    const bool live = row < rows_out; // dead groups still take part in the shuffles
     long src = row;
-    bool padded = false;
-    if (ws > 0) {
+    bool padded = !live;
+    if (ws > 0 && live) {
         const int N = ws * ws;
         const int in = (int)(row % N);
         long wq = row / N;
@@ -94,31 +120,48 @@ __global__ __launch_bounds__(256) void tv_layernorm_kernel(const f16* __restrict
         padded = py >= res || px >= res;
         src = ((long)bb * res + py) * res + px;
     }
+    const int c0 = gl * 8;
+    const bool has = c0 < C;
     float v[8];
+    if (has && !padded) {
+        const f16x8 xv = *reinterpret_cast<const f16x8*>(x + src * C + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)xv[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    }
     float sum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = (!padded && c < C) ? (float)x[src * C + c] : 0.0f;
-        sum += v[i];
-    }
-    const float mean = wave_sum(sum) / (float)C;
+    for (int j = 0; j < 8; ++j) sum += v[j];
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)C;
     float sq = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
-        const float d = c < C ? v[i] - mean : 0.0f;
-        v[i] = d;
-        sq += d * d;
+    for (int j = 0; j < 8; ++j) {
+        v[j] = has ? v[j] - mean : 0.0f;
+        sq += v[j] * v[j];
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
-        if (c >= C) continue;
-        const float o = v[i] * rstd * w[c] + b[c];
-        if (out_f32) reinterpret_cast<float*>(y)[row * C + c] = o;
-        else reinterpret_cast<f16*>(y)[row * C + c] = (f16)o;
+    for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    if (!live || !has) return;
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c0), w1 = *reinterpret_cast<const float4*>(w + c0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c0), b1 = *reinterpret_cast<const float4*>(b + c0 + 4);
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v[j] * rstd * wv[j] + bv[j];
+    if (out_f32) {
+        float* dst = reinterpret_cast<float*>(y) + row * C + c0;
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+        f16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = (f16)o[j];
+        *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(y) + row * C + c0) = ov;
     }
 }
 
@@ -177,20 +220,33 @@ int vx_dwconv3x3_f16(const void* x, const void* w, const float* bias, void* y, i
     VX_REQUIRE(x && w && bias && y && B > 0 && H > 0 && W > 0, "vx_dwconv3x3_f16: bad operands");
     VX_REQUIRE(C % 8 == 0 && (stride == 1 || stride == 2), "vx_dwconv3x3_f16: C %% 8 == 0 and stride 1 or 2 only (C = %d, stride = %d)", C, stride);
     const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
-    const long n = (long)B * OH * OW * (C / 8);
-    hipLaunchKernelGGL(tv_dwconv3x3_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(x),
-                       reinterpret_cast<const f16*>(w), bias, reinterpret_cast<f16*>(y), B, H, W, C, stride, gelu);
+    const f16* xp = reinterpret_cast<const f16*>(x);
+    const f16* wp = reinterpret_cast<const f16*>(w);
+    f16* yp = reinterpret_cast<f16*>(y);
+    if (stride == 1) {
+        constexpr int P = 8;
+        const long n = (long)B * OH * ((OW + P - 1) / P) * (C / 8);
+        hipLaunchKernelGGL((tv_dwconv3x3_kernel<1, P>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), xp, wp, bias, yp, B, H, W, C, OH, OW, gelu);
+    } else {
+        constexpr int P = 4;
+        const long n = (long)B * OH * ((OW + P - 1) / P) * (C / 8);
+        hipLaunchKernelGGL((tv_dwconv3x3_kernel<2, P>), dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), xp, wp, bias, yp, B, H, W, C, OH, OW, gelu);
+    }
     VX_LAUNCH_CHECK();
     return 1;
 }
 
 int vx_layernorm_f16(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int res, int ws, int out_f32,
                      void* stream) {
-    VX_REQUIRE(x && w && b && y && rows_out > 0 && C > 0 && C <= 512, "vx_layernorm_f16: bad operands (C = %d, at most 512)", C);
+    VX_REQUIRE(x && w && b && y && rows_out > 0 && C > 0 && C <= 512 && C % 8 == 0, "vx_layernorm_f16: bad operands (C = %d: a multiple of 8, at most 512)", C);
     const int nw = ws > 0 ? (res + ws - 1) / ws : 0;
     VX_REQUIRE(ws == 0 || rows_out % ((int64_t)nw * nw * ws * ws) == 0, "vx_layernorm_f16: rows do not form whole images of %d x %d windows", nw, nw);
-    hipLaunchKernelGGL(tv_layernorm_kernel, dim3(blocks_for(rows_out, 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(x), w, b, y,
-                       (long)rows_out, C, eps, res, ws, nw, out_f32);
+    const f16* xp = reinterpret_cast<const f16*>(x);
+    const long rows = (long)rows_out;
+    hipStream_t s = as_stream(stream);
+    if (C <= 128) hipLaunchKernelGGL(tv_layernorm_kernel<16>, dim3(blocks_for(rows, 16)), dim3(256), 0, s, xp, w, b, y, rows, C, eps, res, ws, nw, out_f32);
+    else if (C <= 256) hipLaunchKernelGGL(tv_layernorm_kernel<32>, dim3(blocks_for(rows, 8)), dim3(256), 0, s, xp, w, b, y, rows, C, eps, res, ws, nw, out_f32);
+    else hipLaunchKernelGGL(tv_layernorm_kernel<64>, dim3(blocks_for(rows, 4)), dim3(256), 0, s, xp, w, b, y, rows, C, eps, res, ws, nw, out_f32);
     VX_LAUNCH_CHECK();
     return 1;
 }
