@@ -89,7 +89,11 @@ struct packer {
     packed_gemm matrix(int n, int k, std::function<float(int, int)> at, gguf_tensor const* bias) {
         packed_gemm g;
         g.n_real = n; g.k_real = k;
-        g.N = round_up(n, 32); g.K = round_up(k, 64);
+        // N decides the GEMM's block tile (128 wide if N % 128 == 0, else 64, else 32): wider tiles re-read A fewer times, so pad
+        // to 64, and to 128 when that costs at most 10% more columns (480 -> 512, 960 -> 1024; measured +2% on the encoder)
+        g.N = round_up(n, n > 64 ? 64 : 32);
+        if (round_up(n, 128) * 10 <= n * 11) g.N = round_up(n, 128);
+        g.K = round_up(k, 64);
         g.w = ab.alloc((size_t)g.N * g.K * 2);
         if (with_data) {
             uint16_t* w = reinterpret_cast<uint16_t*>(ab.data.data() + g.w);
@@ -261,6 +265,7 @@ struct tv_exec {
     const uint8_t* wa;
     std::vector<std::pair<std::string, void*>> marks;
     std::vector<timing_entry> acc;
+    int gemm_variant = 0; // vx_gemm_args.stages: tile-shape selector of the plain GEMM (0 = its default)
 
     const float* fptr(packed_vec const& v) const { return reinterpret_cast<const float*>(wa + v.off); }
     void mark(const char* name, double flops, double bytes) {
@@ -303,6 +308,7 @@ struct tv_exec {
         a.W = wa + g.w; a.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b);
         a.M = (int)M; a.N = g.N; a.K = g.K; a.n_valid = g.n_real;
         a.epi = epi; a.out = out; a.ldo = g.n_real; a.res1 = res1;
+        a.stages = gemm_variant;
         mark(group, 2.0 * M * g.n_real * g.k_real, (double)M * (g.k_real + g.n_real) * 2);
         VX(vx_gemm_f16(&a, stream));
     }
@@ -366,6 +372,7 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
     void* pe = base + 4 * big + in_bytes;
 
     tv_exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
+    if (const char* e = getenv("VISP_TV_GEMM_VARIANT")) ex.gemm_variant = atoi(e);
     ex.mark("preprocess", 0, (double)B * S * S * 19);
     VX(vx_tv_preprocess(static_cast<const uint8_t*>(rgb_dev), in8, (int64_t)B * S * S, s));
     // patch_embed (mobile-sam.cpp:70-75)
