@@ -24,6 +24,12 @@
  * vectors of tests/test-image.cpp:303-360 and against outputs of the reference's own torch modules
  * (tests/test_esrgan.py:70-212 ResidualDenseBlock_5C / RRDB / RRDBNet, imported in the CPU container by
  * tests/golden/make_golden_esrgan.py; fixtures tests/golden/esrgan_*.npz).
+ *
+ * TinyViT part (vo_tinyvit_*, vo_attention_rel_bias, vo_conv2d_depthwise_nhwc): pinned (tests/test_oracle_tinyvit.py)
+ * against outputs of the reference's own torch TinyViT (tests/test_mobile_sam.py:18-765, imported in the CPU container by
+ * tests/golden/make_golden_tinyvit.py; fixture tests/golden/tinyvit_5m.npz: the 5M configuration at 1024x1024, samples
+ * of every stage boundary). Exact (2e-4) with the torch twin's GELU forms, within the reference's module tolerance in
+ * the ggml form (tanh GELU everywhere).
  */
 #ifndef VISP_ORACLE_H
 #define VISP_ORACLE_H

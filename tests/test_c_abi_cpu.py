@@ -191,3 +191,29 @@ int main(void) {
     want = [C.sizeof(L.GemmArgs), L.GemmArgs.debug_stamps.offset, C.sizeof(L.DconvArgs), L.DconvArgs.stamps.offset, C.sizeof(L.TileLayout),
             C.sizeof(L.ImageView), C.sizeof(L.Timing), C.sizeof(L.EsrganInfo)]
     assert got == want, (got, want)
+
+
+def test_mobile_sam_gguf_is_detected_and_bias_packing_is_host_code(tmp_path):
+    """write_tinyvit_gguf follows convert_sam's header contract (family 0 by architecture string), and the attention-bias
+    packer (host code in the HIP library) lays the [heads][N][N] table out in MFMA accumulator order with -inf pads."""
+    from visioncpp_amd import synth
+    lib = L.get_lib()
+    p = synth.write_tinyvit_gguf(tmp_path / "sam.gguf", seed=5)
+    fam = C.c_int32(-1)
+    L.check(lib.visp_model_detect_family(L.path_to_char_p(p), C.byref(fam)))
+    assert fam.value == 0
+    N, heads, QB = 49, 3, 2
+    assert lib.vx_window_attention_bias_bytes(N, heads) == heads * QB * QB * 64 * 16 * 2
+    assert lib.vx_window_attention_bias_bytes(196, 5) == 5 * 7 * 7 * 64 * 16 * 2
+    bias = np.random.default_rng(0).standard_normal((heads, N, N)).astype(np.float16).astype(np.float32)
+    packed = np.zeros(heads * QB * QB * 64 * 16, np.float16)
+    L.vx_check(lib.vx_window_attention_pack_bias(bias.ctypes.data, N, heads, packed.ctypes.data))
+    pk = packed.reshape(heads, QB, QB, 64, 16).astype(np.float32)
+    lane, e = np.meshgrid(np.arange(64), np.arange(16), indexing="ij")
+    for qb in range(QB):
+        for kb in range(QB):
+            q = qb * 32 + (lane & 31)
+            key = kb * 32 + (e >> 2) * 8 + 4 * (lane >> 5) + (e & 3)
+            want = np.where(key >= N, -np.inf, np.where(q < N, bias[:, np.minimum(q, N - 1), np.minimum(key, N - 1)], 0.0))
+            assert np.array_equal(pk[:, qb, kb], want)
+    assert lib.vx_window_attention_pack_bias(bias.ctypes.data, 300, heads, packed.ctypes.data) == 0  # more than 256 tokens
