@@ -102,6 +102,11 @@ typedef struct {
     int n_valid;        /* columns >= n_valid are not stored (N padded for tiling); 0 = N        */
     int stages;         /* LDS ring depth of the k-loop: 0 = kernel default (tuning knob for benches) */
     float head_bias, head_scale; /* VX_EPI_HEAD_OUT: conv3 bias, max_depth; lambda = conv3 weights f32 [N] */
+    /* VX_EPI_F16_ADD extras (TinyViT): post_gelu: out = gelu(acc + bias + res1 [+ res2]) (mb_conv tail, mobile-sam.cpp:88-90).
+     * win_ws > 0: the M rows are in window order of a win_res x win_res map (window_partition with zero padding,
+     * mobile-sam.cpp:25-46); out and res1/res2 are addressed at the PIXEL row of each window row, padded rows are dropped:
+     * window_reverse + residual add fused (mobile-sam.cpp:48-64, 146-149) */
+    int post_gelu, win_ws, win_res;
     void* debug_stamps; /* diagnostics only: u64 [blocks][8] s_memtime stamps per phase, NULL in product */
 } vx_gemm_args;
 

@@ -130,6 +130,43 @@ def test_gelu_is_finite_for_large_arguments():
     np.testing.assert_allclose(got, O.gelu(x.astype(np.float32), O.GELU_TANH_F32), atol=2e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("res,ws,Cc", [(10, 4, 64), (14, 7, 160), (16, 14, 128)])
+def test_gemm_epilogue_window_reverse_add(res, ws, Cc):
+    """proj linear + window_reverse + residual in one launch: rows in window order are scattered to their pixels, rows of
+    the zero padding are dropped (mobile-sam.cpp:48-64, 146-149)."""
+    from tests import gpu_util as G
+    from visioncpp_amd import _lib as L
+    rng = np.random.default_rng(res * ws)
+    B, nw = 2, -(-res // ws)
+    rows = B * nw * nw * ws * ws
+    a = _h(rng.standard_normal((rows, Cc)) * 0.5)
+    w = _h(rng.standard_normal((Cc, Cc)) / np.sqrt(Cc))
+    bias = rng.standard_normal(Cc).astype(np.float32) * 0.1
+    x = _h(rng.standard_normal((B, res, res, Cc)))
+    out = G.empty(B * res * res * Cc * 2)
+    G.gemm(G.dev(a.astype(np.float16)), G.pad_weight(w), np.pad(bias, (0, (-Cc) % 32)), rows, L.EPI_F16_ADD, lda=Cc, out=out, ldo=Cc,
+           n_valid=Cc, res1=G.dev(x.astype(np.float16)), win_ws=ws, win_res=res)
+    y = _h(a @ w.T + bias).reshape(B, nw, nw, ws, ws, Cc).transpose(0, 1, 3, 2, 4, 5).reshape(B, nw * ws, nw * ws, Cc)[:, :res, :res]
+    np.testing.assert_allclose(out.to_numpy(np.float16, (B, res, res, Cc)).astype(np.float32), y + x, atol=4e-3, rtol=4e-3)
+
+
+def test_gemm_epilogue_residual_then_gelu():
+    """mb_conv tail (mobile-sam.cpp:88-90): gelu(x + conv3(.)) from the GEMM epilogue."""
+    from tests import gpu_util as G
+    from visioncpp_amd import _lib as L
+    rng = np.random.default_rng(3)
+    M, K, N = 300, 256, 64
+    a = _h(rng.standard_normal((M, K)) * 0.5)
+    w = _h(rng.standard_normal((N, K)) / np.sqrt(K))
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    x = _h(rng.standard_normal((M, N)) * 3)
+    out = G.empty(M * N * 2)
+    G.gemm(G.dev(a.astype(np.float16)), G.pad_weight(w), bias, M, L.EPI_F16_ADD, lda=K, out=out, ldo=N, n_valid=N,
+           res1=G.dev(x.astype(np.float16)), post_gelu=1)
+    want = O.gelu(_h(a @ w.T + bias) + x, O.GELU_TANH_F32)
+    np.testing.assert_allclose(out.to_numpy(np.float16, (M, N)).astype(np.float32), want, atol=4e-3, rtol=4e-3)
+
+
 # ---- the whole encoder through the C ABI ---------------------------------------------------------------------------
 
 GOLD = __import__("pathlib").Path(__file__).parent / "golden"

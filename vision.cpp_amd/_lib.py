@@ -64,7 +64,8 @@ class GemmArgs(ctypes.Structure):  # == vx_gemm_args
         ("q", c_void_p), ("k", c_void_p), ("vt", c_void_p), ("qkv_T", c_int), ("qkv_Tp", c_int), ("qkv_H", c_int),
         ("q_scale", c_float),
         ("ps_s", c_int), ("ps_Cout", c_int), ("ps_H", c_int), ("ps_W", c_int),
-        ("res1", c_void_p), ("res2", c_void_p), ("n_valid", c_int), ("stages", c_int), ("head_bias", c_float), ("head_scale", c_float), ("debug_stamps", c_void_p),
+        ("res1", c_void_p), ("res2", c_void_p), ("n_valid", c_int), ("stages", c_int), ("head_bias", c_float), ("head_scale", c_float),
+        ("post_gelu", c_int), ("win_ws", c_int), ("win_res", c_int), ("debug_stamps", c_void_p),
     ]
 
 

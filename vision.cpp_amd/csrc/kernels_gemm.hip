@@ -367,13 +367,27 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
             } else if constexpr (EPI == VX_EPI_F16 || EPI == VX_EPI_F16_GELU || EPI == VX_EPI_F16_RELU) {
                 *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + (long)m * p.ldo + n) = v;
             } else if constexpr (EPI == VX_EPI_F16_ADD) {
-                const long o = (long)m * p.ldo + n;
+                long o = (long)m * p.ldo + n;
+                if (p.win_ws > 0) { // window-order row m -> pixel row (window_reverse); rows of the zero padding are dropped
+                    const int ws = p.win_ws, res = p.win_res, nw = (res + ws - 1) / ws, N = ws * ws;
+                    const int in = m % N;
+                    int wq = m / N;
+                    const int wx = wq % nw;
+                    wq /= nw;
+                    const int wy = wq % nw, bb = wq / nw;
+                    const int py = wy * ws + in / ws, px = wx * ws + in % ws;
+                    if (py >= res || px >= res) continue;
+                    o = (((long)bb * res + py) * res + px) * p.ldo + n;
+                }
                 if (p.res1) {
                     f16x8 a = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.res1) + o);
                     if (p.res2) {
                         f16x8 b = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.res2) + o);
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] = (f16)((float)v[q] + (float)a[q] + (float)b[q]);
+                    } else if (p.post_gelu) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = (f16)gelu_tanh((float)v[q] + (float)a[q]);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] = (f16)((float)v[q] + (float)a[q]);
@@ -499,6 +513,12 @@ extern "C" int vx_gemm_f16(const vx_gemm_args* args, void* stream) {
     }
     if (a.epi == VX_EPI_PIXSHUF) VX_REQUIRE(a.ps_Cout % 8 == 0, "vx_gemm_f16: pixel-shuffle Cout=%d must be a multiple of 8", a.ps_Cout);
     if (a.epi == VX_EPI_QKV) VX_REQUIRE(a.N == 3 * a.qkv_H * 64, "vx_gemm_f16: QKV epilogue needs N == 3*H*64");
+    if (a.post_gelu) VX_REQUIRE(a.epi == VX_EPI_F16_ADD && a.res1 && !a.res2, "vx_gemm_f16: post_gelu needs the F16_ADD epilogue with exactly one residual");
+    if (a.win_ws > 0) {
+        VX_REQUIRE(a.epi == VX_EPI_F16_ADD && a.conv_kh == 0 && a.win_res > 0, "vx_gemm_f16: window-order output needs the plain F16_ADD form");
+        const long nw = (a.win_res + a.win_ws - 1) / a.win_ws;
+        VX_REQUIRE(a.M % (nw * nw * a.win_ws * a.win_ws) == 0, "vx_gemm_f16: M=%d is not a whole number of %ld x %ld window maps", a.M, nw, nw);
+    }
     if (a.epi == VX_EPI_HEAD_OUT) VX_REQUIRE(a.N == 32 && a.lambda, "vx_gemm_f16: head epilogue needs N == 32 and conv3 weights");
     if (a.conv_kh > 0) {
         VX_REQUIRE(a.conv_Cin % 8 == 0, "vx_gemm_f16: conv Cin=%d must be a multiple of 8", a.conv_Cin);

@@ -5,6 +5,8 @@
 // coalesced memory access; the attention core still runs on the VALU (one lane per query).
 #include "vx_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ float gelu_tanh_f(float x) { // ggml_gelu (tanh form), the reference's activation everywhere
@@ -41,7 +43,15 @@ __global__ __launch_bounds__(256) void tv_dwconv3x3_kernel(const f16* __restrict
     constexpr int NC = (P - 1) * S + 3;
     const int c8n = C >> 3, strips = (OW + P - 1) / P;
     const long n = (long)B * OH * strips * c8n;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware block order: blocks b and b+8 share an XCD and its L2. Every XCD gets a contiguous run of the row-major
+    // sequence, so the three output rows that read one input row fetch it through ONE L2 instead of three.
+    long blk;
+    {
+        const long nwg = gridDim.x, b = blockIdx.x;
+        const long q = nwg >> 3, rem = nwg & 7, xcd = b & 7;
+        blk = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+    }
+    const long i = blk * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c8 = (int)(i % c8n);
     long q = i / c8n;

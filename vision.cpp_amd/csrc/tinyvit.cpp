@@ -301,7 +301,8 @@ struct tv_exec {
     }
 
     // C[M, N] = A[M, lda] * W^T (+bias) with the epilogues of the GEMM family
-    void gemm(packed_gemm const& g, const void* A, long M, int lda, void* out, int epi, const void* res1, const char* group) {
+    void gemm(packed_gemm const& g, const void* A, long M, int lda, void* out, int epi, const void* res1, const char* group,
+              bool post_gelu = false, int win_ws = 0, int win_res = 0) {
         vx_gemm_args a;
         memset(&a, 0, sizeof a);
         a.A = A; a.lda = lda;
@@ -309,6 +310,7 @@ struct tv_exec {
         a.M = (int)M; a.N = g.N; a.K = g.K; a.n_valid = g.n_real;
         a.epi = epi; a.out = out; a.ldo = g.n_real; a.res1 = res1;
         a.stages = gemm_variant;
+        a.post_gelu = post_gelu; a.win_ws = win_ws; a.win_res = win_res;
         mark(group, 2.0 * M * g.n_real * g.k_real, (double)M * (g.k_real + g.n_real) * 2);
         VX(vx_gemm_f16(&a, stream));
     }
@@ -386,9 +388,7 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
         const long M = (long)B * res * res;
         ex.gemm(mb.conv1, x, M, C, t1, VX_EPI_F16_GELU, nullptr, "mbconv_1x1");
         ex.dw(mb.conv2, t1, t2, B, res, res, 1, true, "depthwise");
-        ex.gemm(mb.conv3, t2, M, mb.conv1.n_real, t1, VX_EPI_F16, nullptr, "mbconv_1x1");
-        ex.mark("elementwise", 0, (double)M * C * 6);
-        VX(vx_add_gelu_f16(t1, x, t3, M * C, s));
+        ex.gemm(mb.conv3, t2, M, mb.conv1.n_real, t3, VX_EPI_F16_ADD, x, "mbconv_1x1", /*post_gelu=*/true); // gelu(x + conv3) in the epilogue
         std::swap(x, t3);
     }
     auto patch_merging = [&](tv_merge_weights const& mg) { // mobile-sam.cpp:94-110
@@ -414,10 +414,9 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
             ex.gemm(b.qkv, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_qkv");
             ex.mark("window_attention", 4.0 * rows * N * C, (double)rows * C * 8);
             VX(vx_window_attention_f16(t2, ex.wa + b.bias.off, t1, (int)(rows / N), N, L.num_heads, s));
-            ex.gemm(b.proj, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_proj");
-            ex.mark("elementwise", 0, (double)T * C * 6);
-            VX(vx_window_reverse_add_f16(t2, x, t1, B, res, ws, C, s));
-            ex.dw(b.local_conv, t1, t3, B, res, res, 1, false, "depthwise");
+            // proj + window_reverse + residual: window rows are scattered to their pixels by the epilogue
+            ex.gemm(b.proj, t1, rows, C, t2, VX_EPI_F16_ADD, x, "gemm_proj", false, ws, res);
+            ex.dw(b.local_conv, t2, t3, B, res, res, 1, false, "depthwise");
             ex.mark("layernorm", 0, (double)T * C * 4);
             VX(vx_layernorm_f16(t3, ex.fptr(b.mlp_ln_w), ex.fptr(b.mlp_ln_b), t1, T, C, 1e-5f, 0, 0, 0, s));
             ex.gemm(b.fc1, t1, T, C, t2, VX_EPI_F16_GELU, nullptr, "gemm_fc1");
