@@ -468,3 +468,62 @@ def conv2d_depthwise_nhwc(x: np.ndarray, w: np.ndarray, b: np.ndarray | None, st
     y = np.empty((OH, OW, Cc), np.float32)
     _tv_lib().vo_conv2d_depthwise_nhwc(_fp(x), H, W_, Cc, _fp(w), _fp(_f32(b)) if b is not None else None, k, stride, pad, _fp(y))
     return y
+
+
+# ---- MobileSAM prompt encoder + mask decoder (sam_compute) ----------------------------------------------------------
+
+def _sam_lib():
+    L = lib()
+    if not getattr(L, "_sam_ready", False):
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.vo_sam_process_prompt.argtypes = [ip, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.vo_sam_process_prompt.restype = None
+        L.vo_sam_embed_prompt.argtypes = [C.c_void_p, fp, C.c_int, fp, ip]
+        L.vo_sam_predict_masks.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, fp, C.c_int, fp, fp]
+        L.vo_sam_process_mask.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.vo_sam_process_mask.restype = None
+        L.vo_sam_compute.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_void_p, fp, fp]
+        L._sam_ready = True
+    return L
+
+
+def sam_process_prompt(prompt, image_w: int, image_h: int, image_size: int = 1024) -> np.ndarray:
+    """pixel point (x, y) or box (x0, y0, x1, y1) of the original image -> [-1, 1] coordinates"""
+    p = (C.c_int * len(prompt))(*[int(v) for v in prompt])
+    out = np.zeros(4, np.float32)
+    _sam_lib().vo_sam_process_prompt(p, len(prompt), image_w, image_h, image_size, _fp(out))
+    return out
+
+
+def sam_embed_prompt(model: "Model", coords: np.ndarray, is_box: bool) -> np.ndarray:
+    c = _f32(coords)
+    out, dim = np.zeros((2, 512), np.float32), C.c_int()
+    _check(_sam_lib().vo_sam_embed_prompt(model._h, _fp(c), int(is_box), _fp(out), C.byref(dim)))
+    return out.reshape(-1)[: 2 * dim.value].reshape(2, dim.value).copy()
+
+
+def sam_predict_masks(model: "Model", embed: np.ndarray, sparse: np.ndarray):
+    """embed NHWC [res, res, dim], sparse [n, dim] -> masks [4, 4 res, 4 res], iou [4]"""
+    e, s = _f32(embed), _f32(sparse)
+    res, dim = e.shape[0], e.shape[2]
+    masks, iou = np.empty((4, 4 * res, 4 * res), np.float32), np.empty(4, np.float32)
+    _check(_sam_lib().vo_sam_predict_masks(model._h, _fp(e), res, dim, _fp(s), s.shape[0], _fp(masks), _fp(iou)))
+    return masks, iou
+
+
+def sam_process_mask(mask: np.ndarray, target_w: int, target_h: int, image_size: int = 1024) -> np.ndarray:
+    mk = _f32(mask)
+    out = np.empty((target_h, target_w), np.uint8)
+    _sam_lib().vo_sam_process_mask(_fp(mk), mk.shape[0], image_size, target_w, target_h, out.ctypes.data)
+    return out
+
+
+def sam_compute(model: "Model", embed: np.ndarray, image_w: int, image_h: int, prompt, return_all: bool = False):
+    """sam_compute after sam_encode: alpha_u8 mask [image_h, image_w] (+ iou [4], masks [4, 4 res, 4 res])"""
+    e = _f32(embed)
+    res, dim = e.shape[0], e.shape[2]
+    p = (C.c_int * len(prompt))(*[int(v) for v in prompt])
+    out = np.empty((image_h, image_w), np.uint8)
+    iou, masks = np.empty(4, np.float32), np.empty((4, 4 * res, 4 * res), np.float32)
+    _check(_sam_lib().vo_sam_compute(model._h, _fp(e), res, dim, image_w, image_h, p, len(prompt), out.ctypes.data, _fp(iou), _fp(masks)))
+    return (out, iou, masks) if return_all else out

@@ -1469,3 +1469,330 @@ int vo_tinyvit_encode(const vo_model* m, const char* prefix, const vo_tinyvit_pa
     free(n1);
     return 1;
 }
+
+/* ======================================================================================================================
+ * MobileSAM prompt encoder + mask decoder (sam_compute, reference src/visp/vision.cpp:54-84; arch/mobile-sam.cpp:207-531,
+ * 556-583). f32 throughout; torch twins: tests/test_mobile_sam.py:796-1470 (PromptEncoder, TwoWayTransformer, MaskDecoder).
+ * ====================================================================================================================== */
+
+/* sam::transform_coord / preprocess_point / preprocess_box (mobile-sam.cpp:213-236): pixel -> [-1, 1] */
+static float sam_transform_coord(int p, float scale, int image_size) {
+    float center_normalized = ((float)p * scale + 0.5f) / (float)image_size;
+    return 2.f * center_normalized - 1.f;
+}
+void vo_sam_process_prompt(const int* prompt, int n /* 2 = point, 4 = box */, int image_w, int image_h, int image_size, float out[4]) {
+    float scale = (float)image_size / (float)(image_w > image_h ? image_w : image_h);
+    out[0] = sam_transform_coord(prompt[0], scale, image_size);
+    out[1] = sam_transform_coord(prompt[1], scale, image_size);
+    out[2] = n == 4 ? sam_transform_coord(prompt[2], scale, image_size) : 0.f;
+    out[3] = n == 4 ? sam_transform_coord(prompt[3], scale, image_size) : 0.f;
+}
+
+/* position_embedding_random (mobile-sam.cpp:238-248): [sin | cos](2 pi * coords @ gaussian_matrix), coords already in [-1, 1] */
+static int sam_pe_random(const vo_model* m, const float* coords, int n, float* out, int* dim) {
+    int64_t ne[4];
+    const float* g = W(m, "prompt_encoder.pe_layer", "positional_encoding_gaussian_matrix", ne, 1); /* torch [2][F] */
+    if (!g) return 0;
+    int F = (int)ne[0];
+    *dim = 2 * F;
+    for (int i = 0; i < n; ++i)
+        for (int f = 0; f < F; ++f) {
+            float v = coords[2 * i] * g[f] + coords[2 * i + 1] * g[F + f];
+            v *= 2.f * 3.14159265358979323846f;
+            out[(int64_t)i * 2 * F + f] = sinf(v);
+            out[(int64_t)i * 2 * F + F + f] = cosf(v);
+        }
+    return 1;
+}
+
+/* embed_points (one foreground point + the sentinel, :250-267) / embed_box (:269-286) -> sparse prompt [2][dim] */
+int vo_sam_embed_prompt(const vo_model* m, const float coords[4], int is_box, float* out, int* dim) {
+    if (!sam_pe_random(m, coords, 2, out, dim)) return 0;
+    int D = *dim;
+    if (is_box) {
+        const float* c1 = W(m, "prompt_encoder", "point_embeddings.2.weight", NULL, 1);
+        const float* c2 = W(m, "prompt_encoder", "point_embeddings.3.weight", NULL, 1);
+        if (!c1 || !c2) return 0;
+        for (int c = 0; c < D; ++c) { out[c] += c1[c]; out[D + c] += c2[c]; }
+    } else {
+        const float* nap = W(m, "prompt_encoder", "not_a_point_embed.weight", NULL, 1);
+        const float* fg = W(m, "prompt_encoder", "point_embeddings.1.weight", NULL, 1);
+        if (!nap || !fg) return 0;
+        for (int c = 0; c < D; ++c) { out[D + c] = nap[c]; out[c] += fg[c]; }
+    }
+    return 1;
+}
+
+/* attention (nn.cpp:210-244) with different query / key counts: q [Nq][H*hd], k, v [Nk][H*hd] */
+static void sam_cross_attention(const float* q, int Nq, const float* k, const float* v, int Nk, int H, int hd, float* out) {
+    int C = H * hd;
+    float scale = 1.0f / sqrtf((float)hd);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int h = 0; h < H; ++h)
+        for (int i = 0; i < Nq; ++i) {
+            float* s = (float*)malloc((size_t)Nk * 4);
+            float mx = -INFINITY;
+            for (int j = 0; j < Nk; ++j) {
+                float acc = 0.f;
+                for (int d = 0; d < hd; ++d) acc = __builtin_fmaf(q[(int64_t)i * C + h * hd + d], k[(int64_t)j * C + h * hd + d], acc);
+                s[j] = acc * scale;
+                if (s[j] > mx) mx = s[j];
+            }
+            double sum = 0.0;
+            for (int j = 0; j < Nk; ++j) { s[j] = expf(s[j] - mx); sum += (double)s[j]; }
+            float inv = (float)(1.0 / sum);
+            for (int d = 0; d < hd; ++d) {
+                float acc = 0.f;
+                for (int j = 0; j < Nk; ++j) acc = __builtin_fmaf(s[j] * inv, v[(int64_t)j * C + h * hd + d], acc);
+                out[(int64_t)i * C + h * hd + d] = acc;
+            }
+            free(s);
+        }
+}
+
+/* decoder_attention (mobile-sam.cpp:306-320): q/k/v projections, heads, attention, out_proj. Returns a new [Nq][dim] buffer. */
+static float* sam_decoder_attention(const vo_model* m, const char* prefix, const float* q, int Nq, const float* k, const float* v, int Nk,
+                                    int dim, int heads) {
+    char p[200];
+    float *qp = NULL, *kp = NULL, *vp = NULL, *o = NULL;
+    int di = 0, dk = 0, dv = 0, dout = 0;
+    snprintf(p, sizeof p, "%s.q_proj", prefix);
+    if (!tv_linear(m, p, q, Nq, dim, &di, &qp)) return NULL;
+    snprintf(p, sizeof p, "%s.k_proj", prefix);
+    if (!tv_linear(m, p, k, Nk, dim, &dk, &kp)) { free(qp); return NULL; }
+    snprintf(p, sizeof p, "%s.v_proj", prefix);
+    if (!tv_linear(m, p, v, Nk, dim, &dv, &vp)) { free(qp); free(kp); return NULL; }
+    float* a = (float*)malloc((size_t)Nq * di * 4);
+    sam_cross_attention(qp, Nq, kp, vp, Nk, heads, di / heads, a);
+    snprintf(p, sizeof p, "%s.out_proj", prefix);
+    int ok = tv_linear(m, p, a, Nq, di, &dout, &o);
+    free(qp); free(kp); free(vp); free(a);
+    return ok ? o : NULL;
+}
+
+static float* sam_add_new(const float* a, const float* b, int64_t n) {
+    float* y = (float*)malloc((size_t)n * 4);
+    for (int64_t i = 0; i < n; ++i) y[i] = a[i] + b[i];
+    return y;
+}
+static void sam_add_inplace(float* a, const float* b, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) a[i] += b[i];
+}
+static int sam_norm(const vo_model* m, const char* prefix, const char* name, float* x, int64_t M, int C) {
+    char p[200];
+    snprintf(p, sizeof p, "%s.%s", prefix, name);
+    return tv_layer_norm(m, p, x, M, C, 1e-5f, x);
+}
+
+/* two_way_attention_block (mobile-sam.cpp:322-364); queries [Nt][dim], keys [Nk][dim] updated in place */
+static int sam_two_way_block(const vo_model* m, const char* prefix, float* queries, int Nt, float* keys, int Nk, const float* query_pe,
+                             const float* key_pe, int dim, int heads, int skip_first_layer_pe) {
+    char p[200];
+    snprintf(p, sizeof p, "%s.self_attn", prefix);
+    if (skip_first_layer_pe) {
+        float* a = sam_decoder_attention(m, p, queries, Nt, queries, queries, Nt, dim, heads);
+        if (!a) return 0;
+        memcpy(queries, a, (size_t)Nt * dim * 4);
+        free(a);
+    } else {
+        float* q = sam_add_new(queries, query_pe, (int64_t)Nt * dim);
+        float* a = sam_decoder_attention(m, p, q, Nt, q, queries, Nt, dim, heads);
+        free(q);
+        if (!a) return 0;
+        sam_add_inplace(queries, a, (int64_t)Nt * dim);
+        free(a);
+    }
+    if (!sam_norm(m, prefix, "norm1", queries, Nt, dim)) return 0;
+    /* tokens attending to the image embedding */
+    float* q = sam_add_new(queries, query_pe, (int64_t)Nt * dim);
+    float* k = sam_add_new(keys, key_pe, (int64_t)Nk * dim);
+    snprintf(p, sizeof p, "%s.cross_attn_t2i", prefix);
+    float* a = sam_decoder_attention(m, p, q, Nt, k, keys, Nk, dim, heads);
+    free(q);
+    if (!a) { free(k); return 0; }
+    sam_add_inplace(queries, a, (int64_t)Nt * dim);
+    free(a);
+    if (!sam_norm(m, prefix, "norm2", queries, Nt, dim)) { free(k); return 0; }
+    /* mlp_block: lin1, relu, lin2 (:294-299) */
+    float *h1 = NULL, *h2 = NULL;
+    int hid = 0, dout = 0;
+    snprintf(p, sizeof p, "%s.mlp.lin1", prefix);
+    if (!tv_linear(m, p, queries, Nt, dim, &hid, &h1)) { free(k); return 0; }
+    for (int64_t i = 0; i < (int64_t)Nt * hid; ++i) h1[i] = h1[i] > 0.f ? h1[i] : 0.f;
+    snprintf(p, sizeof p, "%s.mlp.lin2", prefix);
+    if (!tv_linear(m, p, h1, Nt, hid, &dout, &h2)) { free(h1); free(k); return 0; }
+    sam_add_inplace(queries, h2, (int64_t)Nt * dim);
+    free(h1); free(h2);
+    if (!sam_norm(m, prefix, "norm3", queries, Nt, dim)) { free(k); return 0; }
+    /* image embedding attending to the tokens; k = keys + key_pe from above */
+    q = sam_add_new(queries, query_pe, (int64_t)Nt * dim);
+    snprintf(p, sizeof p, "%s.cross_attn_i2t", prefix);
+    a = sam_decoder_attention(m, p, k, Nk, q, queries, Nt, dim, heads);
+    free(q); free(k);
+    if (!a) return 0;
+    sam_add_inplace(keys, a, (int64_t)Nk * dim);
+    free(a);
+    return sam_norm(m, prefix, "norm4", keys, Nk, dim);
+}
+
+/* hypernetwork_mlp (:406-415): linear (+ relu except after the last) */
+static float* sam_hyper_mlp(const vo_model* m, const char* prefix, const float* x, int dim, int n_layers, int* out_dim) {
+    float* cur = (float*)malloc((size_t)dim * 4);
+    memcpy(cur, x, (size_t)dim * 4);
+    int d = dim;
+    for (int i = 0; i < n_layers; ++i) {
+        char p[200];
+        snprintf(p, sizeof p, "%s.layers.%d", prefix, i);
+        float* y = NULL;
+        int n = 0;
+        if (!tv_linear(m, p, cur, 1, d, &n, &y)) { free(cur); return NULL; }
+        if (i < n_layers - 1) for (int c = 0; c < n; ++c) y[c] = y[c] > 0.f ? y[c] : 0.f;
+        free(cur);
+        cur = y;
+        d = n;
+    }
+    *out_dim = d;
+    return cur;
+}
+
+/* predict_masks (mobile-sam.cpp:417-483) with dense prompt = no_mask_embed (sam_predict_mask :600-605).
+ * embed: image embedding NHWC [res][res][dim]; sparse [n_sparse][dim] -> masks [4][(4 res)^2], iou [4] */
+int vo_sam_predict_masks(const vo_model* m, const float* embed, int res, int dim, const float* sparse, int n_sparse, float* masks, float* iou) {
+    const int heads = 8, depth = 2, n_mask = 4;
+    const float* iou_token = W(m, "dec", "iou_token.weight", NULL, 1);
+    const float* mask_tokens = W(m, "dec", "mask_tokens.weight", NULL, 1);
+    const float* no_mask = W(m, "prompt_encoder", "no_mask_embed.weight", NULL, 1);
+    int64_t pe_ne[4];
+    const float* image_pe = W(m, "dec", "dense_positional_embedding", pe_ne, 1);
+    if (!iou_token || !mask_tokens || !no_mask || !image_pe) return 0;
+    const int Nk = res * res, Nt = 1 + n_mask + n_sparse;
+    if (pe_ne[0] != dim || pe_ne[1] * pe_ne[2] != Nk) VO_FAIL("dense_positional_embedding has the wrong shape");
+    float* tokens = (float*)malloc((size_t)Nt * dim * 4);
+    memcpy(tokens, iou_token, (size_t)dim * 4);
+    memcpy(tokens + dim, mask_tokens, (size_t)n_mask * dim * 4);
+    memcpy(tokens + (size_t)(1 + n_mask) * dim, sparse, (size_t)n_sparse * dim * 4);
+    float* keys = (float*)malloc((size_t)Nk * dim * 4);
+    for (int64_t i = 0; i < Nk; ++i)
+        for (int c = 0; c < dim; ++c) keys[i * dim + c] = embed[i * dim + c] + no_mask[c];
+    float* queries = (float*)malloc((size_t)Nt * dim * 4);
+    memcpy(queries, tokens, (size_t)Nt * dim * 4);
+    int ok = 1;
+    for (int i = 0; i < depth && ok; ++i) { /* two_way_transformer :366-394 */
+        char p[64];
+        snprintf(p, sizeof p, "dec.transformer.layers.%d", i);
+        ok = sam_two_way_block(m, p, queries, Nt, keys, Nk, tokens, image_pe, dim, heads, i == 0);
+    }
+    if (ok) {
+        float* q = sam_add_new(queries, tokens, (int64_t)Nt * dim);
+        float* k = sam_add_new(keys, image_pe, (int64_t)Nk * dim);
+        float* a = sam_decoder_attention(m, "dec.transformer.final_attn_t2i", q, Nt, k, keys, Nk, dim, heads);
+        free(q); free(k);
+        ok = a != NULL;
+        if (ok) {
+            sam_add_inplace(queries, a, (int64_t)Nt * dim);
+            free(a);
+            ok = sam_norm(m, "dec.transformer", "norm_final_attn", queries, Nt, dim);
+        }
+    }
+    float *up1 = NULL, *up2 = NULL;
+    int c1 = 0, c2 = 0;
+    if (ok) { /* upscale_outputs :396-404: convT k2 s2, LayerNorm (eps 1e-5, nn.cpp:14-19), GELU, convT k2 s2, GELU */
+        int64_t ne[4];
+        const float* w0 = W(m, "dec.output_upscaling.0", "weight", ne, 1);
+        const float* w3 = W(m, "dec.output_upscaling.3", "weight", NULL, 1);
+        ok = w0 && w3;
+        if (ok) {
+            c1 = (int)ne[2];
+            up1 = (float*)malloc((size_t)4 * Nk * c1 * 4);
+            vo_conv_transpose2d_nhwc(keys, 1, res, res, dim, w0, W(m, "dec.output_upscaling.0", "bias", NULL, 0), c1, 2, 2, 2, up1);
+            ok = tv_layer_norm(m, "dec.output_upscaling.1", up1, (int64_t)4 * Nk, c1, 1e-5f, up1);
+            if (ok) {
+                gelu_inplace(up1, (int64_t)4 * Nk * c1);
+                int64_t ne3[4];
+                W(m, "dec.output_upscaling.3", "weight", ne3, 1);
+                c2 = (int)ne3[2];
+                up2 = (float*)malloc((size_t)16 * Nk * c2 * 4);
+                vo_conv_transpose2d_nhwc(up1, 1, 2 * res, 2 * res, c1, w3, W(m, "dec.output_upscaling.3", "bias", NULL, 0), c2, 2, 2, 2, up2);
+                gelu_inplace(up2, (int64_t)16 * Nk * c2);
+            }
+        }
+    }
+    if (ok) {
+        const int64_t P = (int64_t)16 * Nk;
+        for (int i = 0; i < n_mask && ok; ++i) {
+            char p[64];
+            snprintf(p, sizeof p, "dec.output_hypernetworks_mlps.%d", i);
+            int od = 0;
+            float* hy = sam_hyper_mlp(m, p, queries + (size_t)(1 + i) * dim, dim, 3, &od);
+            ok = hy != NULL && od == c2;
+            if (ok) {
+#pragma omp parallel for schedule(static)
+                for (int64_t px = 0; px < P; ++px) {
+                    float acc = 0.f;
+                    for (int c = 0; c < c2; ++c) acc = __builtin_fmaf(up2[px * c2 + c], hy[c], acc);
+                    masks[(int64_t)i * P + px] = acc;
+                }
+            }
+            free(hy);
+        }
+        if (ok) {
+            int od = 0;
+            float* q = sam_hyper_mlp(m, "dec.iou_prediction_head", queries, dim, 3, &od);
+            ok = q != NULL && od == n_mask;
+            if (ok) memcpy(iou, q, (size_t)n_mask * 4);
+            free(q);
+        }
+    }
+    free(tokens); free(keys); free(queries); free(up1); free(up2);
+    return ok;
+}
+
+/* sam::interpolate_bilinear (mobile-sam.cpp:485-516): half-pixel centres, source clamped at 0 and extent - 1 */
+static void sam_interp(const float* src, int sw, int sh, int sstride, float* dst_f, uint8_t* dst_u8, int dw, int dh, int dstride) {
+    float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            float sxf = fmaxf(((float)x + 0.5f) * scale_x - 0.5f, 0.0f), syf = fmaxf(((float)y + 0.5f) * scale_y - 0.5f, 0.0f);
+            int x0 = (int)sxf, y0 = (int)syf;
+            int x1 = x0 + 1 < sw - 1 ? x0 + 1 : sw - 1, y1 = y0 + 1 < sh - 1 ? y0 + 1 : sh - 1;
+            float v00 = src[y0 * sstride + x0], v01 = src[y0 * sstride + x1], v10 = src[y1 * sstride + x0], v11 = src[y1 * sstride + x1];
+            float wx = sxf - (float)x0, wy = syf - (float)y0;
+            float v0 = (1 - wx) * v00 + wx * v01, v1 = (1 - wx) * v10 + wx * v11;
+            float v = (1 - wy) * v0 + wy * v1;
+            if (dst_f) dst_f[y * dstride + x] = v;
+            else dst_u8[y * dstride + x] = (uint8_t)(v > 0.0f ? 255 : 0);
+        }
+}
+
+/* sam_process_mask (mobile-sam.cpp:556-583): mask [mask_size^2] -> image_size^2 -> crop to the scaled extent -> target, threshold 0 */
+void vo_sam_process_mask(const float* mask, int mask_size, int image_size, int target_w, int target_h, uint8_t* out) {
+    float scale = (float)image_size / (float)(target_w > target_h ? target_w : target_h);
+    int sw = (int)((float)target_w * scale + 0.5f), sh = (int)((float)target_h * scale + 0.5f);
+    float* scaled = (float*)malloc((size_t)image_size * image_size * 4);
+    sam_interp(mask, mask_size, mask_size, mask_size, scaled, NULL, image_size, image_size, image_size);
+    sam_interp(scaled, sw, sh, image_size, NULL, out, target_w, target_h, target_w);
+    free(scaled);
+}
+
+/* sam_compute_impl (vision.cpp:54-84) after sam_encode: prompt in pixels of the original image (2 = point, 4 = box) */
+int vo_sam_compute(const vo_model* m, const float* embed, int res, int dim, int image_w, int image_h, const int* prompt, int n_prompt,
+                   uint8_t* out_mask, float* iou_out, float* masks_out) {
+    if (n_prompt != 2 && n_prompt != 4) VO_FAIL("sam: bad number of arguments (%d), must be 2 or 4", n_prompt);
+    const int image_size = 16 * res, mask_size = 4 * res;
+    float coords[4], sparse[2 * 512], iou[4];
+    int pd = 0;
+    vo_sam_process_prompt(prompt, n_prompt, image_w, image_h, image_size, coords);
+    if (!vo_sam_embed_prompt(m, coords, n_prompt == 4, sparse, &pd)) return 0;
+    if (pd != dim) VO_FAIL("sam: prompt embedding has %d channels, image embedding %d", pd, dim);
+    float* masks = (float*)malloc((size_t)4 * mask_size * mask_size * 4);
+    int ok = vo_sam_predict_masks(m, embed, res, dim, sparse, 2, masks, iou);
+    if (ok) {
+        int idx = 0;
+        for (int i = 1; i < 3; ++i) if (iou[i] > iou[idx]) idx = i; /* max_element over the first three (vision.cpp:80-82) */
+        vo_sam_process_mask(masks + (size_t)idx * mask_size * mask_size, mask_size, image_size, image_w, image_h, out_mask);
+        if (iou_out) memcpy(iou_out, iou, sizeof iou);
+        if (masks_out) memcpy(masks_out, masks, (size_t)4 * mask_size * mask_size * 4);
+    }
+    free(masks);
+    return ok;
+}

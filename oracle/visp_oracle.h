@@ -182,6 +182,18 @@ int vo_attention_rel_bias(const vo_model*, const char* prefix, const float* x, i
 /* conv_2d_depthwise + bias on NHWC (nn.cpp:102-115); weight [C][1][kw][kh] after transfer */
 void vo_conv2d_depthwise_nhwc(const float* x, int H, int W, int C, const float* w, const float* bias, int k, int stride, int pad, float* y);
 
+/* ---- MobileSAM prompt encoder + mask decoder (sam_compute: vision.cpp:54-84, mobile-sam.cpp:207-531, 556-583) ---- */
+/* pixel prompt of the original image (n = 2 point, 4 box) -> [-1, 1] coordinates (preprocess_point / preprocess_box) */
+void vo_sam_process_prompt(const int* prompt, int n, int image_w, int image_h, int image_size, float out[4]);
+/* embed_points (point + sentinel) / embed_box -> sparse prompt [2][dim] */
+int vo_sam_embed_prompt(const vo_model*, const float coords[4], int is_box, float* out, int* dim);
+/* predict_masks with the no-mask dense prompt: embed NHWC [res][res][dim], sparse [n][dim] -> masks [4][(4 res)^2], iou [4] */
+int vo_sam_predict_masks(const vo_model*, const float* embed, int res, int dim, const float* sparse, int n_sparse, float* masks, float* iou);
+void vo_sam_process_mask(const float* mask, int mask_size, int image_size, int target_w, int target_h, uint8_t* out);
+/* whole sam_compute after sam_encode; out_mask alpha_u8 [image_h][image_w]; iou_out [4] and masks_out [4][(4 res)^2] optional */
+int vo_sam_compute(const vo_model*, const float* embed, int res, int dim, int image_w, int image_h, const int* prompt, int n_prompt,
+                   uint8_t* out_mask, float* iou_out, float* masks_out);
+
 /* dino building blocks, exposed for module-level parity tests */
 int vo_dino_layer(const vo_model*, const char* prefix, int n_heads, int gelu_mode, float* x /*[N][C] in/out*/,
                   int64_t N, int64_t C);

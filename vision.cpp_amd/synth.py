@@ -406,3 +406,112 @@ def write_tinyvit_gguf(path: str | Path, cfg: TinyVitConfig = TINYVIT_5M, seed: 
         w.add_tensor(name, t)
     w.write()
     return Path(path)
+
+
+# ---- MobileSAM prompt encoder + mask decoder (reference tests/test_mobile_sam.py:796-1470, scripts/convert.py:204-282) ----
+
+def sam_decoder_state_dict(seed: int = 0, dim: int = 256, heads: int = 8, mlp_dim: int = 2048, depth: int = 2) -> dict[str, np.ndarray]:
+    """float32 tensors under the names of a SAM checkpoint (prompt_encoder.*, mask_decoder.*); mask_downscaling is never read
+    by the reference's graph and is left out."""
+    rng = np.random.default_rng(seed)
+    sd: dict[str, np.ndarray] = {}
+
+    def linear(name, n, k, gain=1.0):
+        sd[f"{name}.weight"] = (rng.standard_normal((n, k)) * gain / np.sqrt(k)).astype(np.float32)
+        sd[f"{name}.bias"] = (0.02 * rng.standard_normal(n)).astype(np.float32)
+
+    def norm(name, c):
+        sd[f"{name}.weight"] = (1 + 0.05 * rng.standard_normal(c)).astype(np.float32)
+        sd[f"{name}.bias"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+
+    def attention(name, internal):
+        for pj in ("q_proj", "k_proj", "v_proj"):
+            linear(f"{name}.{pj}", internal, dim)
+        linear(f"{name}.out_proj", dim, internal, gain=0.7)
+
+    pe = "prompt_encoder"
+    sd[f"{pe}.pe_layer.positional_encoding_gaussian_matrix"] = rng.standard_normal((2, dim // 2)).astype(np.float32)
+    for i in range(4):
+        sd[f"{pe}.point_embeddings.{i}.weight"] = (0.5 * rng.standard_normal((1, dim))).astype(np.float32)
+    sd[f"{pe}.not_a_point_embed.weight"] = (0.5 * rng.standard_normal((1, dim))).astype(np.float32)
+    sd[f"{pe}.no_mask_embed.weight"] = (0.2 * rng.standard_normal((1, dim))).astype(np.float32)
+    md = "mask_decoder"
+    for i in range(depth):
+        p = f"{md}.transformer.layers.{i}"
+        attention(f"{p}.self_attn", dim)
+        norm(f"{p}.norm1", dim)
+        attention(f"{p}.cross_attn_token_to_image", dim // 2)
+        norm(f"{p}.norm2", dim)
+        linear(f"{p}.mlp.lin1", mlp_dim, dim)
+        linear(f"{p}.mlp.lin2", dim, mlp_dim, gain=0.7)
+        norm(f"{p}.norm3", dim)
+        norm(f"{p}.norm4", dim)
+        attention(f"{p}.cross_attn_image_to_token", dim // 2)
+    attention(f"{md}.transformer.final_attn_token_to_image", dim // 2)
+    norm(f"{md}.transformer.norm_final_attn", dim)
+    sd[f"{md}.iou_token.weight"] = rng.standard_normal((1, dim)).astype(np.float32)
+    sd[f"{md}.mask_tokens.weight"] = rng.standard_normal((4, dim)).astype(np.float32)
+    sd[f"{md}.output_upscaling.0.weight"] = (rng.standard_normal((dim, dim // 4, 2, 2)) / np.sqrt(dim)).astype(np.float32)
+    sd[f"{md}.output_upscaling.0.bias"] = (0.02 * rng.standard_normal(dim // 4)).astype(np.float32)
+    norm(f"{md}.output_upscaling.1", dim // 4)
+    sd[f"{md}.output_upscaling.3.weight"] = (rng.standard_normal((dim // 4, dim // 8, 2, 2)) / np.sqrt(dim // 4)).astype(np.float32)
+    sd[f"{md}.output_upscaling.3.bias"] = (0.02 * rng.standard_normal(dim // 8)).astype(np.float32)
+    for i in range(4):
+        p = f"{md}.output_hypernetworks_mlps.{i}.layers"
+        linear(f"{p}.0", dim, dim)
+        linear(f"{p}.1", dim, dim)
+        linear(f"{p}.2", dim // 8, dim)
+    p = f"{md}.iou_prediction_head.layers"
+    linear(f"{p}.0", 256, dim)
+    linear(f"{p}.1", 256, 256)
+    linear(f"{p}.2", 4, 256)
+    return sd
+
+
+def sam_dense_positional_embedding(gaussian: np.ndarray, size: int = 64) -> np.ndarray:
+    """build_dense_positional_embeddings (scripts/convert.py:265-282): [size, size, 2F] float32, (h, w, c) order."""
+    g = np.asarray(gaussian, np.float32)
+    centre = ((np.arange(size, dtype=np.float32) + np.float32(1) - np.float32(0.5)) / np.float32(size)).astype(np.float32)
+    coords = np.stack(np.broadcast_arrays(centre[None, :], centre[:, None]), axis=-1).astype(np.float32)  # (x, y) per (h, w)
+    coords = np.float32(2) * coords - np.float32(1)
+    proj = (np.float32(2 * np.pi) * (coords @ g)).astype(np.float32)
+    return np.concatenate([np.sin(proj), np.cos(proj)], axis=-1).astype(np.float32)
+
+
+def sam_decoder_gguf_tensors(sd: dict[str, np.ndarray]) -> dict[str, np.ndarray]:
+    """convert_sam's rules for everything outside the image encoder (scripts/convert.py:210-247): mask_decoder. -> dec.,
+    _token_to_image / _image_to_token -> _t2i / _i2t, the dense positional embedding precomputed (f32), iou / mask tokens f32,
+    everything else f16."""
+    out: dict[str, np.ndarray] = {}
+    for key, t in sd.items():
+        name = key.replace("mask_decoder.", "dec.").replace("_image_to_token.", "_i2t.").replace("_token_to_image.", "_t2i.")
+        if key == "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix":
+            out["dec.dense_positional_embedding"] = sam_dense_positional_embedding(t)
+        if name in ("dec.iou_token.weight", "dec.mask_tokens.weight"):
+            out[name] = t.astype(np.float32)
+            continue
+        out[name] = t.astype(np.float16)
+    return out
+
+
+def mobile_sam_gguf_tensors(enc_sd: dict[str, np.ndarray], dec_sd: dict[str, np.ndarray]):
+    tensors, conv2d = tinyvit_gguf_tensors(enc_sd)
+    tensors.update(sam_decoder_gguf_tensors(dec_sd))
+    return tensors, conv2d
+
+
+def write_mobile_sam_gguf(path: str | Path, cfg: TinyVitConfig = TINYVIT_5M, seed: int = 0, enc_sd=None, dec_sd=None) -> Path:
+    """The whole MobileSAM file: image encoder + prompt encoder + mask decoder."""
+    enc_sd = enc_sd if enc_sd is not None else tinyvit_state_dict(cfg, seed)
+    dec_sd = dec_sd if dec_sd is not None else sam_decoder_state_dict(seed + 1000)
+    tensors, conv2d = mobile_sam_gguf_tensors(enc_sd, dec_sd)
+    w = GGUFWriter(path, "mobile-sam")
+    w.add_string("mobile-sam.tensor_data_layout", "whcn")
+    w.add_uint32("general.quantization_version", 2)
+    w.add_uint32("general.file_type", 1)
+    if conv2d:
+        w.add_array_i32("mobile-sam.conv2d_weights", conv2d)
+    for name, t in tensors.items():
+        w.add_tensor(name, t)
+    w.write()
+    return Path(path)
