@@ -140,13 +140,18 @@ VISP_API int32_t visp_esrgan_generate_host(visp_model* m, float const* rgb, int3
 VISP_API int32_t visp_esrgan_enable_timing(visp_model* m, int32_t enable);
 VISP_API int32_t visp_esrgan_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
 
-/* ---- MobileSAM image encoder extension (family 0; reference vision.h:186-222, vision.cpp:26-52, mobile-sam.cpp:20-215) ----
- * visp_model_load reads the `enc.*` tensors of a mobile-sam GGUF. sam_compute (prompt encoder + mask decoder) is not
- * built yet: visp_model_compute fails for this family. */
+/* ---- MobileSAM extension (family 0; reference vision.h:186-222, vision.cpp:26-92, mobile-sam.cpp) ----
+ * visp_model_load / visp_model_compute work as in the reference: one image + 2 (point) or 4 (box) integer arguments in
+ * pixels of that image -> alpha_u8 mask at the image's extent (sam_encode + sam_compute, c-api.cpp:34-52). A file
+ * with only the enc.* tensors loads too; sam_compute then fails. */
 /* sam_encode: any extent / u8 colour format; the embedding is kept on the device with the model */
 VISP_API int32_t visp_sam_encode(visp_model* m, visp_image_view const* image);
 /* embedding of the last visp_sam_encode: f32 [64, 64, 256] (rows, columns, channels), shape returned via shape[3] */
 VISP_API int32_t visp_sam_read_embedding(visp_model* m, float* host_out, int64_t capacity, int64_t shape[3]);
+/* sam_compute on the embedding of the last visp_sam_encode (several prompts per image, vision.cpp:54-92) */
+VISP_API int32_t visp_sam_compute(visp_model* m, int32_t const* prompt, int32_t n_prompt, visp_image_view* out_image, visp_image_data** out_data);
+/* test hook: mask logits [4][256][256] (f16-rounded) and iou predictions [4] of the last sam_compute */
+VISP_API int32_t visp_sam_read_masks(visp_model* m, float* masks, int64_t capacity, float iou[4]);
 /* rgb: u8 [B, 1024, 1024, 3] already at the model extent -> out f32 [B, 64, 64, 256]; device pointers;
  * stream = hipStream_t or NULL (NULL: the device's stream, synchronised before returning) */
 VISP_API int32_t visp_sam_encode_batch_device(visp_model* m, void const* rgb, int32_t batch, void* out, void* stream);

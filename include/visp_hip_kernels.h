@@ -180,6 +180,11 @@ VX_API int vx_window_attention_pack_bias(const float* bias_host, int N, int head
 VX_API int vx_window_attention_f16(const void* qkv, const void* bias_packed, void* out, int n_windows, int N, int heads, void* stream);
 /* window_reverse + residual: y[b,py,px,:] = x[b,py,px,:] + a[window row of (py,px),:] (mobile-sam.cpp:48-64, 146-149) */
 VX_API int vx_window_reverse_add_f16(const void* a, const void* x, void* y, int B, int res, int ws, int C, void* stream);
+/* y f16 = a + b[i mod b_period]; a f16 or f32 (SAM decoder: queries + query_pe, keys + key_pe, embedding + no_mask_embed) */
+VX_API int vx_add_rows_f16(const void* a, int a_is_f32, const void* b, int64_t b_period, void* y, int64_t n, void* stream);
+/* attention with few queries or few keys (SAM mask decoder, mobile-sam.cpp:306-320): q [Nq][heads*hd], k, v [Nk][heads*hd]
+ * -> out [Nq][heads*hd]; hd in {8, 16, 32}, Nk <= 4096; scale = 1/sqrt(hd) */
+VX_API int vx_small_attention_f16(const void* q, const void* k, const void* v, void* out, int Nq, int Nk, int heads, int hd, void* stream);
 /* y = gelu(a + b), b nullable (mb_conv tail, mobile-sam.cpp:88-90) */
 VX_API int vx_add_gelu_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
 

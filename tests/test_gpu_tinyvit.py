@@ -259,8 +259,10 @@ def test_sam_encode_pads_by_edge_replication(sam):
 def test_sam_errors(sam, tmp_path):
     from visioncpp_amd import _lib as L, synth, vision
     m = sam["model"]
-    with pytest.raises(L.Error, match="sam_compute"):
-        m.compute(sam["imgs"][0][:64, :64])
+    with pytest.raises(L.Error, match="no prompt encoder / mask decoder"):   # encoder-only file
+        m.compute(sam["imgs"][0][:64, :64], args=[10, 10])
+    with pytest.raises(L.Error, match="must be 2 or 4"):
+        m.compute(sam["imgs"][0][:64, :64], args=[10, 10, 3])
     fresh = vision.Model.load(synth.write_tinyvit_gguf(tmp_path / "t.gguf", sam["cfg"], seed=1), m._device)
     with pytest.raises(L.Error, match="call sam_encode"):
         out = np.empty((64, 64, 256), np.float32)
@@ -271,3 +273,117 @@ def test_sam_errors(sam, tmp_path):
     del sd["layers.2.blocks.3.mlp.fc1.weight"]
     with pytest.raises(L.Error, match="fc1"):
         vision.Model.load(synth.write_tinyvit_gguf(tmp_path / "broken.gguf", sam["cfg"], sd=sd), m._device)
+
+
+# ---- prompt encoder + mask decoder (sam_compute) ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("Nq,Nk,heads,hd", [(7, 4096, 8, 16), (4096, 7, 8, 16), (7, 7, 8, 32), (3, 100, 2, 8)])
+def test_small_attention(Nq, Nk, heads, hd):
+    from tests import gpu_util as G
+    from visioncpp_amd import _lib as L
+    rng = np.random.default_rng(Nq + Nk)
+    Cc = heads * hd
+    q, k, v = (_h(rng.standard_normal((n, Cc))) for n in (Nq, Nk, Nk))
+    out = G.empty(Nq * Cc * 2)
+    L.vx_check(G.api().vx_small_attention_f16(G.dev(q.astype(np.float16)).ptr, G.dev(k.astype(np.float16)).ptr, G.dev(v.astype(np.float16)).ptr,
+                                              out.ptr, Nq, Nk, heads, hd, None))
+    G.sync()
+    qh, kh, vh = (a.reshape(-1, heads, hd).transpose(1, 0, 2) for a in (q, k, v))
+    s = qh @ kh.transpose(0, 2, 1) / np.sqrt(hd)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ vh).transpose(1, 0, 2).reshape(Nq, Cc)
+    np.testing.assert_allclose(out.to_numpy(np.float16, (Nq, Cc)).astype(np.float32), ref, atol=3e-3, rtol=3e-3)
+
+
+def test_add_rows():
+    from tests import gpu_util as G
+    from visioncpp_amd import _lib as L
+    rng = np.random.default_rng(1)
+    a32 = rng.standard_normal((40, 64)).astype(np.float32)
+    b = _h(rng.standard_normal(64))
+    out = G.empty(40 * 64 * 2)
+    L.vx_check(G.api().vx_add_rows_f16(G.dev(a32).ptr, 1, G.dev(b.astype(np.float16)).ptr, 64, out.ptr, 40 * 64, None))
+    G.sync()
+    np.testing.assert_allclose(out.to_numpy(np.float16, (40, 64)).astype(np.float32), _h(a32 + b), atol=1e-3)
+    a16 = _h(a32)
+    L.vx_check(G.api().vx_add_rows_f16(G.dev(a16.astype(np.float16)).ptr, 0, G.dev(a16[::-1].astype(np.float16).copy()).ptr, 40 * 64, out.ptr, 40 * 64, None))
+    G.sync()
+    np.testing.assert_allclose(out.to_numpy(np.float16, (40, 64)).astype(np.float32), _h(a16 + a16[::-1]), atol=1e-3)
+
+
+@pytest.fixture(scope="module")
+def sam_full(tmp_path_factory):
+    """The whole MobileSAM file (encoder seed 2 + decoder seed 11 = the two torch-pinned fixtures) and its oracle twin."""
+    from visioncpp_amd import synth, vision
+    cfg = synth.TINYVIT_5M
+    enc_sd, dec_sd = synth.tinyvit_state_dict(cfg, 2), synth.sam_decoder_state_dict(11)
+    path = synth.write_mobile_sam_gguf(tmp_path_factory.mktemp("samfull") / "mobile_sam.gguf", cfg, enc_sd=enc_sd, dec_sd=dec_sd)
+    dev = vision.Device.init(vision.Backend.gpu)
+    model = vision.Model.load(path, dev)
+    tensors, conv2d = synth.mobile_sam_gguf_tensors(enc_sd, dec_sd)
+    yield dict(model=model, om=O.Model(tensors, conv2d, "whcn"), cfg=cfg)
+    del model, dev
+
+
+def _iou(a, b):
+    a, b = a > 0, b > 0
+    return (a & b).sum() / max(1, (a | b).sum())
+
+
+@pytest.mark.parametrize("prompt", [[700, 300], [200, 120, 640, 900]])
+def test_decoder_matches_oracle_on_the_same_embedding(sam_full, prompt):
+    """sam_compute from ONE embedding on both sides (the GPU's own, read back): isolates the decoder. f16 activations against
+    the f32 oracle: mask logits within 2 % of their scale, iou predictions within 0.02, final u8 masks differ on < 0.5 % of
+    the pixels (only where a logit is within rounding of 0)."""
+    from visioncpp_amd import synth
+    m = sam_full["model"]
+    img = synth.images(1, 1024, 1024, seed=31)[0]
+    embed = m.sam_encode(img)
+    got = m.sam_compute(prompt)
+    masks, iou = m.sam_read_masks()
+    want, wiou, wmasks = O.sam_compute(sam_full["om"], embed, 1024, 1024, prompt, return_all=True)
+    scale = np.abs(wmasks).mean()
+    err = np.abs(masks - wmasks)
+    assert err.mean() < 0.02 * scale and err.max() < 0.25 * max(1.0, np.abs(wmasks).max()), (err.mean(), err.max(), scale)
+    np.testing.assert_allclose(iou, wiou, atol=0.02)
+    assert got.shape == want.shape == (1024, 1024) and set(np.unique(got)) <= {0, 255}
+    if int(np.argmax(iou[:3])) == int(np.argmax(wiou[:3])):
+        assert (got != want).mean() < 5e-3 and _iou(got, want) > 0.99, ((got != want).mean(), _iou(got, want))
+
+
+def test_model_compute_is_encode_plus_compute(sam_full):
+    """visp_model_compute for family sam (c-api.cpp:34-52) on a non-square bgra image with a point and with a box; the whole
+    pipeline (encoder + decoder) against the oracle's."""
+    from visioncpp_amd import synth, vision
+    m = sam_full["model"]
+    img = synth.images(1, 640, 480, seed=8)[0]          # [480, 640, 3]
+    via_compute = m.compute(img, args=[320, 200])
+    m.sam_encode(img)
+    assert np.array_equal(via_compute, m.sam_compute([320, 200]))
+    box = m.sam_compute([100, 80, 500, 400])
+    assert box.shape == (480, 640) and set(np.unique(box)) <= {0, 255}
+    bgra = np.concatenate([img[..., ::-1], np.full(img.shape[:2] + (1,), 255, np.uint8)], axis=-1)
+    assert np.array_equal(m.compute(bgra, vision.ImageFormat.bgra_u8, args=[320, 200]), via_compute)
+    # oracle end to end: same preprocessing as sam_process_input when the longest side is already 1024
+    big = synth.images(1, 1024, 768, seed=9)[0]         # [768, 1024, 3]
+    got = m.compute(big, args=[500, 300])
+    sq = np.pad(big, ((0, 256), (0, 0), (0, 0)), mode="edge").astype(np.float32) / np.float32(255.0)
+    x = (sq - MEAN) / STD
+    cfg = sam_full["cfg"]
+    emb = O.tinyvit_encode(sam_full["om"], O.tinyvit_params(cfg.img_size, cfg.layers()), x)
+    want, wiou, _ = O.sam_compute(sam_full["om"], emb, 1024, 768, [500, 300], return_all=True)
+    _, iou = m.sam_read_masks()
+    np.testing.assert_allclose(iou, wiou, atol=0.03)
+    if int(np.argmax(iou[:3])) == int(np.argmax(wiou[:3])):
+        assert (got != want).mean() < 0.01 and _iou(got, want) > 0.98, ((got != want).mean(), _iou(got, want))
+
+
+def test_sam_compute_errors(sam_full, tmp_path):
+    from visioncpp_amd import _lib as L, synth, vision
+    m = sam_full["model"]
+    fresh = vision.Model.load(synth.write_mobile_sam_gguf(tmp_path / "s.gguf", seed=4), m._device)
+    with pytest.raises(L.Error, match="call sam_encode"):
+        fresh.sam_compute([1, 2])
+    with pytest.raises(L.Error, match="must be 2 or 4"):
+        m.sam_compute([1, 2, 3])

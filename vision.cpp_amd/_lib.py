@@ -91,7 +91,7 @@ C_API_SYMBOLS = [
     "visp_esrgan_generate_host", "visp_esrgan_enable_timing", "visp_esrgan_read_timing",
     "visp_sam_encode", "visp_sam_read_embedding", "visp_sam_encode_batch_device", "visp_sam_encode_batch_host",
     "visp_sam_weights_arena", "visp_sam_weights_ready", "visp_sam_enable_timing", "visp_sam_read_timing",
-    "visp_sam_enable_captures", "visp_sam_read_capture",
+    "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks",
 ]
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
@@ -102,7 +102,7 @@ KERNEL_SYMBOLS = [
     "vx_layernorm_f32_f16", "vx_layernorm_resid_supported", "vx_layernorm_resid_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
     "vx_dconv3x3_f16", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
-    "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
+    "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
 ]
 
 
@@ -171,6 +171,8 @@ def init() -> ctypes.CDLL:
     lib.visp_sam_encode_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_void_p]
     lib.visp_sam_weights_arena.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]
     lib.visp_sam_weights_ready.argtypes = [c_void_p]
+    lib.visp_sam_compute.argtypes = [c_void_p, POINTER(c_int32), c_int32, POINTER(ImageView), POINTER(c_void_p)]
+    lib.visp_sam_read_masks.argtypes = [c_void_p, c_void_p, c_int64, POINTER(ctypes.c_float)]
     lib.visp_sam_enable_captures.argtypes = [c_void_p, c_int32]
     lib.visp_sam_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
     lib.visp_sam_enable_timing.argtypes = [c_void_p, c_int32]
@@ -216,6 +218,8 @@ def init() -> ctypes.CDLL:
     lib.vx_dwconv3x3_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_int, c_void_p]
     lib.vx_window_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.vx_add_rows_f16.argtypes = [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+    lib.vx_small_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_window_attention_bias_bytes.argtypes = [c_int, c_int]
     lib.vx_window_attention_bias_bytes.restype = c_size_t
     lib.vx_window_attention_pack_bias.argtypes = [c_void_p, c_int, c_int, c_void_p]

@@ -175,20 +175,24 @@ void visp_model_destroy(visp_model* model, int32_t arch) {
     else if (base->family == VISP_SAM) delete static_cast<sam_model*>(base);
 }
 
-int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* inputs, int32_t n_inputs, int32_t*, int32_t,
+int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* inputs, int32_t n_inputs, int32_t* args, int32_t n_args,
                            visp_image_view* out_image, visp_image_data** out_data) {
     return handle_errors([&]() {
         require_built(family);
         if (family_of(model) != family) throw except("model handle belongs to family %d, not %d", family_of(model), family);
-        if (family == VISP_SAM) // model_funcs<sam>::compute = sam_encode + sam_compute (reference c-api.cpp:34-52)
-            throw except("sam: the prompt encoder / mask decoder (sam_compute) are not built in this backend; the image encoder is "
-                         "available through visp_sam_encode / visp_sam_encode_batch_*");
         if (n_inputs != 1) throw except("Expected %d input images, but got %d.", 1, n_inputs);
         image_view in;
         in.extent = {{inputs[0].width, inputs[0].height}};
         in.stride = inputs[0].stride;
         in.format = image_format(inputs[0].format);
         in.data = inputs[0].data;
+        if (family == VISP_SAM) { // model_funcs<sam>::compute = sam_encode + sam_compute (reference c-api.cpp:34-52)
+            if (n_args != 2 && n_args != 4) throw except("sam: bad number of arguments (%d), must be 2 or 4", n_args);
+            sam_model& sm = as_sam(model);
+            sam_encode(sm, in);
+            return_image(sam_compute(sm, args, n_args), out_image, out_data);
+            return;
+        }
         if (family == VISP_ESRGAN) { // model_funcs<esrgan>::compute (reference c-api.cpp:103-106)
             return_image(esrgan_compute(as_esrgan(model), in), out_image, out_data);
             return;
@@ -419,6 +423,23 @@ int32_t visp_sam_read_embedding(visp_model* m, float* host_out, int64_t capacity
         if (capacity < (int64_t)R * R * 256) throw except("sam: embedding buffer too small (%lld < %d)", (long long)capacity, R * R * 256);
         if (!vx_memcpy_d2h(host_out, sm.embed.ptr, (size_t)R * R * 256 * 4, sm.backend->stream) || !vx_stream_sync(sm.backend->stream))
             throw except("%s", vx_last_error());
+    });
+}
+
+int32_t visp_sam_compute(visp_model* m, int32_t const* prompt, int32_t n_prompt, visp_image_view* out_image, visp_image_data** out_data) {
+    return handle_errors([&]() {
+        if (!prompt || !out_image || !out_data) throw except("sam: null argument");
+        return_image(sam_compute(as_sam(m), prompt, n_prompt), out_image, out_data);
+    });
+}
+
+int32_t visp_sam_read_masks(visp_model* m, float* masks, int64_t capacity, float iou[4]) {
+    return handle_errors([&]() {
+        sam_model& sm = as_sam(m);
+        if (sm.last_masks.empty()) throw except("sam: no masks yet, call sam_compute() first");
+        if (capacity < (int64_t)sm.last_masks.size()) throw except("sam: mask buffer too small (%lld < %zu)", (long long)capacity, sm.last_masks.size());
+        memcpy(masks, sm.last_masks.data(), sm.last_masks.size() * sizeof(float));
+        memcpy(iou, sm.last_iou, sizeof sm.last_iou);
     });
 }
 

@@ -215,6 +215,77 @@ __global__ void tv_add_gelu_kernel(const f16* __restrict__ a, const f16* __restr
 
 unsigned blocks_for(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
+// ---- y = a + b[i mod period] on f16 (a may be f32): the decoder's "queries + query_pe", "keys + key_pe" and
+// "image_embeddings + no_mask_embed" adds (mobile-sam.cpp:331-358, 437-440)
+template <typename TA>
+__global__ void tv_add_rows_kernel(const TA* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ y, long n8, long period8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const f16x8 bv = reinterpret_cast<const f16x8*>(b)[i % period8];
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)((float)a[i * 8 + j] + (float)bv[j]);
+    reinterpret_cast<f16x8*>(y)[i] = o;
+}
+
+// ---- attention with few queries or few keys (SAM mask decoder, mobile-sam.cpp:306-320 -> nn.cpp:210-244): q [Nq][H*hd],
+// k, v [Nk][H*hd], out [Nq][H*hd], hd <= 32, Nk <= 4096. One block per (query, head): scores in LDS, two block reductions,
+// then the 256 threads split the keys for the weighted sum of V. Launch-latency sized work (7 tokens x 4096 pixels).
+constexpr int SA_MAX_KEYS = 4096;
+__global__ __launch_bounds__(256) void tv_small_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                                                                 f16* __restrict__ out, int Nk, int H, int hd, float scale) {
+    __shared__ float sc[SA_MAX_KEYS];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
+    const int C = H * hd;
+    float qv[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) qv[d] = d < hd ? (float)q[(long)qi * C + h * hd + d] * scale : 0.0f;
+    float m = -INFINITY;
+    for (int j = tid; j < Nk; j += 256) {
+        const f16* kr = k + (long)j * C + h * hd;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d)
+            if (d < hd) s = fmaf(qv[d], (float)kr[d], s);
+        sc[j] = s;
+        m = fmaxf(m, s);
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    float sum = 0.0f;
+    for (int j = tid; j < Nk; j += 256) {
+        const float p = __expf(sc[j] - m);
+        sc[j] = p;
+        sum += p;
+    }
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float inv = 1.0f / red[0];
+    __syncthreads();
+    const int d = tid % hd, g = tid / hd, G = 256 / hd;
+    float acc = 0.0f;
+    for (int j = g; j < Nk; j += G) acc = fmaf(sc[j], (float)v[(long)j * C + h * hd + d], acc);
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < hd) {
+        float t = 0.0f;
+        for (int gg = 0; gg < G; ++gg) t += red[gg * hd + tid];
+        out[(long)qi * C + h * hd + tid] = (f16)(t * inv);
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -274,6 +345,30 @@ int vx_add_gelu_f16(const void* a, const void* b, void* y, int64_t n, void* stre
     VX_REQUIRE(a && y && n > 0 && n % 8 == 0, "vx_add_gelu_f16: n must be a positive multiple of 8");
     hipLaunchKernelGGL(tv_add_gelu_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(a),
                        reinterpret_cast<const f16*>(b), reinterpret_cast<f16*>(y), (long)(n / 8));
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_add_rows_f16(const void* a, int a_is_f32, const void* b, int64_t b_period, void* y, int64_t n, void* stream) {
+    VX_REQUIRE(a && b && y && n > 0 && n % 8 == 0 && b_period > 0 && b_period % 8 == 0, "vx_add_rows_f16: n and the period must be positive multiples of 8");
+    const long n8 = (long)(n / 8);
+    if (a_is_f32)
+        hipLaunchKernelGGL(tv_add_rows_kernel<float>, dim3(blocks_for(n8)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float*>(a),
+                           reinterpret_cast<const f16*>(b), reinterpret_cast<f16*>(y), n8, (long)(b_period / 8));
+    else
+        hipLaunchKernelGGL(tv_add_rows_kernel<f16>, dim3(blocks_for(n8)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(a),
+                           reinterpret_cast<const f16*>(b), reinterpret_cast<f16*>(y), n8, (long)(b_period / 8));
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_small_attention_f16(const void* q, const void* k, const void* v, void* out, int Nq, int Nk, int heads, int hd, void* stream) {
+    VX_REQUIRE(q && k && v && out && Nq > 0 && Nk > 0 && heads > 0, "vx_small_attention_f16: bad operands");
+    VX_REQUIRE(Nk <= SA_MAX_KEYS && hd > 0 && hd <= 32 && 256 % hd == 0, "vx_small_attention_f16: at most %d keys, head_dim a power of two <= 32 (Nk = %d, hd = %d)",
+               SA_MAX_KEYS, Nk, hd);
+    hipLaunchKernelGGL(tv_small_attention_kernel, dim3((unsigned)Nq * heads), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
+                       reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), Nk, heads, hd,
+                       1.0f / sqrtf((float)hd));
     VX_LAUNCH_CHECK();
     return 1;
 }

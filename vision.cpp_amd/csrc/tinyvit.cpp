@@ -69,6 +69,39 @@ struct packer {
         return v;
     }
 
+    packed_vec f16_vec(std::string const& name, int64_t expect = -1) { // arena f16 copy (n = element count)
+        gguf_tensor const& t = get(name);
+        if (expect >= 0 && t.n_elements() != expect) throw except("tensor %s: %lld elements, expected %lld", name.c_str(), (long long)t.n_elements(), (long long)expect);
+        packed_vec v;
+        v.n = (int)t.n_elements();
+        v.off = ab.alloc((size_t)v.n * 2 + 64);
+        if (with_data) {
+            uint16_t* d = reinterpret_cast<uint16_t*>(ab.data.data() + v.off);
+            for (int i = 0; i < v.n; ++i) d[i] = f32_to_f16(tensor_at(t, i));
+        }
+        return v;
+    }
+    std::vector<float> host_vec(std::string const& name, int64_t expect) {
+        gguf_tensor const& t = get(name);
+        if (t.n_elements() != expect) throw except("tensor %s: %lld elements, expected %lld", name.c_str(), (long long)t.n_elements(), (long long)expect);
+        std::vector<float> v(with_data ? (size_t)expect : 0);
+        for (size_t i = 0; i < v.size(); ++i) v[i] = tensor_at(t, i);
+        return v;
+    }
+    // conv_transpose_2d with kernel == stride (nn.cpp:117-129; weight ne [kw, kh, Cout, Cin] = torch [Cin][Cout][kh][kw], never
+    // permuted by the converter) as a GEMM whose row n = (dy * s + dx) * Cout + co feeds the pixel-shuffle epilogue
+    packed_gemm conv_transpose(std::string const& prefix, int stride, int* cout_out) {
+        gguf_tensor const& w = get(prefix + ".weight");
+        const int kw = (int)w.ne[0], kh = (int)w.ne[1], cout = (int)w.ne[2], cin = (int)w.ne[3];
+        if (kw != stride || kh != stride) throw except("%s: conv_transpose kernel %dx%d with stride %d is not supported", prefix.c_str(), kw, kh, stride);
+        *cout_out = cout;
+        auto at = [&](int n, int k) {
+            const int tap = n / cout, co = n % cout, dy = tap / stride, dx = tap % stride;
+            return tensor_at(w, (((size_t)k * cout + co) * kh + dy) * kw + dx);
+        };
+        return matrix(stride * stride * cout, cin, at, file.find(prefix + ".bias"), cout);
+    }
+
     // attention_biases_indexed [heads][N][N] -> the accumulator-order f16 image of kernels_winattn.hip
     packed_vec attention_bias(std::string const& name, int N, int heads) {
         gguf_tensor const& t = get(name);
@@ -86,7 +119,7 @@ struct packer {
     }
 
     // rows [n][k] -> f16 [N pad 32][K pad 64] + f32 bias [N]
-    packed_gemm matrix(int n, int k, std::function<float(int, int)> at, gguf_tensor const* bias) {
+    packed_gemm matrix(int n, int k, std::function<float(int, int)> at, gguf_tensor const* bias, int bias_period = 0) {
         packed_gemm g;
         g.n_real = n; g.k_real = k;
         // N decides the GEMM's block tile (128 wide if N % 128 == 0, else 64, else 32): wider tiles re-read A fewer times, so pad
@@ -101,11 +134,12 @@ struct packer {
                 for (int c = 0; c < k; ++c) w[(size_t)r * g.K + c] = f32_to_f16(at(r, c));
         }
         if (bias) {
-            if ((int)bias->n_elements() != n) throw except("tensor %s: %d elements, expected %d", bias->name.c_str(), (int)bias->n_elements(), n);
+            const int period = bias_period ? bias_period : n; // conv_transpose: the Cout biases repeat for every (dy, dx)
+            if ((int)bias->n_elements() != period) throw except("tensor %s: %d elements, expected %d", bias->name.c_str(), (int)bias->n_elements(), period);
             g.b = ab.alloc((size_t)g.N * 4);
             if (with_data) {
                 float* b = reinterpret_cast<float*>(ab.data.data() + g.b);
-                for (int r = 0; r < n; ++r) b[r] = tensor_at(*bias, r);
+                for (int r = 0; r < n; ++r) b[r] = tensor_at(*bias, r % period);
             }
         }
         return g;
@@ -237,6 +271,57 @@ sam_model* sam_load_model(char const* filepath, backend_device const& dev, int f
     Wt.neck3_w = pk.vec(e + "neck.3.weight");
     Wt.neck3_b = pk.vec(e + "neck.3.bias");
 
+    if (file.find("dec.iou_token.weight")) { // prompt encoder + mask decoder (mobile-sam.cpp:207-483)
+        samdec_weights& D = model->dec;
+        D.present = true;
+        const int dim = D.dim;
+        D.res = P.layers[3].resolution;
+        D.gaussian = pk.host_vec("prompt_encoder.pe_layer.positional_encoding_gaussian_matrix", dim);
+        for (int i = 0; i < 4; ++i) D.point_embed[i] = pk.host_vec("prompt_encoder.point_embeddings." + std::to_string(i) + ".weight", dim);
+        D.not_a_point = pk.host_vec("prompt_encoder.not_a_point_embed.weight", dim);
+        D.output_tokens = pk.host_vec("dec.iou_token.weight", dim);
+        std::vector<float> mt = pk.host_vec("dec.mask_tokens.weight", 4 * dim);
+        D.output_tokens.insert(D.output_tokens.end(), mt.begin(), mt.end());
+        D.no_mask = pk.f16_vec("prompt_encoder.no_mask_embed.weight", dim);
+        D.dense_pe = pk.f16_vec("dec.dense_positional_embedding", (int64_t)D.res * D.res * dim);
+        auto attn = [&](std::string const& p) {
+            sam_attn_weights a;
+            a.q = pk.linear(p + ".q_proj");
+            a.k = pk.linear(p + ".k_proj");
+            a.v = pk.linear(p + ".v_proj");
+            a.o = pk.linear(p + ".out_proj");
+            if (a.q.k_real != dim || a.o.n_real != dim || a.q.n_real % D.heads || a.q.n_real / D.heads > 32)
+                throw except("mobile-sam: %s has an unsupported shape (%d -> %d)", p.c_str(), a.q.k_real, a.q.n_real);
+            return a;
+        };
+        for (int i = 0; i < 2; ++i) {
+            std::string p = "dec.transformer.layers." + std::to_string(i);
+            sam_twoway_weights L;
+            L.self_attn = attn(p + ".self_attn");
+            L.t2i = attn(p + ".cross_attn_t2i");
+            L.i2t = attn(p + ".cross_attn_i2t");
+            L.lin1 = pk.linear(p + ".mlp.lin1");
+            L.lin2 = pk.linear(p + ".mlp.lin2");
+            for (int n = 0; n < 4; ++n) {
+                L.norm_w[n] = pk.vec(p + ".norm" + std::to_string(n + 1) + ".weight");
+                L.norm_b[n] = pk.vec(p + ".norm" + std::to_string(n + 1) + ".bias");
+            }
+            D.layers.push_back(L);
+        }
+        D.final_attn = attn("dec.transformer.final_attn_t2i");
+        D.final_norm_w = pk.vec("dec.transformer.norm_final_attn.weight");
+        D.final_norm_b = pk.vec("dec.transformer.norm_final_attn.bias");
+        D.up0 = pk.conv_transpose("dec.output_upscaling.0", 2, &D.up_c1);
+        D.up_norm_w = pk.vec("dec.output_upscaling.1.weight");
+        D.up_norm_b = pk.vec("dec.output_upscaling.1.bias");
+        D.up3 = pk.conv_transpose("dec.output_upscaling.3", 2, &D.up_c2);
+        if (D.up_c1 % 8 || D.up_c2 % 8 || D.up_c2 > 64) throw except("mobile-sam: upscaling widths %d / %d are not supported", D.up_c1, D.up_c2);
+        for (int i = 0; i < 4; ++i)
+            for (int l = 0; l < 3; ++l) D.hyper[i][l] = pk.linear("dec.output_hypernetworks_mlps." + std::to_string(i) + ".layers." + std::to_string(l));
+        for (int l = 0; l < 3; ++l) D.iou_head[l] = pk.linear("dec.iou_prediction_head.layers." + std::to_string(l));
+        if (D.hyper[0][2].n_real != D.up_c2 || D.iou_head[2].n_real != 4) throw except("mobile-sam: hypernetwork / iou head output widths do not match");
+    }
+
     VX(vx_set_device(dev.index));
     model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256) + 4096;
     VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
@@ -253,6 +338,7 @@ void sam_weights_ready(sam_model& m) { m.weights_uploaded = true; }
 sam_model::~sam_model() {
     vx_free(ws.ptr);
     vx_free(embed.ptr);
+    vx_free(dec_ws.ptr);
     for (auto& c : capture_bufs) vx_free(c.second.dev);
     vx_free(weight_arena.ptr);
 }
@@ -501,6 +587,206 @@ void sam_encode(sam_model& m, image_view image) {
     }
     vx_free(din);
     m.image_extent = image.extent;
+}
+
+// ---- sam_compute: prompt encoder + mask decoder + mask post-processing ------------------------------------------------
+
+namespace {
+
+// sam::interpolate_bilinear (mobile-sam.cpp:485-516): half-pixel centres, source clamped at 0 and extent - 1
+template <typename Store>
+void sam_interpolate(const float* src, int sw, int sh, int sstride, int dw, int dh, Store&& store) {
+    const float scale_x = float(sw) / float(dw), scale_y = float(sh) / float(dh);
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            const float sxf = std::max((x + 0.5f) * scale_x - 0.5f, 0.0f), syf = std::max((y + 0.5f) * scale_y - 0.5f, 0.0f);
+            const int x0 = int(sxf), y0 = int(syf);
+            const int x1 = std::min(x0 + 1, sw - 1), y1 = std::min(y0 + 1, sh - 1);
+            const float v00 = src[y0 * sstride + x0], v01 = src[y0 * sstride + x1], v10 = src[y1 * sstride + x0], v11 = src[y1 * sstride + x1];
+            const float wx = sxf - x0, wy = syf - y0;
+            const float v0 = (1 - wx) * v00 + wx * v01, v1 = (1 - wx) * v10 + wx * v11;
+            store(x, y, (1 - wy) * v0 + wy * v1);
+        }
+}
+
+// sam_process_mask (mobile-sam.cpp:556-583)
+image_data sam_process_mask(const float* mask, int mask_size, int image_size, i32x2 target) {
+    const float scale = float(image_size) / float(std::max(target[0], target[1]));
+    const int sw = int(target[0] * scale + 0.5f), sh = int(target[1] * scale + 0.5f);
+    std::vector<float> scaled((size_t)image_size * image_size);
+    sam_interpolate(mask, mask_size, mask_size, mask_size, image_size, image_size, [&](int x, int y, float v) { scaled[(size_t)y * image_size + x] = v; });
+    image_data out = image_alloc(target, image_format::alpha_u8);
+    uint8_t* dst = out.data.get();
+    sam_interpolate(scaled.data(), sw, sh, image_size, target[0], target[1], [&](int x, int y, float v) { dst[(size_t)y * target[0] + x] = uint8_t(v > 0.0f ? 255 : 0); });
+    return out;
+}
+
+float sam_transform_coord(int p, float scale, int image_size) { // mobile-sam.cpp:213-217
+    const float center_normalized = (float(p) * scale + 0.5f) / float(image_size);
+    return 2.f * center_normalized - 1.f;
+}
+
+} // namespace
+
+image_data sam_compute(sam_model& m, int const* prompt, int n_prompt) {
+    samdec_weights const& D = m.dec;
+    if (n_prompt != 2 && n_prompt != 4) throw except("sam: bad number of arguments (%d), must be 2 or 4", n_prompt);
+    if (!D.present) throw except("sam: this model file holds no prompt encoder / mask decoder (dec.* tensors)");
+    if (D.gaussian.empty()) throw except("sam: the decoder's host tables were not read (model loaded without data)");
+    if (!m.embed.ptr || m.image_extent[0] <= 0) throw except("Missing image embeds, call sam_encode() first");
+    VX(vx_set_device(m.backend->index));
+    void* s = m.backend->stream;
+    const int dim = D.dim, H = D.heads, res = D.res, Nk = res * res, Nt = 7, F = dim / 2;
+    const int image_size = m.params.img_size, mask_size = 4 * res;
+    const bool is_box = n_prompt == 4;
+
+    // ---- prompt encoder on the host (two points of 256 sin/cos values; mobile-sam.cpp:219-286)
+    const float scale = float(image_size) / float(std::max(m.image_extent[0], m.image_extent[1]));
+    float coords[4] = {sam_transform_coord(prompt[0], scale, image_size), sam_transform_coord(prompt[1], scale, image_size), 0.f, 0.f};
+    if (is_box) { coords[2] = sam_transform_coord(prompt[2], scale, image_size); coords[3] = sam_transform_coord(prompt[3], scale, image_size); }
+    std::vector<float> tokens(D.output_tokens); // [iou | 4 mask tokens]
+    tokens.resize((size_t)Nt * dim);
+    for (int i = 0; i < 2; ++i) {
+        float* t = tokens.data() + (size_t)(5 + i) * dim;
+        for (int f = 0; f < F; ++f) {
+            float v = coords[2 * i] * D.gaussian[f] + coords[2 * i + 1] * D.gaussian[F + f];
+            v *= 2.f * 3.14159265358979323846f;
+            t[f] = std::sin(v);
+            t[F + f] = std::cos(v);
+        }
+        if (is_box) for (int c = 0; c < dim; ++c) t[c] += D.point_embed[2 + i][c];
+        else if (i == 0) for (int c = 0; c < dim; ++c) t[c] += D.point_embed[1][c];
+        else for (int c = 0; c < dim; ++c) t[c] = D.not_a_point[c];
+    }
+    std::vector<uint16_t> tokens_h((size_t)8 * dim, 0);
+    for (size_t i = 0; i < tokens.size(); ++i) tokens_h[i] = f32_to_f16(tokens[i]);
+
+    // ---- scratch (f16 elements)
+    const size_t big = (size_t)Nk * dim, tok = (size_t)8 * dim;
+    size_t cursor = 0;
+    auto take = [&](size_t elems) { size_t o = cursor; cursor += round_up<size_t>(elems * 2 + 256, 256); return o; };
+    const size_t o_T = take(tok), o_Q = take(tok), o_t1 = take(tok), o_t2 = take(tok), o_h = take((size_t)8 * 2048 + 64);
+    const size_t o_K = take(big), o_k1 = take(big), o_k2 = take(big), o_pq = take(big), o_pk = take(big), o_pv = take(big), o_ao = take(big);
+    const size_t o_u1 = take((size_t)4 * Nk * D.up_c1), o_u1n = take((size_t)4 * Nk * D.up_c1), o_u2p = take((size_t)16 * Nk * D.up_c2), o_u2 = take((size_t)16 * Nk * D.up_c2 + 64);
+    const size_t o_hy = take((size_t)32 * 64), o_ha = take(tok), o_hb = take(tok), o_mask = take((size_t)16 * Nk * 8), o_iou = take(64);
+    if (m.dec_ws.bytes < cursor) {
+        VX(vx_stream_sync(s));
+        vx_free(m.dec_ws.ptr);
+        m.dec_ws = {};
+        VX(vx_malloc(&m.dec_ws.ptr, cursor));
+        m.dec_ws.bytes = cursor;
+        VX(vx_memset(m.dec_ws.ptr, 0, cursor, s));
+    }
+    uint8_t* base = static_cast<uint8_t*>(m.dec_ws.ptr);
+    auto P = [&](size_t off) { return static_cast<void*>(base + off); };
+    void *T = P(o_T), *Q = P(o_Q), *t1 = P(o_t1), *t2 = P(o_t2), *hbuf = P(o_h), *K = P(o_K), *k1 = P(o_k1), *k2 = P(o_k2);
+    void *pq = P(o_pq), *pk = P(o_pk), *pv = P(o_pv), *ao = P(o_ao), *u1 = P(o_u1), *u1n = P(o_u1n), *u2p = P(o_u2p), *u2 = P(o_u2);
+    void *hy = P(o_hy), *ha = P(o_ha), *hb = P(o_hb), *masks_d = P(o_mask), *iou_d = P(o_iou);
+
+    tv_exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
+    const bool timing = m.timing;
+    m.timing = false; // the per-group table belongs to the encoder
+    const uint8_t* wa = ex.wa;
+    VX(vx_memcpy_h2d(T, tokens_h.data(), tokens_h.size() * 2, s));
+    VX(vx_memcpy_d2d(Q, T, tok * 2, s));
+    // src = image_embeddings + dense prompt (no_mask_embed broadcast over the pixels), mobile-sam.cpp:437-440
+    VX(vx_add_rows_f16(m.embed.ptr, 1, wa + D.no_mask.off, dim, K, (int64_t)Nk * dim, s));
+    const void* KPE = wa + D.dense_pe.off;
+
+    auto linear = [&](packed_gemm const& g, const void* A, int M, void* out, int epi = VX_EPI_F16, const void* res1 = nullptr) {
+        ex.gemm(g, A, M, g.k_real, out, epi, res1, "decoder");
+    };
+    auto norm = [&](packed_vec const& w, packed_vec const& b, const void* x, void* y, long rows, int C) {
+        VX(vx_layernorm_f16(x, ex.fptr(w), ex.fptr(b), y, rows, C, 1e-5f, 0, 0, 0, s));
+    };
+    // decoder_attention (mobile-sam.cpp:306-320); out = [res1 +] out_proj(attention(q_proj(q), k_proj(k), v_proj(v)))
+    auto attention = [&](sam_attn_weights const& w, const void* q, int Nq, const void* k, const void* v, int Nkv, void* out, const void* res1) {
+        linear(w.q, q, Nq, pq);
+        linear(w.k, k, Nkv, pk);
+        linear(w.v, v, Nkv, pv);
+        VX(vx_small_attention_f16(pq, pk, pv, ao, Nq, Nkv, H, w.q.n_real / H, s));
+        linear(w.o, ao, Nq, out, res1 ? VX_EPI_F16_ADD : VX_EPI_F16, res1);
+    };
+    auto add = [&](const void* a, const void* b, void* y, long n) { VX(vx_add_rows_f16(a, 0, b, n, y, n, s)); };
+
+    for (size_t li = 0; li < D.layers.size(); ++li) { // two_way_attention_block (mobile-sam.cpp:322-364)
+        sam_twoway_weights const& L = D.layers[li];
+        if (li == 0) { // skip_first_layer_pe: queries = self_attn(queries)
+            attention(L.self_attn, Q, Nt, Q, Q, Nt, t2, nullptr);
+        } else {
+            add(Q, T, t1, (long)Nt * dim);
+            attention(L.self_attn, t1, Nt, t1, Q, Nt, t2, Q);
+        }
+        norm(L.norm_w[0], L.norm_b[0], t2, Q, Nt, dim);
+        add(Q, T, t1, (long)Nt * dim); // tokens attending to the image embedding
+        add(K, KPE, k1, (long)Nk * dim);
+        attention(L.t2i, t1, Nt, k1, K, Nk, t2, Q);
+        norm(L.norm_w[1], L.norm_b[1], t2, Q, Nt, dim);
+        linear(L.lin1, Q, Nt, hbuf, VX_EPI_F16_RELU); // mlp_block
+        linear(L.lin2, hbuf, Nt, t2, VX_EPI_F16_ADD, Q);
+        norm(L.norm_w[2], L.norm_b[2], t2, Q, Nt, dim);
+        add(Q, T, t1, (long)Nt * dim); // image embedding attending to the tokens (k1 = keys + key_pe from above)
+        attention(L.i2t, k1, Nk, t1, Q, Nt, k2, K);
+        norm(L.norm_w[3], L.norm_b[3], k2, K, Nk, dim);
+    }
+    add(Q, T, t1, (long)Nt * dim); // final attention from the points to the image (mobile-sam.cpp:386-392)
+    add(K, KPE, k1, (long)Nk * dim);
+    attention(D.final_attn, t1, Nt, k1, K, Nk, t2, Q);
+    norm(D.final_norm_w, D.final_norm_b, t2, Q, Nt, dim);
+
+    // upscale_outputs (mobile-sam.cpp:396-404): convT k2 s2 -> LayerNorm -> GELU -> convT k2 s2 -> GELU
+    auto conv_transpose = [&](packed_gemm const& g, const void* x, int hw, int cin, int cout, void* out) {
+        vx_gemm_args a;
+        memset(&a, 0, sizeof a);
+        a.A = x; a.lda = cin;
+        a.W = wa + g.w; a.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b);
+        a.M = hw * hw; a.N = g.N; a.K = g.K; a.n_valid = g.n_real;
+        a.epi = VX_EPI_PIXSHUF; a.out = out; a.ldo = cout;
+        a.ps_s = 2; a.ps_Cout = cout; a.ps_H = hw; a.ps_W = hw;
+        VX(vx_gemm_f16(&a, s));
+    };
+    conv_transpose(D.up0, K, res, dim, D.up_c1, u1);
+    norm(D.up_norm_w, D.up_norm_b, u1, u1n, (long)4 * Nk, D.up_c1);
+    VX(vx_add_gelu_f16(u1n, nullptr, u1, (int64_t)4 * Nk * D.up_c1, s));
+    conv_transpose(D.up3, u1, 2 * res, D.up_c1, D.up_c2, u2p);
+    VX(vx_add_gelu_f16(u2p, nullptr, u2, (int64_t)16 * Nk * D.up_c2, s));
+
+    // hypernetwork MLPs on the four mask tokens -> hyper_in rows (a [32][64] f16 operand, zero padded)
+    auto raw_gemm = [&](const void* A, int M, int lda, const void* W, const float* bias, int N, int Kp, int n_valid, void* out, int ldo, int epi) {
+        vx_gemm_args a;
+        memset(&a, 0, sizeof a);
+        a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.M = M; a.N = N; a.K = Kp; a.n_valid = n_valid; a.epi = epi; a.out = out; a.ldo = ldo;
+        VX(vx_gemm_f16(&a, s));
+    };
+    auto bias_of = [&](packed_gemm const& g) { return g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b); };
+    for (int i = 0; i < 4; ++i) {
+        const uint8_t* tok_i = static_cast<const uint8_t*>(Q) + (size_t)(1 + i) * dim * 2;
+        linear(D.hyper[i][0], tok_i, 1, ha, VX_EPI_F16_RELU);
+        linear(D.hyper[i][1], ha, 1, hb, VX_EPI_F16_RELU);
+        packed_gemm const& g = D.hyper[i][2];
+        raw_gemm(hb, 1, g.k_real, wa + g.w, bias_of(g), g.N, g.K, g.n_real, static_cast<uint8_t*>(hy) + (size_t)i * 64 * 2, 64, VX_EPI_F16);
+    }
+    // masks[i][pixel] = <upscaled[pixel], hyper_in[i]> (mobile-sam.cpp:472-473): M = 16 Nk pixels, K = up_c2, 4 of 8 stored columns real
+    raw_gemm(u2, 16 * Nk, D.up_c2, hy, nullptr, 32, 64, 8, masks_d, 8, VX_EPI_F16);
+    // iou prediction head on the iou token
+    linear(D.iou_head[0], Q, 1, ha, VX_EPI_F16_RELU);
+    linear(D.iou_head[1], ha, 1, hb, VX_EPI_F16_RELU);
+    {
+        packed_gemm const& g = D.iou_head[2];
+        raw_gemm(hb, 1, g.k_real, wa + g.w, bias_of(g), g.N, g.K, 8, iou_d, 8, VX_EPI_F16);
+    }
+    const size_t n_px = (size_t)mask_size * mask_size;
+    std::vector<uint16_t> mh(n_px * 8), ih(8);
+    VX(vx_memcpy_d2h(mh.data(), masks_d, mh.size() * 2, s));
+    VX(vx_memcpy_d2h(ih.data(), iou_d, 16, s));
+    VX(vx_stream_sync(s));
+    m.timing = timing;
+    m.last_masks.resize(4 * n_px);
+    for (size_t px = 0; px < n_px; ++px)
+        for (int i = 0; i < 4; ++i) m.last_masks[(size_t)i * n_px + px] = f16_to_f32(mh[px * 8 + i]);
+    for (int i = 0; i < 4; ++i) m.last_iou[i] = f16_to_f32(ih[i]);
+    const int idx = int(std::max_element(m.last_iou, m.last_iou + 3) - m.last_iou); // best of the FIRST THREE (vision.cpp:80-82)
+    return sam_process_mask(m.last_masks.data() + (size_t)idx * n_px, mask_size, image_size, m.image_extent);
 }
 
 } // namespace visp

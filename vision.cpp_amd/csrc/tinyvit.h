@@ -33,6 +33,29 @@ struct tinyvit_weights {
     packed_vec neck1_w, neck1_b, neck3_w, neck3_b;
 };
 
+// prompt encoder + mask decoder (mobile-sam.cpp:207-483); present when the file holds the dec.* / prompt_encoder.* tensors
+struct sam_attn_weights { packed_gemm q, k, v, o; };
+struct sam_twoway_weights {
+    sam_attn_weights self_attn, t2i, i2t;
+    packed_gemm lin1, lin2;
+    packed_vec norm_w[4], norm_b[4];
+};
+struct samdec_weights {
+    bool present = false;
+    int dim = 256, heads = 8, res = 64;
+    std::vector<float> gaussian;                       // host: positional_encoding_gaussian_matrix [2][dim/2]
+    std::vector<float> point_embed[4], not_a_point;    // host: label embeddings [dim]
+    std::vector<float> output_tokens;                  // host: [iou_token | mask_tokens] = [5][dim]
+    packed_vec no_mask, dense_pe;                      // arena f16: [dim], [res*res][dim] (n = f16 count)
+    std::vector<sam_twoway_weights> layers;
+    sam_attn_weights final_attn;
+    packed_vec final_norm_w, final_norm_b;
+    packed_gemm up0, up3;                              // conv_transpose k2 s2 as GEMM + pixel shuffle
+    packed_vec up_norm_w, up_norm_b;
+    int up_c1 = 0, up_c2 = 0;
+    packed_gemm hyper[4][3], iou_head[3];
+};
+
 struct sam_model : model_base { // vision.h sam_model counterpart (encoder part)
     sam_model() : model_base(family_sam) {}
     backend_device const* backend = nullptr;
@@ -41,6 +64,10 @@ struct sam_model : model_base { // vision.h sam_model counterpart (encoder part)
     device_buffer weight_arena;
     bool weights_uploaded = false;
     device_buffer ws;
+    samdec_weights dec;
+    device_buffer dec_ws;         // decoder scratch
+    std::vector<float> last_masks; // [4][mask_size^2] logits of the last sam_compute (f16-rounded), and their iou predictions
+    float last_iou[4] = {0, 0, 0, 0};
     device_buffer embed;          // image embedding of the last sam_encode: f32 [64, 64, 256] (NHWC)
     i32x2 image_extent = {{0, 0}}; // extent of the image passed to sam_encode (vision.h sam_model::image_extent)
     bool timing = false, captures = false;
@@ -57,5 +84,8 @@ void sam_encode_batch_host(sam_model&, uint8_t const* rgb, int batch, float* out
 // reference API (vision.cpp:36-52): any extent, any u8 colour format; longest side scaled to 1024, edge-replicated to the
 // square (sam_process_input); the embedding stays on the device in model.embed
 void sam_encode(sam_model&, image_view image);
+// reference API (vision.cpp:54-92): point (n = 2) or box (n = 4) in pixels of the image given to sam_encode -> alpha_u8 mask
+// at that image's extent (best of the first three masks by predicted iou)
+image_data sam_compute(sam_model&, int const* prompt, int n);
 
 } // namespace visp

@@ -98,13 +98,17 @@ class Model:
             self._handle = None
 
     # ---- reference API: one image of any size/format -> u8 depth map (c-api.cpp:230-251)
-    def compute(self, image: np.ndarray, format: ImageFormat = ImageFormat.rgb_u8) -> np.ndarray:
+    def compute(self, image: np.ndarray, format: ImageFormat = ImageFormat.rgb_u8, args: list[int] | None = None) -> np.ndarray:
         img = np.ascontiguousarray(image, dtype=np.uint8)
         h, w = img.shape[:2]
         view = lib.ImageView(w, h, w * _CHANNELS[format.value], format.value, img.ctypes.data)
         views = (lib.ImageView * 1)(view)
         out_view, out_data = lib.ImageView(), c_void_p()
-        check(self._api.visp_model_compute(self._handle, self.arch.value, views, 1, (c_int32 * 1)(), 0, byref(out_view), byref(out_data)))
+        a = list(args or [])
+        check(self._api.visp_model_compute(self._handle, self.arch.value, views, 1, (c_int32 * max(1, len(a)))(*a), len(a), byref(out_view), byref(out_data)))
+        return self._take_image(out_view, out_data)
+
+    def _take_image(self, out_view, out_data) -> np.ndarray:
         try:
             n = out_view.height * out_view.stride
             buf = (ctypes.c_uint8 * n).from_address(out_view.data)
@@ -230,6 +234,18 @@ class Model:
         out = np.empty((64, 64, 256), np.float32)
         check(self._api.visp_sam_read_embedding(self._handle, out.ctypes.data, out.size, shape))
         return out.reshape([int(d) for d in shape])
+
+    def sam_compute(self, prompt: list[int]) -> np.ndarray:
+        """sam_compute (reference vision.cpp:54-92) on the last sam_encode: point [x, y] or box [x0, y0, x1, y1] -> u8 mask [h, w]."""
+        out_view, out_data = lib.ImageView(), c_void_p()
+        check(self._api.visp_sam_compute(self._handle, (c_int32 * len(prompt))(*prompt), len(prompt), byref(out_view), byref(out_data)))
+        return self._take_image(out_view, out_data)
+
+    def sam_read_masks(self):
+        """mask logits [4, 256, 256] and iou predictions [4] of the last sam_compute."""
+        masks, iou = np.empty((4, 256, 256), np.float32), (ctypes.c_float * 4)()
+        check(self._api.visp_sam_read_masks(self._handle, masks.ctypes.data, masks.size, iou))
+        return masks, np.array(list(iou), np.float32)
 
     def sam_encode_batch(self, images: np.ndarray) -> np.ndarray:
         """images: uint8 [B, 1024, 1024, 3] on the host -> image embeddings float32 [B, 64, 64, 256]."""
