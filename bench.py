@@ -386,7 +386,7 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
     cfg = synth.TINYVIT_5M
     tmp = Path(tempfile.gettempdir()) / f"visp_bench_mobile_sam_f16_{os.environ.get('MASTER_PORT', '0')}.gguf"
     if rank == 0:
-        synth.write_tinyvit_gguf(tmp, cfg, seed=3)
+        synth.write_mobile_sam_gguf(tmp, cfg, enc_sd=synth.tinyvit_state_dict(cfg, 3), dec_sd=synth.sam_decoder_state_dict(1003))
     barrier()
     dev = vision.Device.init(index=device_index)
     model = vision.Model.load(tmp, dev, vision.Arch.sam, no_upload=(rank != 0))
@@ -470,6 +470,17 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
         res["roofline"]["launches_per_step"] = dom["launches"]
         res["roofline"]["share_of_step"] = round(dom["ms"] / tot, 3)
         res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
+    # configs[0] of BASELINE.json (encode + decode of one 1024x1024 image), outside the timed region: latency of the reference
+    # API calls sam_encode / sam_compute from host buffers (decode = prompt encoder + mask decoder on the GPU + the reference's
+    # host-side mask resize / threshold)
+    t0 = time.perf_counter()
+    model.sam_encode(imgs[0])
+    t1 = time.perf_counter()
+    for k in range(5):
+        mask = model.sam_compute([400 + 40 * k, 500])
+    t2 = time.perf_counter()
+    res["single_image_latency_ms"] = {"sam_encode": round(1e3 * (t1 - t0), 2), "sam_compute": round(1e3 * (t2 - t1) / 5, 2),
+                                      "note": "host buffers in, u8 mask out; batch 1; not part of value"}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
 

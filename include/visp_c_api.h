@@ -150,7 +150,7 @@ VISP_API int32_t visp_sam_encode(visp_model* m, visp_image_view const* image);
 VISP_API int32_t visp_sam_read_embedding(visp_model* m, float* host_out, int64_t capacity, int64_t shape[3]);
 /* sam_compute on the embedding of the last visp_sam_encode (several prompts per image, vision.cpp:54-92) */
 VISP_API int32_t visp_sam_compute(visp_model* m, int32_t const* prompt, int32_t n_prompt, visp_image_view* out_image, visp_image_data** out_data);
-/* test hook: mask logits [4][256][256] (f16-rounded) and iou predictions [4] of the last sam_compute */
+/* test hook: mask logits [4][256][256] (f16-rounded; kept only while captures are enabled) and iou predictions [4] of the last sam_compute */
 VISP_API int32_t visp_sam_read_masks(visp_model* m, float* masks, int64_t capacity, float iou[4]);
 /* rgb: u8 [B, 1024, 1024, 3] already at the model extent -> out f32 [B, 64, 64, 256]; device pointers;
  * stream = hipStream_t or NULL (NULL: the device's stream, synchronised before returning) */

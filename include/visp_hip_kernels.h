@@ -185,6 +185,9 @@ VX_API int vx_add_rows_f16(const void* a, int a_is_f32, const void* b, int64_t b
 /* attention with few queries or few keys (SAM mask decoder, mobile-sam.cpp:306-320): q [Nq][heads*hd], k, v [Nk][heads*hd]
  * -> out [Nq][heads*hd]; hd in {8, 16, 32}, Nk <= 4096; scale = 1/sqrt(hd) */
 VX_API int vx_small_attention_f16(const void* q, const void* k, const void* v, void* out, int Nq, int Nk, int heads, int hd, void* stream);
+/* sam::interpolate_bilinear (mobile-sam.cpp:485-516) for sam_process_mask (:556-583): source element (x, y) at
+ * src[(y * sstride + x) * step], f16 or f32; dst f32 [dh][dw], or u8 thresholded at 0 (0 / 255) when out_u8 */
+VX_API int vx_sam_interpolate(const void* src, int src_f16, int sw, int sh, int sstride, int step, void* dst, int dw, int dh, int out_u8, void* stream);
 /* y = gelu(a + b), b nullable (mb_conv tail, mobile-sam.cpp:88-90) */
 VX_API int vx_add_gelu_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
 

@@ -321,6 +321,7 @@ def sam_full(tmp_path_factory):
     path = synth.write_mobile_sam_gguf(tmp_path_factory.mktemp("samfull") / "mobile_sam.gguf", cfg, enc_sd=enc_sd, dec_sd=dec_sd)
     dev = vision.Device.init(vision.Backend.gpu)
     model = vision.Model.load(path, dev)
+    model.enable_captures(True)   # keeps the four mask logit planes of every sam_compute for sam_read_masks
     tensors, conv2d = synth.mobile_sam_gguf_tensors(enc_sd, dec_sd)
     yield dict(model=model, om=O.Model(tensors, conv2d, "whcn"), cfg=cfg)
     del model, dev
@@ -387,3 +388,26 @@ def test_sam_compute_errors(sam_full, tmp_path):
         fresh.sam_compute([1, 2])
     with pytest.raises(L.Error, match="must be 2 or 4"):
         m.sam_compute([1, 2, 3])
+
+
+@pytest.mark.parametrize("tw,th", [(1024, 1024), (640, 480), (333, 517)])
+def test_process_mask_kernels_match_the_reference_arithmetic(tw, th):
+    """sam_process_mask (mobile-sam.cpp:556-583) as two launches of vx_sam_interpolate, the source being one column of the
+    [pixels][8] mask GEMM output: identical to the oracle's restatement (fp contraction off on the GPU side)."""
+    from tests import gpu_util as G
+    from visioncpp_amd import _lib as L
+    rng = np.random.default_rng(tw)
+    yy, xx = np.meshgrid(np.linspace(-3, 3, 256), np.linspace(-3, 3, 256), indexing="ij")
+    mask = _h(np.sin(2 * xx) * np.cos(3 * yy) + 0.3 * rng.standard_normal((256, 256)))
+    planes = np.zeros((256 * 256, 8), np.float16)
+    planes[:, 2] = mask.reshape(-1)
+    src = G.dev(planes)
+    scaled, out = G.empty(1024 * 1024 * 4), G.empty(tw * th)
+    up = np.float32(1024) / np.float32(max(tw, th))
+    sw, sh = int(np.float32(tw) * up + np.float32(0.5)), int(np.float32(th) * up + np.float32(0.5))
+    L.vx_check(G.api().vx_sam_interpolate(src.ptr + 2 * 2, 1, 256, 256, 256, 8, scaled.ptr, 1024, 1024, 0, None))
+    L.vx_check(G.api().vx_sam_interpolate(scaled.ptr, 0, sw, sh, 1024, 1, out.ptr, tw, th, 1, None))
+    G.sync()
+    got = out.to_numpy(np.uint8, (th, tw))
+    want = O.sam_process_mask(mask, tw, th)
+    assert (got != want).mean() < 1e-5, (got != want).mean()

@@ -436,7 +436,7 @@ int32_t visp_sam_compute(visp_model* m, int32_t const* prompt, int32_t n_prompt,
 int32_t visp_sam_read_masks(visp_model* m, float* masks, int64_t capacity, float iou[4]) {
     return handle_errors([&]() {
         sam_model& sm = as_sam(m);
-        if (sm.last_masks.empty()) throw except("sam: no masks yet, call sam_compute() first");
+        if (sm.last_masks.empty()) throw except("sam: no mask logits kept: enable captures, then call sam_compute()");
         if (capacity < (int64_t)sm.last_masks.size()) throw except("sam: mask buffer too small (%lld < %zu)", (long long)capacity, sm.last_masks.size());
         memcpy(masks, sm.last_masks.data(), sm.last_masks.size() * sizeof(float));
         memcpy(iou, sm.last_iou, sizeof sm.last_iou);

@@ -286,6 +286,29 @@ __global__ __launch_bounds__(256) void tv_small_attention_kernel(const f16* __re
     }
 }
 
+// ---- sam::interpolate_bilinear (mobile-sam.cpp:485-516): half-pixel centres, source clamped at 0 and extent - 1, for the two
+// passes of sam_process_mask (:556-583). src element i lives at src[i * step] (a column of the [pixels][8] mask GEMM output);
+// out_u8: threshold at 0 -> 0 / 255, else f32. Contraction is off so the coordinates round as in the reference's C++.
+template <typename TS>
+__global__ void tv_sam_interp_kernel(const TS* __restrict__ src, int sw, int sh, int sstride, int step, void* __restrict__ dst, int dw, int dh,
+                                     int out_u8) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dw * dh) return;
+    const int x = i % dw, y = i / dw;
+    const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+    const float sxf = fmaxf(((float)x + 0.5f) * scale_x - 0.5f, 0.0f), syf = fmaxf(((float)y + 0.5f) * scale_y - 0.5f, 0.0f);
+    const int x0 = (int)sxf, y0 = (int)syf;
+    const int x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+    const float v00 = (float)src[((long)y0 * sstride + x0) * step], v01 = (float)src[((long)y0 * sstride + x1) * step];
+    const float v10 = (float)src[((long)y1 * sstride + x0) * step], v11 = (float)src[((long)y1 * sstride + x1) * step];
+    const float wx = sxf - (float)x0, wy = syf - (float)y0;
+    const float v0 = (1 - wx) * v00 + wx * v01, v1 = (1 - wx) * v10 + wx * v11;
+    const float v = (1 - wy) * v0 + wy * v1;
+    if (out_u8) reinterpret_cast<uint8_t*>(dst)[i] = v > 0.0f ? 255 : 0;
+    else reinterpret_cast<float*>(dst)[i] = v;
+}
+
 } // namespace
 
 extern "C" {
@@ -369,6 +392,19 @@ int vx_small_attention_f16(const void* q, const void* k, const void* v, void* ou
     hipLaunchKernelGGL(tv_small_attention_kernel, dim3((unsigned)Nq * heads), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
                        reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), Nk, heads, hd,
                        1.0f / sqrtf((float)hd));
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+int vx_sam_interpolate(const void* src, int src_f16, int sw, int sh, int sstride, int step, void* dst, int dw, int dh, int out_u8, void* stream) {
+    VX_REQUIRE(src && dst && sw > 0 && sh > 0 && dw > 0 && dh > 0 && step > 0 && sstride >= sw, "vx_sam_interpolate: bad operands");
+    const long n = (long)dw * dh;
+    if (src_f16)
+        hipLaunchKernelGGL(tv_sam_interp_kernel<f16>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(src), sw, sh,
+                           sstride, step, dst, dw, dh, out_u8);
+    else
+        hipLaunchKernelGGL(tv_sam_interp_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float*>(src), sw, sh,
+                           sstride, step, dst, dw, dh, out_u8);
     VX_LAUNCH_CHECK();
     return 1;
 }

@@ -563,63 +563,34 @@ void sam_encode(sam_model& m, image_view image) {
     }
     std::vector<uint8_t> square((size_t)S * S * 3);
     const uint8_t* src = static_cast<const uint8_t*>(v.data);
-    for (int y = 0; y < S; ++y) {
-        const uint8_t* row = src + (size_t)std::min(y, v.extent[1] - 1) * v.stride;
-        for (int x = 0; x < S; ++x) memcpy(&square[((size_t)y * S + x) * 3], row + (size_t)std::min(x, v.extent[0] - 1) * 3, 3);
+    const int vw = std::min(v.extent[0], S), vh = std::min(v.extent[1], S);
+    for (int y = 0; y < S; ++y) { // clamped source coordinates = edge replication (image.cpp convert<>, :216-226)
+        uint8_t* dst = &square[(size_t)y * S * 3];
+        if (y < vh) {
+            memcpy(dst, src + (size_t)y * v.stride, (size_t)vw * 3);
+            for (int x = vw; x < S; ++x) memcpy(dst + (size_t)x * 3, dst + (size_t)(vw - 1) * 3, 3);
+        } else {
+            memcpy(dst, dst - (size_t)S * 3, (size_t)S * 3);
+        }
     }
     VX(vx_set_device(m.backend->index));
     const int R = m.params.layers[3].resolution;
     const size_t out_bytes = (size_t)R * R * 256 * 4;
-    if (!m.embed.ptr) {
-        VX(vx_malloc(&m.embed.ptr, out_bytes));
-        m.embed.bytes = out_bytes;
+    if (!m.embed.ptr) { // embedding + the staging copy of the input stay with the model
+        VX(vx_malloc(&m.embed.ptr, out_bytes + square.size()));
+        m.embed.bytes = out_bytes + square.size();
     }
-    void* din = nullptr;
-    VX(vx_malloc(&din, square.size()));
+    void* din = static_cast<uint8_t*>(m.embed.ptr) + out_bytes;
     void* s = m.backend->stream;
-    try {
-        VX(vx_memcpy_h2d(din, square.data(), square.size(), s));
-        sam_encode_batch_device(m, din, 1, m.embed.ptr, s);
-        VX(vx_stream_sync(s));
-    } catch (...) {
-        vx_free(din);
-        throw;
-    }
-    vx_free(din);
+    VX(vx_memcpy_h2d(din, square.data(), square.size(), s));
+    sam_encode_batch_device(m, din, 1, m.embed.ptr, s);
+    VX(vx_stream_sync(s));
     m.image_extent = image.extent;
 }
 
 // ---- sam_compute: prompt encoder + mask decoder + mask post-processing ------------------------------------------------
 
 namespace {
-
-// sam::interpolate_bilinear (mobile-sam.cpp:485-516): half-pixel centres, source clamped at 0 and extent - 1
-template <typename Store>
-void sam_interpolate(const float* src, int sw, int sh, int sstride, int dw, int dh, Store&& store) {
-    const float scale_x = float(sw) / float(dw), scale_y = float(sh) / float(dh);
-    for (int y = 0; y < dh; ++y)
-        for (int x = 0; x < dw; ++x) {
-            const float sxf = std::max((x + 0.5f) * scale_x - 0.5f, 0.0f), syf = std::max((y + 0.5f) * scale_y - 0.5f, 0.0f);
-            const int x0 = int(sxf), y0 = int(syf);
-            const int x1 = std::min(x0 + 1, sw - 1), y1 = std::min(y0 + 1, sh - 1);
-            const float v00 = src[y0 * sstride + x0], v01 = src[y0 * sstride + x1], v10 = src[y1 * sstride + x0], v11 = src[y1 * sstride + x1];
-            const float wx = sxf - x0, wy = syf - y0;
-            const float v0 = (1 - wx) * v00 + wx * v01, v1 = (1 - wx) * v10 + wx * v11;
-            store(x, y, (1 - wy) * v0 + wy * v1);
-        }
-}
-
-// sam_process_mask (mobile-sam.cpp:556-583)
-image_data sam_process_mask(const float* mask, int mask_size, int image_size, i32x2 target) {
-    const float scale = float(image_size) / float(std::max(target[0], target[1]));
-    const int sw = int(target[0] * scale + 0.5f), sh = int(target[1] * scale + 0.5f);
-    std::vector<float> scaled((size_t)image_size * image_size);
-    sam_interpolate(mask, mask_size, mask_size, mask_size, image_size, image_size, [&](int x, int y, float v) { scaled[(size_t)y * image_size + x] = v; });
-    image_data out = image_alloc(target, image_format::alpha_u8);
-    uint8_t* dst = out.data.get();
-    sam_interpolate(scaled.data(), sw, sh, image_size, target[0], target[1], [&](int x, int y, float v) { dst[(size_t)y * target[0] + x] = uint8_t(v > 0.0f ? 255 : 0); });
-    return out;
-}
 
 float sam_transform_coord(int p, float scale, int image_size) { // mobile-sam.cpp:213-217
     const float center_normalized = (float(p) * scale + 0.5f) / float(image_size);
@@ -669,6 +640,7 @@ image_data sam_compute(sam_model& m, int const* prompt, int n_prompt) {
     const size_t o_K = take(big), o_k1 = take(big), o_k2 = take(big), o_pq = take(big), o_pk = take(big), o_pv = take(big), o_ao = take(big);
     const size_t o_u1 = take((size_t)4 * Nk * D.up_c1), o_u1n = take((size_t)4 * Nk * D.up_c1), o_u2p = take((size_t)16 * Nk * D.up_c2), o_u2 = take((size_t)16 * Nk * D.up_c2 + 64);
     const size_t o_hy = take((size_t)32 * 64), o_ha = take(tok), o_hb = take(tok), o_mask = take((size_t)16 * Nk * 8), o_iou = take(64);
+    const size_t o_scaled = take((size_t)image_size * image_size * 2 /* f32 */), o_out = take(((size_t)m.image_extent[0] * m.image_extent[1] + 1) / 2);
     if (m.dec_ws.bytes < cursor) {
         VX(vx_stream_sync(s));
         vx_free(m.dec_ws.ptr);
@@ -681,7 +653,7 @@ image_data sam_compute(sam_model& m, int const* prompt, int n_prompt) {
     auto P = [&](size_t off) { return static_cast<void*>(base + off); };
     void *T = P(o_T), *Q = P(o_Q), *t1 = P(o_t1), *t2 = P(o_t2), *hbuf = P(o_h), *K = P(o_K), *k1 = P(o_k1), *k2 = P(o_k2);
     void *pq = P(o_pq), *pk = P(o_pk), *pv = P(o_pv), *ao = P(o_ao), *u1 = P(o_u1), *u1n = P(o_u1n), *u2p = P(o_u2p), *u2 = P(o_u2);
-    void *hy = P(o_hy), *ha = P(o_ha), *hb = P(o_hb), *masks_d = P(o_mask), *iou_d = P(o_iou);
+    void *hy = P(o_hy), *ha = P(o_ha), *hb = P(o_hb), *masks_d = P(o_mask), *iou_d = P(o_iou), *scaled = P(o_scaled), *mask_u8 = P(o_out);
 
     tv_exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
     const bool timing = m.timing;
@@ -775,18 +747,34 @@ image_data sam_compute(sam_model& m, int const* prompt, int n_prompt) {
         packed_gemm const& g = D.iou_head[2];
         raw_gemm(hb, 1, g.k_real, wa + g.w, bias_of(g), g.N, g.K, 8, iou_d, 8, VX_EPI_F16);
     }
+    // the decoder's only host decision: best of the FIRST THREE masks by predicted iou (vision.cpp:80-82)
     const size_t n_px = (size_t)mask_size * mask_size;
-    std::vector<uint16_t> mh(n_px * 8), ih(8);
-    VX(vx_memcpy_d2h(mh.data(), masks_d, mh.size() * 2, s));
+    std::vector<uint16_t> ih(8);
     VX(vx_memcpy_d2h(ih.data(), iou_d, 16, s));
     VX(vx_stream_sync(s));
-    m.timing = timing;
-    m.last_masks.resize(4 * n_px);
-    for (size_t px = 0; px < n_px; ++px)
-        for (int i = 0; i < 4; ++i) m.last_masks[(size_t)i * n_px + px] = f16_to_f32(mh[px * 8 + i]);
     for (int i = 0; i < 4; ++i) m.last_iou[i] = f16_to_f32(ih[i]);
-    const int idx = int(std::max_element(m.last_iou, m.last_iou + 3) - m.last_iou); // best of the FIRST THREE (vision.cpp:80-82)
-    return sam_process_mask(m.last_masks.data() + (size_t)idx * n_px, mask_size, image_size, m.image_extent);
+    const int idx = int(std::max_element(m.last_iou, m.last_iou + 3) - m.last_iou);
+    // sam_process_mask (mobile-sam.cpp:556-583): mask -> image_size^2, crop to the scaled extent, resize to the image, threshold
+    const i32x2 target = m.image_extent;
+    const float up = float(image_size) / float(std::max(target[0], target[1]));
+    const int sw = int(target[0] * up + 0.5f), sh = int(target[1] * up + 0.5f);
+    VX(vx_sam_interpolate(static_cast<const uint16_t*>(masks_d) + idx, 1, mask_size, mask_size, mask_size, 8, scaled, image_size, image_size, 0, s));
+    VX(vx_sam_interpolate(scaled, 0, sw, sh, image_size, 1, mask_u8, target[0], target[1], 1, s));
+    image_data out = image_alloc(target, image_format::alpha_u8);
+    VX(vx_memcpy_d2h(out.data.get(), mask_u8, (size_t)target[0] * target[1], s));
+    if (m.captures) { // test hook: the four logit planes (f16-rounded)
+        std::vector<uint16_t> mh(n_px * 8);
+        VX(vx_memcpy_d2h(mh.data(), masks_d, mh.size() * 2, s));
+        VX(vx_stream_sync(s));
+        m.last_masks.resize(4 * n_px);
+        for (size_t px = 0; px < n_px; ++px)
+            for (int i = 0; i < 4; ++i) m.last_masks[(size_t)i * n_px + px] = f16_to_f32(mh[px * 8 + i]);
+    } else {
+        m.last_masks.clear();
+    }
+    VX(vx_stream_sync(s));
+    m.timing = timing;
+    return out;
 }
 
 } // namespace visp
