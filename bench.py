@@ -469,6 +469,14 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
         res["roofline"]["avg_launch_ms"] = round(dom["ms"] / max(dom["launches"], 1), 4)
         res["roofline"]["launches_per_step"] = dom["launches"]
         res["roofline"]["share_of_step"] = round(dom["ms"] / tot, 3)
+        res["roofline"]["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
+        pmc = ROOT / "profiles" / "r01_pmc" / "traffic_sam.json"
+        key = {"depthwise_mbconv": "depthwise"}.get(dom["name"])
+        if key and pmc.exists():  # counters were collected at batch 16; the kernel's traffic is linear in the batch
+            k = json.loads(pmc.read_text())["kernels"].get(key)
+            if k:
+                res["roofline"]["traffic"] = round(k["hbm_bytes_per_launch"] * B / 16)
+                res["roofline"]["traffic_source"] = "profiles/r01_pmc/traffic_sam.json (FETCH_SIZE x2 + WRITE_SIZE, batch 16, scaled by batch)"
         res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
     # configs[0] of BASELINE.json (encode + decode of one 1024x1024 image), outside the timed region: latency of the reference
     # API calls sam_encode / sam_compute from host buffers (decode = prompt encoder + mask decoder on the GPU + the reference's

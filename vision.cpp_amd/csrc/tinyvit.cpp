@@ -473,7 +473,7 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
     for (tv_mbconv_weights const& mb : Wt.mbconv) {
         const long M = (long)B * res * res;
         ex.gemm(mb.conv1, x, M, C, t1, VX_EPI_F16_GELU, nullptr, "mbconv_1x1");
-        ex.dw(mb.conv2, t1, t2, B, res, res, 1, true, "depthwise");
+        ex.dw(mb.conv2, t1, t2, B, res, res, 1, true, "depthwise_mbconv"); // the step's largest kernel: [B, 256, 256, 256] in and out
         ex.gemm(mb.conv3, t2, M, mb.conv1.n_real, t3, VX_EPI_F16_ADD, x, "mbconv_1x1", /*post_gelu=*/true); // gelu(x + conv3) in the epilogue
         std::swap(x, t3);
     }
