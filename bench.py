@@ -456,7 +456,9 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
     }
     if groups:
         tot = sum(g["ms"] for g in groups)
-        dom = groups[0]
+        # the profile is flat (no group above 12 %): the roofline object describes the step's longest single launch among the
+        # groups that matter (>= 5 % of the step), which is one kernel at one shape -- the MBConv depthwise conv
+        dom = max((g for g in groups if g["ms"] >= 0.05 * tot), key=lambda g: g["ms"] / max(g["launches"], 1))
         hbm_bound = dom["flops"] / max(dom["bytes"], 1) < PEAK_MFMA_F16 / PEAK_HBM
         if hbm_bound:
             ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
@@ -481,14 +483,18 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
     # configs[0] of BASELINE.json (encode + decode of one 1024x1024 image), outside the timed region: latency of the reference
     # API calls sam_encode / sam_compute from host buffers (decode = prompt encoder + mask decoder on the GPU + the reference's
     # host-side mask resize / threshold)
-    t0 = time.perf_counter()
     model.sam_encode(imgs[0])
-    t1 = time.perf_counter()
+    model.sam_compute([300, 300])  # first calls allocate the staging / decoder scratch
+    t0 = time.perf_counter()
     for k in range(5):
+        model.sam_encode(imgs[k % len(imgs)])
+    t1 = time.perf_counter()
+    for k in range(10):
         mask = model.sam_compute([400 + 40 * k, 500])
     t2 = time.perf_counter()
-    res["single_image_latency_ms"] = {"sam_encode": round(1e3 * (t1 - t0), 2), "sam_compute": round(1e3 * (t2 - t1) / 5, 2),
-                                      "note": "host buffers in, u8 mask out; batch 1; not part of value"}
+    assert mask.shape == (S, S) and set(np.unique(mask)) <= {0, 255}
+    res["single_image_latency_ms"] = {"sam_encode": round(1e3 * (t1 - t0) / 5, 2), "sam_compute": round(1e3 * (t2 - t1) / 10, 2),
+                                      "note": "steady state, host buffers in, u8 mask out; batch 1; not part of value"}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
 
