@@ -217,3 +217,27 @@ def test_mobile_sam_gguf_is_detected_and_bias_packing_is_host_code(tmp_path):
             want = np.where(key >= N, -np.inf, np.where(q < N, bias[:, np.minimum(q, N - 1), np.minimum(key, N - 1)], 0.0))
             assert np.array_equal(pk[:, qb, kb], want)
     assert lib.vx_window_attention_pack_bias(bias.ctypes.data, 300, heads, packed.ctypes.data) == 0  # more than 256 tokens
+
+
+def test_mobile_sam_converter_writes_the_reference_contract(tmp_path):
+    """convert_sam on a checkpoint-shaped state dict (image_encoder. / prompt_encoder. / mask_decoder. keys, BatchNorm
+    bookkeeping tensors included) gives the file the synthetic writer gives, and the loader's family detection accepts it."""
+    from visioncpp_amd import convert, gguf, synth
+    cfg = synth.TINYVIT_5M
+    enc, dec = synth.tinyvit_state_dict(cfg, 6), synth.sam_decoder_state_dict(7)
+    ckpt = {"image_encoder." + k: v for k, v in enc.items()}
+    ckpt["image_encoder.patch_embed.seq.0.bn.num_batches_tracked"] = np.array(3, np.int64)
+    ckpt.update(dec)
+    p = convert.convert_sam(ckpt, tmp_path / "conv.gguf")
+    ref = synth.write_mobile_sam_gguf(tmp_path / "ref.gguf", cfg, enc_sd=enc, dec_sd=dec)
+    a, b = gguf.GGUFFile(p), gguf.GGUFFile(ref)
+    assert list(a.tensors) == list(b.tensors)
+    for name, t in a.tensors.items():
+        assert t.dtype == b.tensors[name].dtype and np.array_equal(t, b.tensors[name]), name
+    assert a.tensors["dec.iou_token.weight"].dtype == np.float32 and a.tensors["enc.neck.2.weight"].dtype == np.float16
+    assert max(len(n) for n in a.tensors) < 64
+    fam = C.c_int32(-1)
+    L.check(L.get_lib().visp_model_detect_family(L.path_to_char_p(p), C.byref(fam)))
+    assert fam.value == 0
+    with pytest.raises(ValueError, match="not a MobileSAM"):
+        convert.convert_sam({"foo": np.zeros(3, np.float32)}, tmp_path / "x.gguf")

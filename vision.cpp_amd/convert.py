@@ -134,3 +134,30 @@ def convert_esrgan(state_dict: dict[str, np.ndarray], out_path: str | Path) -> P
         w.add_tensor(name, t)
     w.write()
     return Path(out_path)
+
+
+def convert_sam(state_dict: dict[str, np.ndarray], out_path: str | Path) -> Path:
+    """MobileSAM checkpoint (image_encoder.* = TinyViT-5M, prompt_encoder.*, mask_decoder.*) -> GGUF with the on-disk contract
+    of the reference's convert_sam (scripts/convert.py:204-262): BatchNorm fused into `<conv>.c.weight/.c.bias`, `local_conv`
+    always NHWC and unlisted, `attention_biases_indexed`, neck convs listed, mask_decoder. -> dec., _token_to_image /
+    _image_to_token -> _t2i / _i2t, iou / mask tokens f32, dense positional embedding precomputed."""
+    from .synth import mobile_sam_gguf_tensors
+
+    enc = {k[len("image_encoder."):]: np.asarray(v, np.float32) for k, v in state_dict.items()
+           if k.startswith("image_encoder.") and not k.endswith("num_batches_tracked") and "attention_bias_idxs" not in k}
+    dec = {k: np.asarray(v, np.float32) for k, v in state_dict.items() if not k.startswith("image_encoder.")}
+    if "patch_embed.seq.0.c.weight" not in enc or "mask_decoder.iou_token.weight" not in dec:
+        raise ValueError("not a MobileSAM state dict (image_encoder.patch_embed / mask_decoder.iou_token missing)")
+    tensors, conv2d = mobile_sam_gguf_tensors(enc, dec)
+    too_long = [n for n in tensors if len(n) >= 64]  # GGML_MAX_NAME (convert.py:58-59)
+    if too_long:
+        raise ValueError(f"tensor name too long for GGUF: {too_long[0]}")
+    w = GGUFWriter(out_path, "mobile-sam")
+    w.add_string("mobile-sam.tensor_data_layout", "whcn")
+    w.add_uint32("general.quantization_version", 2)
+    w.add_uint32("general.file_type", 1)
+    w.add_array_i32("mobile-sam.conv2d_weights", conv2d)
+    for name, t in tensors.items():
+        w.add_tensor(name, t)
+    w.write()
+    return Path(out_path)
