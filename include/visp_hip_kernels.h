@@ -167,6 +167,14 @@ VX_API int vx_esrgan_tiles_out(const float* tiles, int B, const vx_tile_layout* 
 VX_API int vx_tv_preprocess(const uint8_t* rgb, void* out, int64_t n_pixels, void* stream);
 /* depthwise 3x3 pad 1 (+ bias, optional GELU) on NHWC f16: conv_2d_depthwise, nn.cpp:102-115; w f16 [9][C], bias f32 [C] */
 VX_API int vx_dwconv3x3_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int stride, int gelu, void* stream);
+/* second half of mb_conv in one launch (mobile-sam.cpp:82-90; kernels_mbconv.hip): y = gelu(x + conv3(gelu(dw3x3(h) + b2)) + b3)
+ * h f16 [B,H,W,C] (= gelu(conv1(x))), w2 f16 [9][C], w3 f16 = vx_mbconv_pack_w3 (host code) of the row-major [Cout][C] weight
+ * (MFMA fragment order, same byte count), x / y f16 [B,H,W,Cout]. Built for C = 256, Cout = 64, W % 64 == 0
+ * (vx_mbconv_dw_pw_supported); the depthwise output only exists as an LDS tile. */
+VX_API int vx_mbconv_dw_pw_supported(int C, int Cout, int W);
+VX_API int vx_mbconv_pack_w3(const void* w3_rows_host, void* packed_host);
+VX_API int vx_mbconv_dw_pw_f16(const void* h, const void* w2, const float* b2, const void* w3, const float* b3, const void* x, void* y, int B, int H,
+                               int W, int C, int Cout, void* stream);
 /* LayerNorm of f16 rows (nn.cpp:14-19). ws > 0: output rows in window order of a res x res map (window_partition,
  * mobile-sam.cpp:25-46; padded positions = norm of zero = bias). out_f32: f32 output. C <= 512. */
 VX_API int vx_layernorm_f16(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int res, int ws,

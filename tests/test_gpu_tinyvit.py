@@ -411,3 +411,30 @@ def test_process_mask_kernels_match_the_reference_arithmetic(tw, th):
     got = out.to_numpy(np.uint8, (th, tw))
     want = O.sam_process_mask(mask, tw, th)
     assert (got != want).mean() < 1e-5, (got != want).mean()
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 5, 64), (1, 9, 192)])
+def test_fused_mbconv_second_half(B, H, W):
+    """depthwise 3x3 + GELU + 1x1 conv + residual + GELU in one launch (kernels_mbconv.hip) against the oracle's pieces."""
+    from tests import gpu_util as G
+    from visioncpp_amd import _lib as L
+    rng = np.random.default_rng(H * W)
+    Cc, Co = 256, 64
+    h = _h(rng.standard_normal((B, H, W, Cc)))
+    w2 = _h(rng.standard_normal((3, 3, Cc)) / 3)
+    b2 = rng.standard_normal(Cc).astype(np.float32) * 0.1
+    w3 = _h(rng.standard_normal((Co, Cc)) / np.sqrt(Cc))
+    b3 = rng.standard_normal(Co).astype(np.float32) * 0.1
+    x = _h(rng.standard_normal((B, H, W, Co)))
+    assert G.api().vx_mbconv_dw_pw_supported(Cc, Co, W) == 1 and G.api().vx_mbconv_dw_pw_supported(128, Co, W) == 0
+    out = G.empty(B * H * W * Co * 2)
+    w3h, w3p = np.ascontiguousarray(w3.astype(np.float16)), np.zeros((Co, Cc), np.float16)
+    L.vx_check(G.api().vx_mbconv_pack_w3(w3h.ctypes.data, w3p.ctypes.data))
+    L.vx_check(G.api().vx_mbconv_dw_pw_f16(G.dev(h.astype(np.float16)).ptr, G.dev(w2.astype(np.float16)).ptr, G.dev(b2).ptr, G.dev(w3p).ptr,
+                                           G.dev(b3).ptr, G.dev(x.astype(np.float16)).ptr, out.ptr, B, H, W, Cc, Co, None))
+    G.sync()
+    got = out.to_numpy(np.float16, (B, H, W, Co)).astype(np.float32)
+    for i in range(B):
+        d = _h(O.gelu(O.conv2d_depthwise_nhwc(h[i], w2, b2, 1, 1), O.GELU_TANH_F32))   # the tile is stored as f16 in LDS
+        want = O.gelu(d.reshape(-1, Cc) @ w3.T + b3 + x[i].reshape(-1, Co), O.GELU_TANH_F32).reshape(H, W, Co)
+        np.testing.assert_allclose(got[i], want, atol=5e-3, rtol=5e-3)

@@ -102,7 +102,7 @@ KERNEL_SYMBOLS = [
     "vx_layernorm_f32_f16", "vx_layernorm_resid_supported", "vx_layernorm_resid_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
     "vx_dconv3x3_f16", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
-    "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
+    "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_mbconv_dw_pw_supported", "vx_mbconv_pack_w3", "vx_mbconv_dw_pw_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
 ]
 
 
@@ -221,6 +221,9 @@ def init() -> ctypes.CDLL:
     lib.vx_add_rows_f16.argtypes = [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
     lib.vx_small_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_sam_interpolate.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.vx_mbconv_pack_w3.argtypes = [c_void_p, c_void_p]
+    lib.vx_mbconv_dw_pw_supported.argtypes = [c_int, c_int, c_int]
+    lib.vx_mbconv_dw_pw_f16.argtypes = [c_void_p] * 7 + [c_int] * 5 + [c_void_p]
     lib.vx_window_attention_bias_bytes.argtypes = [c_int, c_int]
     lib.vx_window_attention_bias_bytes.restype = c_size_t
     lib.vx_window_attention_pack_bias.argtypes = [c_void_p, c_int, c_int, c_void_p]

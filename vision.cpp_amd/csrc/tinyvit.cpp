@@ -240,6 +240,14 @@ sam_model* sam_load_model(char const* filepath, backend_device const& dev, int f
         mb.conv1 = pk.conv(p + ".conv1.c");
         mb.conv2 = pk.depthwise(p + ".conv2.c");
         mb.conv3 = pk.conv(p + ".conv3.c");
+        if (vx_mbconv_dw_pw_supported(mb.conv2.C, mb.conv3.n_real, P.layers[0].resolution) && mb.conv3.N == mb.conv3.n_real && mb.conv3.K == mb.conv2.C) {
+            mb.conv3_frag = ab.alloc((size_t)mb.conv3.N * mb.conv3.K * 2); // the fused kernel reads W3 in MFMA fragment order
+            if (with_data) {
+                std::vector<uint16_t> rows((size_t)mb.conv3.N * mb.conv3.K); // copy: alloc() may have moved the arena
+                memcpy(rows.data(), ab.data.data() + mb.conv3.w, rows.size() * 2);
+                VX(vx_mbconv_pack_w3(rows.data(), ab.data.data() + mb.conv3_frag));
+            }
+        }
         Wt.mbconv.push_back(mb);
     }
     Wt.merge[0] = merge(e + "layers.0.downsample");
@@ -461,6 +469,7 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
 
     tv_exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
     if (const char* e = getenv("VISP_TV_GEMM_VARIANT")) ex.gemm_variant = atoi(e);
+    const bool fuse_mbconv = !getenv("VISP_TV_NO_FUSED_MBCONV");
     ex.mark("preprocess", 0, (double)B * S * S * 19);
     VX(vx_tv_preprocess(static_cast<const uint8_t*>(rgb_dev), in8, (int64_t)B * S * S, s));
     // patch_embed (mobile-sam.cpp:70-75)
@@ -473,8 +482,15 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
     for (tv_mbconv_weights const& mb : Wt.mbconv) {
         const long M = (long)B * res * res;
         ex.gemm(mb.conv1, x, M, C, t1, VX_EPI_F16_GELU, nullptr, "mbconv_1x1");
-        ex.dw(mb.conv2, t1, t2, B, res, res, 1, true, "depthwise_mbconv"); // the step's largest kernel: [B, 256, 256, 256] in and out
-        ex.gemm(mb.conv3, t2, M, mb.conv1.n_real, t3, VX_EPI_F16_ADD, x, "mbconv_1x1", /*post_gelu=*/true); // gelu(x + conv3) in the epilogue
+        if (fuse_mbconv && mb.conv3_frag != SIZE_MAX && mb.conv3.b != SIZE_MAX && vx_mbconv_dw_pw_supported(mb.conv2.C, mb.conv3.n_real, res)) {
+            // depthwise + GELU + conv3 + residual + GELU in one launch: the depthwise output stays in LDS (kernels_mbconv.hip)
+            ex.mark("mbconv_dw_pw", 2.0 * M * (9.0 * mb.conv2.C + (double)mb.conv2.C * C), (double)M * (mb.conv2.C + 2.0 * C) * 2);
+            VX(vx_mbconv_dw_pw_f16(t1, ex.wa + mb.conv2.w, reinterpret_cast<const float*>(ex.wa + mb.conv2.b), ex.wa + mb.conv3_frag,
+                                   reinterpret_cast<const float*>(ex.wa + mb.conv3.b), x, t3, B, res, res, mb.conv2.C, C, s));
+        } else {
+            ex.dw(mb.conv2, t1, t2, B, res, res, 1, true, "depthwise_mbconv"); // the step's largest kernel: [B, 256, 256, 256] in and out
+            ex.gemm(mb.conv3, t2, M, mb.conv1.n_real, t3, VX_EPI_F16_ADD, x, "mbconv_1x1", /*post_gelu=*/true); // gelu(x + conv3) in the epilogue
+        }
         std::swap(x, t3);
     }
     auto patch_merging = [&](tv_merge_weights const& mg) { // mobile-sam.cpp:94-110

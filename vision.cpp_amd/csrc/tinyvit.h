@@ -16,7 +16,7 @@ struct tiny_vit_params { // mobile-sam.h:16-37
 };
 
 struct packed_dw { size_t w = 0, b = 0; int C = 0; };   // depthwise 3x3: f16 [9][C] + f32 bias [C]
-struct tv_mbconv_weights { packed_gemm conv1, conv3; packed_dw conv2; };
+struct tv_mbconv_weights { packed_gemm conv1, conv3; packed_dw conv2; size_t conv3_frag = SIZE_MAX; }; // conv3_frag: vx_mbconv_pack_w3 image
 struct tv_merge_weights { packed_gemm conv1, conv3; packed_dw conv2; int stride = 2; };
 struct tv_block_weights {
     packed_vec attn_ln_w, attn_ln_b, bias; // bias: attention_biases_indexed packed f16 (vx_window_attention_pack_bias), n = f16 count
