@@ -473,7 +473,7 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
         res["roofline"]["share_of_step"] = round(dom["ms"] / tot, 3)
         res["roofline"]["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
         pmc = ROOT / "profiles" / "r01_pmc" / "traffic_sam.json"
-        key = {"depthwise_mbconv": "depthwise"}.get(dom["name"])
+        key = {"depthwise_mbconv": "depthwise", "mbconv_dw_pw": "mbconv_dw_pw"}.get(dom["name"])
         if key and pmc.exists():  # counters were collected at batch 16; the kernel's traffic is linear in the batch
             k = json.loads(pmc.read_text())["kernels"].get(key)
             if k:

@@ -289,6 +289,48 @@ __global__ __launch_bounds__(256) void tv_small_attention_kernel(const f16* __re
     }
 }
 
+// few keys (image -> token attention of the mask decoder: 4096 queries, 7 keys): one thread per (query, head), everything in registers
+constexpr int SA_FEW_KEYS = 16;
+__global__ __launch_bounds__(256) void tv_few_keys_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                                                                    f16* __restrict__ out, int Nq, int Nk, int H, int hd, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nq * H) return;
+    const int qi = i / H, h = i - qi * H;
+    const int C = H * hd;
+    float qv[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) qv[d] = d < hd ? (float)q[(long)qi * C + h * hd + d] * scale : 0.0f;
+    float s[SA_FEW_KEYS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SA_FEW_KEYS; ++j) {
+        s[j] = -INFINITY;
+        if (j < Nk) {
+            const f16* kr = k + (long)j * C + h * hd;
+            float a = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d)
+                if (d < hd) a = fmaf(qv[d], (float)kr[d], a);
+            s[j] = a;
+        }
+        m = fmaxf(m, s[j]);
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SA_FEW_KEYS; ++j) {
+        s[j] = __expf(s[j] - m); // exp(-inf) = 0 for the unused slots
+        sum += s[j];
+    }
+    const float inv = 1.0f / sum;
+    for (int d = 0; d < hd; ++d) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < SA_FEW_KEYS; ++j)
+            if (j < Nk) a = fmaf(s[j], (float)v[(long)j * C + h * hd + d], a);
+        out[(long)qi * C + h * hd + d] = (f16)(a * inv);
+    }
+}
+
 // ---- sam::interpolate_bilinear (mobile-sam.cpp:485-516): half-pixel centres, source clamped at 0 and extent - 1, for the two
 // passes of sam_process_mask (:556-583). src element i lives at src[i * step] (a column of the [pixels][8] mask GEMM output);
 // out_u8: threshold at 0 -> 0 / 255, else f32. Contraction is off so the coordinates round as in the reference's C++.
@@ -392,9 +434,14 @@ int vx_small_attention_f16(const void* q, const void* k, const void* v, void* ou
     VX_REQUIRE(q && k && v && out && Nq > 0 && Nk > 0 && heads > 0, "vx_small_attention_f16: bad operands");
     VX_REQUIRE(Nk <= SA_MAX_KEYS && hd > 0 && hd <= 32 && 256 % hd == 0, "vx_small_attention_f16: at most %d keys, head_dim a power of two <= 32 (Nk = %d, hd = %d)",
                SA_MAX_KEYS, Nk, hd);
-    hipLaunchKernelGGL(tv_small_attention_kernel, dim3((unsigned)Nq * heads), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
-                       reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), Nk, heads, hd,
-                       1.0f / sqrtf((float)hd));
+    if (Nk <= SA_FEW_KEYS && Nq >= 256)
+        hipLaunchKernelGGL(tv_few_keys_attention_kernel, dim3(blocks_for((long)Nq * heads)), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
+                           reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), Nq, Nk, heads, hd,
+                           1.0f / sqrtf((float)hd));
+    else
+        hipLaunchKernelGGL(tv_small_attention_kernel, dim3((unsigned)Nq * heads), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
+                           reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), Nk, heads, hd,
+                           1.0f / sqrtf((float)hd));
     VX_LAUNCH_CHECK();
     return 1;
 }
