@@ -22,14 +22,15 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         v[i] = xr[lane + 64 * i];
         sum += v[i].x + v[i].y;
     }
-    const float mean = wave_sum(sum) / (float)C;
+    const float inv_c = 1.0f / (float)C; // uniform: one scalar division per wave
+    const float mean = wave_sum(sum) * inv_c;
     float sq = 0.0f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         v[i].x -= mean; v[i].y -= mean;
         sq += v[i].x * v[i].x + v[i].y * v[i].y;
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(wave_sum(sq), inv_c, eps)); // v_rsq_f32: no IEEE division / sqrt sequence per lane
     const float2* wr = reinterpret_cast<const float2*>(w);
     const float2* br = reinterpret_cast<const float2*>(b);
     f16x2* yr = reinterpret_cast<f16x2*>(y + (long)row * C);
@@ -68,14 +69,15 @@ __global__ __launch_bounds__(256) void layernorm_resid_vec_kernel(float* __restr
         sum += v[i].x + v[i].y;
     }
     if (!y) return; // update only (no consumer of the normalised row)
-    const float mean = wave_sum(sum) / (float)C;
+    const float inv_c = 1.0f / (float)C; // uniform: one scalar division per wave
+    const float mean = wave_sum(sum) * inv_c;
     float sq = 0.0f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         v[i].x -= mean; v[i].y -= mean;
         sq += v[i].x * v[i].x + v[i].y * v[i].y;
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(wave_sum(sq), inv_c, eps)); // v_rsq_f32: no IEEE division / sqrt sequence per lane
     const float2* wr = reinterpret_cast<const float2*>(w);
     const float2* br = reinterpret_cast<const float2*>(b);
     f16x2* yr = reinterpret_cast<f16x2*>(y + (long)row * C);
@@ -97,10 +99,11 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
     const float* xr = x + (long)row * C;
     float sum = 0.0f;
     for (int c = lane; c < C; c += 64) sum += xr[c];
-    const float mean = wave_sum(sum) / (float)C;
+    const float inv_c = 1.0f / (float)C; // uniform: one scalar division per wave
+    const float mean = wave_sum(sum) * inv_c;
     float sq = 0.0f;
     for (int c = lane; c < C; c += 64) { float d = xr[c] - mean; sq += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(wave_sum(sq), inv_c, eps)); // v_rsq_f32: no IEEE division / sqrt sequence per lane
     for (int c = lane; c < C; c += 64) y[(long)row * C + c] = (f16)((xr[c] - mean) * rstd * w[c] + b[c]);
 }
 

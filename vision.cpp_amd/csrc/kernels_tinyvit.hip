@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void tv_layernorm_kernel(const f16* __restrict
     for (int j = 0; j < 8; ++j) sum += v[j];
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    const float mean = sum / (float)C;
+    const float inv_c = 1.0f / (float)C; // uniform
+    const float mean = sum * inv_c;
     float sq = 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void tv_layernorm_kernel(const f16* __restrict
     }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(sq, inv_c, eps)); // v_rsq_f32 instead of an IEEE division + sqrt per lane
     if (!live || !has) return;
     const float4 w0 = *reinterpret_cast<const float4*>(w + c0), w1 = *reinterpret_cast<const float4*>(w + c0 + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(b + c0), b1 = *reinterpret_cast<const float4*>(b + c0 + 4);
