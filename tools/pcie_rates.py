@@ -31,3 +31,13 @@ for _ in range(5):
     es.upscale_batch(small)
 dt = (time.perf_counter() - t0) / 5
 print(f"esrgan host API: {16 / dt:.0f} images/s ({dt * 1e3:.1f} ms per 16 images; 3.1 MB in, 67.1 MB out)")
+with tempfile.TemporaryDirectory() as td:
+    sm = Model.load(synth.write_tinyvit_gguf(Path(td) / "s.gguf", synth.TINYVIT_5M, 3), dev)
+big = synth.images(4, 1024, 1024, seed=3)
+big = __import__("numpy").concatenate([big] * 4)
+sm.sam_encode_batch(big)
+t0 = time.perf_counter()
+for _ in range(5):
+    sm.sam_encode_batch(big)
+dt = (time.perf_counter() - t0) / 5
+print(f"mobile-sam encoder host API: {16 / dt:.0f} images/s ({dt * 1e3:.1f} ms per 16 images; 50.3 MB in, 67.1 MB out)")
