@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["depthany", "esrgan", "sam"], default="depthany",
                     help="depthany = the headline metric (BASELINE.json configs[1]); esrgan = configs[2], the next SURVEY section 8 row")
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 for depthany, 16 for esrgan)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 for depthany, 16 for esrgan, 128 for sam)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=32, help="bounded CPU-baseline sample (about 10 s at 16 threads)")
@@ -382,7 +382,7 @@ def run_esrgan(args, torch, dist, rank, world, device_index, barrier, api):
 def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
     """A step = sam_encode's graph (mobile-sam.cpp:20-215: TinyViT-5M, 1024x1024 -> embedding [64, 64, 256]) for a batch of
     synthetic rgb_u8 images resident in HBM. Images are independent: ranks take whole images, no data-path collective."""
-    B, S = args.batch or 16, 1024
+    B, S = args.batch or 128, 1024  # configs[4]: a 1k-image batch over 8 GPUs = 128 images per GPU and step
     cfg = synth.TINYVIT_5M
     tmp = Path(tempfile.gettempdir()) / f"visp_bench_mobile_sam_f16_{os.environ.get('MASTER_PORT', '0')}.gguf"
     if rank == 0:
@@ -478,7 +478,7 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
             k = json.loads(pmc.read_text())["kernels"].get(key)
             if k:
                 res["roofline"]["traffic"] = round(k["hbm_bytes_per_launch"] * B / 16)
-                res["roofline"]["traffic_source"] = "profiles/r01_pmc/traffic_sam.json (FETCH_SIZE x2 + WRITE_SIZE, batch 16, scaled by batch)"
+                res["roofline"]["traffic_source"] = "profiles/r01_pmc/traffic_sam.json (FETCH_SIZE x2 + WRITE_SIZE, collected at batch 16, scaled by batch)"
         res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
     # configs[0] of BASELINE.json (encode + decode of one 1024x1024 image), outside the timed region: latency of the reference
     # API calls sam_encode / sam_compute from host buffers (decode = prompt encoder + mask decoder on the GPU + the reference's
