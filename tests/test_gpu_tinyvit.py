@@ -438,3 +438,21 @@ def test_fused_mbconv_second_half(B, H, W):
         d = _h(O.gelu(O.conv2d_depthwise_nhwc(h[i], w2, b2, 1, 1), O.GELU_TANH_F32))   # the tile is stored as f16 in LDS
         want = O.gelu(d.reshape(-1, Cc) @ w3.T + b3 + x[i].reshape(-1, Co), O.GELU_TANH_F32).reshape(H, W, Co)
         np.testing.assert_allclose(got[i], want, atol=5e-3, rtol=5e-3)
+
+
+@pytest.mark.parametrize("w,h", [(2000, 1500), (100, 60), (777, 1024)])
+def test_sam_pipeline_on_other_extents(sam_full, w, h):
+    """sam_process_input resizes the longest side to 1024 (image_scale) before the edge-replicated square: larger and smaller
+    inputs run through encode + decode and give a binary mask at the caller's extent; a box and a point prompt differ."""
+    from visioncpp_amd import synth
+    m = sam_full["model"]
+    img = synth.images(1, w, h, seed=w)[0]
+    assert img.shape == (h, w, 3)
+    point = m.compute(img, args=[w // 2, h // 2])
+    box = m.compute(img, args=[w // 8, h // 8, w - w // 8, h - h // 8])
+    for mask in (point, box):
+        assert mask.shape == (h, w) and mask.dtype == np.uint8 and set(np.unique(mask)) <= {0, 255}
+    _, iou = m.sam_read_masks()
+    assert np.isfinite(iou).all()
+    emb = m.sam_encode(img)
+    assert emb.shape == (64, 64, 256) and np.isfinite(emb).all() and 0.5 < emb.std() < 2.0   # LayerNorm-ed output
