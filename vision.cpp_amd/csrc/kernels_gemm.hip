@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
     constexpr int THREADS = WAVE * NWAVES;
     constexpr int A_INSTR = BM / (8 * NWAVES); // global_load_lds instructions per wave per k-tile (8 rows each)
     constexpr int B_INSTR = BN / (8 * NWAVES);
-    static_assert(A_INSTR >= 1 && B_INSTR >= 1 && (128 * (BN / 8)) % THREADS == 0, "tile / wave layout");
+    static_assert(A_INSTR >= 1 && B_INSTR >= 1 && (128 * (BN / 8)) % THREADS == 0 && THREADS >= BM, "tile / wave layout");
 
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int LOADS = A_INSTR + B_INSTR; // global_load_lds per wave per k-tile (vmcnt units)
@@ -90,6 +90,25 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
     // epilogue (16 dependent float4 loads per lane measured 10-30k cycles there)
     float* const s_bias = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);
     float* const s_lambda = s_bias + BN;
+    int* const s_pix = reinterpret_cast<int*>(s_lambda + BN); // VX_EPI_F16_ADD with win_ws: pixel row of every tile row, -1 = dropped
+    if constexpr (EPI == VX_EPI_F16_ADD) {
+        // window-order row m -> pixel row (window_reverse), once per tile row instead of six integer divisions per 16-byte chunk
+        if (p.win_ws > 0 && tid < BM) {
+            const int m = m0 + tid;
+            int pix = -1;
+            if (m < p.M) {
+                const int ws = p.win_ws, res = p.win_res, nw = (res + ws - 1) / ws, N = ws * ws;
+                const int in = m % N;
+                int wq = m / N;
+                const int wx = wq % nw;
+                wq /= nw;
+                const int wy = wq % nw, bb = wq / nw;
+                const int py = wy * ws + in / ws, px = wx * ws + in % ws;
+                if (py < res && px < res) pix = (bb * res + py) * res + px;
+            }
+            s_pix[tid] = pix;
+        }
+    }
     if (tid < BN) {
         s_bias[tid] = p.bias ? p.bias[n0 + tid] : 0.0f;
         if constexpr (EPI == VX_EPI_RESID_F32 || EPI == VX_EPI_HEAD_OUT) s_lambda[tid] = p.lambda[n0 + tid];
@@ -368,16 +387,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
                 *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + (long)m * p.ldo + n) = v;
             } else if constexpr (EPI == VX_EPI_F16_ADD) {
                 long o = (long)m * p.ldo + n;
-                if (p.win_ws > 0) { // window-order row m -> pixel row (window_reverse); rows of the zero padding are dropped
-                    const int ws = p.win_ws, res = p.win_res, nw = (res + ws - 1) / ws, N = ws * ws;
-                    const int in = m % N;
-                    int wq = m / N;
-                    const int wx = wq % nw;
-                    wq /= nw;
-                    const int wy = wq % nw, bb = wq / nw;
-                    const int py = wy * ws + in / ws, px = wx * ws + in % ws;
-                    if (py >= res || px >= res) continue;
-                    o = (((long)bb * res + py) * res + px) * p.ldo + n;
+                if (p.win_ws > 0) { // window_reverse: rows of the zero padding are dropped
+                    const int pix = s_pix[m - m0];
+                    if (pix < 0) continue;
+                    o = (long)pix * p.ldo + n;
                 }
                 if (p.res1) {
                     f16x8 a = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.res1) + o);
@@ -428,7 +441,7 @@ template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool CONV>
 int launch(const vx_gemm_args& a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * BK * 2;
     constexpr int out_stage = epi_is_f16_tile(EPI) ? 128 * BN * 2 : 0;
-    constexpr int smem = (ring > out_stage ? ring : out_stage) + 2 * BN * 4; // + bias / lambda side buffer
+    constexpr int smem = (ring > out_stage ? ring : out_stage) + 2 * BN * 4 + (EPI == VX_EPI_F16_ADD ? BM * 4 : 0); // + bias / lambda (+ pixel row) side buffers
     auto kern = gemm_kernel<BM, BN, WM, WN, STAGES, EPI, CONV>;
     if constexpr (smem > 48 * 1024) {
         static bool attr_set = false;
