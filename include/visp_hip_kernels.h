@@ -205,6 +205,34 @@ VX_API int vx_add_gelu_f16(const void* a, const void* b, void* y, int64_t n, voi
 VX_API int vx_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int T,
                             void* stream);
 
+/* ---- token-stationary DINOv2 block (kernels_block.hip; embed dim 384, mlp 1536, head dim 64) ------------------------------
+ * One launch per layer replaces everything between two attentions of dino::layer (src/visp/arch/dino.cpp:48-90):
+ *   att != NULL:  x += lambda1 * (att Wo^T + bo);  x += lambda2 * (gelu(LN2(x) W1^T + b1) W2^T + b2)
+ *   feat != NULL: feat = LN_final(x) as f16 rows (get_intermediate_layers, dino.cpp:100-107)
+ *   q != NULL:    q, k, v = LN1(x) Wqkv^T + b of the NEXT layer, head-major f16 [B, H, T, 64], q scaled by q_scale
+ * (att == NULL, q != NULL: the first layer's LN1 + QKV on x as it is.)
+ * att f16 [M, 384]; x f32 [M, 384] in place; weights as the slab streams of vx_dino_block_pack_mlp / _qkv;
+ * vec_mlp f32 = bo | lambda1 | ln2.w | ln2.b | b1[1536] | b2 | lambda2 (3840 floats), vec_qkv f32 = ln1.w | ln1.b | bqkv[1152]
+ * (1920 floats), vec_tap f32 = lnf.w | lnf.b (768 floats). M % T == 0 when q != NULL. */
+typedef struct {
+    const void* att; float* x;
+    const void* w_mlp; const float* vec_mlp;
+    const void* w_qkv; const float* vec_qkv;
+    const float* vec_tap; void* feat;
+    void *q, *k, *v;
+    int M, T, H;
+    float q_scale, eps;
+    float* cap_x1; /* tests only: f32 [M, 384] copy of x after the attention half; NULL in the product path */
+} vx_dino_block_args;
+VX_API int vx_dino_block_supported(int embed_dim, int hidden, int head_dim);
+VX_API size_t vx_dino_block_mlp_bytes(void);
+VX_API size_t vx_dino_block_qkv_bytes(void);
+/* host code: f16 row-major wo [384][384], w1 [1536][384], w2 [384][1536] -> out (vx_dino_block_mlp_bytes());
+ * wqkv [1152][384] (q rows, then k, then v) -> out (vx_dino_block_qkv_bytes()) */
+VX_API int vx_dino_block_pack_mlp(const void* wo, const void* w1, const void* w2, void* out);
+VX_API int vx_dino_block_pack_qkv(const void* wqkv, void* out);
+VX_API int vx_dino_block_f16(const vx_dino_block_args* args, void* stream);
+
 /* ---- LayerNorm (nn.cpp:14-19): x f32 [M,C] -> y f16 [M,C]; biased variance, eps in sqrt --- */
 VX_API int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y, int M, int C,
                                 float eps, void* stream);

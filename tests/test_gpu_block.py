@@ -1,0 +1,173 @@
+"""-m gpu: the token-stationary DINOv2 block kernel (csrc/kernels_block.hip, vx_dino_block_f16) against the CPU oracle's
+linear / layer_norm / gelu on the same seeded inputs, through the vx_* C ABI. Every output the kernel produces is
+compared: the residual stream after the attention half (capture), after the MLP half, the tapped LayerNorm rows and the
+next layer's head-major q / k / v. Tolerances are relative to the largest reference magnitude of each tensor."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from visioncpp_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import api, dev, empty, rel_err, release, sync  # noqa: E402
+
+D, HID, H = 384, 1536, 6
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    a = L.get_lib()
+    assert a.vx_device_count() > 0, "no HIP device visible: the product path has no CPU fallback"
+    L.vx_check(a.vx_set_device(0))
+    yield
+
+
+@pytest.fixture(autouse=True)
+def _release_buffers():
+    yield
+    release()
+
+
+def _h(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def make_weights(seed, lam=0.1):
+    rng = np.random.default_rng(seed)
+    r = lambda *s, scale=1.0: (rng.standard_normal(s) * scale).astype(np.float32)  # noqa: E731
+    w = dict(
+        wo=_h(r(D, D, scale=D ** -0.5)), bo=r(D, scale=0.1), lam1=np.full(D, lam, np.float32) + r(D, scale=0.01),
+        g2=1 + r(D, scale=0.05), b2=r(D, scale=0.05),
+        w1=_h(r(HID, D, scale=D ** -0.5)), b1=r(HID, scale=0.1), w2=_h(r(D, HID, scale=HID ** -0.5)), bfc2=r(D, scale=0.1),
+        lam2=np.full(D, lam, np.float32) + r(D, scale=0.01),
+        gn=1 + r(D, scale=0.05), bn=r(D, scale=0.05), wqkv=_h(r(3 * D, D, scale=D ** -0.5)), bqkv=r(3 * D, scale=0.1),
+        gf=1 + r(D, scale=0.05), bf=r(D, scale=0.05),
+    )
+    return w
+
+
+def pack(w):
+    a = api()
+    mlp = np.zeros(a.vx_dino_block_mlp_bytes() // 2, np.uint16)
+    qkv = np.zeros(a.vx_dino_block_qkv_bytes() // 2, np.uint16)
+    f16 = lambda m: np.ascontiguousarray(m.astype(np.float16))  # noqa: E731
+    wo, w1, w2, wq = f16(w["wo"]), f16(w["w1"]), f16(w["w2"]), f16(w["wqkv"])
+    L.vx_check(a.vx_dino_block_pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, mlp.ctypes.data))
+    L.vx_check(a.vx_dino_block_pack_qkv(wq.ctypes.data, qkv.ctypes.data))
+    vec_mlp = np.concatenate([w["bo"], w["lam1"], w["g2"], w["b2"], w["b1"], w["bfc2"], w["lam2"]]).astype(np.float32)
+    vec_qkv = np.concatenate([w["gn"], w["bn"], w["bqkv"]]).astype(np.float32)
+    vec_tap = np.concatenate([w["gf"], w["bf"]]).astype(np.float32)
+    assert vec_mlp.size == 3840 and vec_qkv.size == 1920 and vec_tap.size == 768
+    return dev(mlp), dev(qkv), dev(vec_mlp), dev(vec_qkv), dev(vec_tap)
+
+
+def reference(w, x, att, eps, mlp, tap, qkv, T, q_scale):
+    """dino.cpp:48-90 with the device's rounding points: LayerNorm rows and the hidden activations are rounded to f16
+    before the next product (they are MFMA operands), everything else stays f32."""
+    out = {}
+    if mlp:
+        x = x + w["lam1"] * oracle.linear(att, w["wo"], w["bo"])
+        out["x1"] = x.copy()
+        ln = _h(oracle.layer_norm(x, w["g2"], w["b2"], eps))
+        hid = _h(oracle.gelu(oracle.linear(ln, w["w1"], w["b1"]), oracle.GELU_TANH_F32))
+        x = x + w["lam2"] * oracle.linear(hid, w["w2"], w["bfc2"])
+    out["x"] = x
+    if tap:
+        out["feat"] = oracle.layer_norm(x, w["gf"], w["bf"], eps)
+    if qkv:
+        ln = _h(oracle.layer_norm(x, w["gn"], w["bn"], eps))
+        y = oracle.linear(ln, w["wqkv"], w["bqkv"])  # [M, 3D]
+        B = x.shape[0] // T
+        for i, name in enumerate("qkv"):
+            t = y[:, i * D:(i + 1) * D].reshape(B, T, H, 64).transpose(0, 2, 1, 3)  # head-major [B, H, T, 64]
+            out[name] = t * (q_scale if i == 0 else 1.0)
+    return out
+
+
+@pytest.mark.parametrize("M,T,mlp,tap,qkv", [
+    (128, 64, True, True, True),       # one full workgroup
+    (300, 75, True, False, True),      # tail workgroup: 44 valid rows, two waves with none; images straddle workgroups
+    (130, 65, True, True, False),      # last layer: tap, no next QKV
+    (257, 257, False, False, True),    # first layer: LN1 + QKV only
+    (1370 * 2, 1370, True, True, True),  # two images of the north-star grid
+])
+def test_block_vs_oracle(M, T, mlp, tap, qkv):
+    rng = np.random.default_rng(M * 7 + T)
+    w = make_weights(M + 1)
+    x0 = (rng.standard_normal((M, D)) * 1.5 + rng.standard_normal((1, D)) * 0.5).astype(np.float32)
+    att = _h(rng.standard_normal((M, D)).astype(np.float32))
+    eps, q_scale = 1e-6, 0.125
+    want = reference(w, x0, att, eps, mlp, tap, qkv, T, q_scale)
+
+    d_mlp, d_qkv, v_mlp, v_qkv, v_tap = pack(w)
+    xd = dev(x0)
+    attd = dev(att.astype(np.float16))
+    cap = empty(M * D * 4)
+    feat = empty(M * D * 2)
+    q, k, v = (empty(M * D * 2) for _ in range(3))
+    a = L.DinoBlockArgs()
+    a.x, a.M, a.T, a.H, a.q_scale, a.eps = xd.ptr, M, T, H, q_scale, eps
+    if mlp:
+        a.att, a.w_mlp, a.vec_mlp, a.cap_x1 = attd.ptr, d_mlp.ptr, v_mlp.ptr, cap.ptr
+    if tap:
+        a.feat, a.vec_tap = feat.ptr, v_tap.ptr
+    if qkv:
+        a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, d_qkv.ptr, v_qkv.ptr
+    L.vx_check(api().vx_dino_block_f16(C.byref(a), None))
+    sync()
+
+    got_x = xd.to_numpy(np.float32, (M, D))
+    # residual stream: f32, the branch contributions went through f16 operands (2^-11 relative each)
+    if mlp:
+        assert rel_err(cap.to_numpy(np.float32, (M, D)), want["x1"]) < 1e-3
+    assert rel_err(got_x, want["x"]) < 1e-3
+    if not mlp:
+        assert np.array_equal(got_x, x0), "the QKV-only instance must not touch the residual stream"
+    if tap:
+        assert rel_err(feat.to_numpy(np.float16, (M, D)).astype(np.float32), want["feat"]) < 2e-3
+    if qkv:
+        B = M // T
+        for name, buf in zip("qkv", (q, k, v)):
+            got = buf.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32)
+            assert rel_err(got, want[name]) < 4e-3, name
+
+
+def test_block_rows_are_independent():
+    """A row's results do not depend on which workgroup / wave / lane processes it: the same rows placed at another
+    offset of a larger problem give bit-identical outputs (the property the batch sharding relies on)."""
+    M1, M2, T = 192, 448, 64
+    rng = np.random.default_rng(5)
+    w = make_weights(9)
+    x = (rng.standard_normal((M2, D)) * 1.5).astype(np.float32)
+    att = rng.standard_normal((M2, D)).astype(np.float16)
+    d_mlp, d_qkv, v_mlp, v_qkv, v_tap = pack(w)
+
+    def run(xs, atts):
+        M = xs.shape[0]
+        xd, ad, feat = dev(xs), dev(atts), empty(M * D * 2)
+        q, k, v = (empty(M * D * 2) for _ in range(3))
+        a = L.DinoBlockArgs()
+        a.x, a.M, a.T, a.H, a.q_scale, a.eps = xd.ptr, M, T, H, 0.125, 1e-6
+        a.att, a.w_mlp, a.vec_mlp = ad.ptr, d_mlp.ptr, v_mlp.ptr
+        a.feat, a.vec_tap = feat.ptr, v_tap.ptr
+        a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, d_qkv.ptr, v_qkv.ptr
+        L.vx_check(api().vx_dino_block_f16(C.byref(a), None))
+        sync()
+        return xd.to_numpy(np.float32, (M, D)), feat.to_numpy(np.uint16, (M, D)), q.to_numpy(np.uint16, (M // T, H, T, 64))
+
+    xa, fa, qa = run(x, att)
+    xb, fb, qb = run(x[256:256 + M1], att[256:256 + M1])
+    assert np.array_equal(xa[256:256 + M1], xb) and np.array_equal(fa[256:256 + M1], fb)
+    assert np.array_equal(qa[4:7], qb)
+
+
+def test_block_argument_errors():
+    a = L.DinoBlockArgs()
+    assert api().vx_dino_block_f16(C.byref(a), None) == 0  # empty problem
+    x = empty(128 * D * 4)
+    a.x, a.M = x.ptr, 128
+    assert api().vx_dino_block_f16(C.byref(a), None) == 0 and b"nothing to do" in api().vx_last_error()
+    assert api().vx_dino_block_supported(384, 1536, 64) == 1 and api().vx_dino_block_supported(768, 3072, 64) == 0

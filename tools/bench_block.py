@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the token-stationary DINOv2 block kernel (vx_dino_block_f16) at the north-star shape
+(M = 32 x 1370 tokens), next to the launches it replaces (LayerNorm + QKV / out-proj / fc1 / fc2 GEMMs)."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from bench_kernels import api, gemm_case, stream, timeit, L, DeviceBuffer  # noqa: E402
+
+D, HID, H, T = 384, 1536, 6, 1370
+
+
+def block_case(B, mlp=True, tap=False, qkv=True):
+    M = B * T
+    rng = np.random.default_rng(0)
+    f16 = lambda *s, sc=1.0: np.ascontiguousarray((rng.standard_normal(s) * sc).astype(np.float16))  # noqa: E731
+    wo, w1, w2, wq = f16(D, D, sc=D ** -0.5), f16(HID, D, sc=D ** -0.5), f16(D, HID, sc=HID ** -0.5), f16(3 * D, D, sc=D ** -0.5)
+    pm = np.zeros(api.vx_dino_block_mlp_bytes() // 2, np.uint16)
+    pq = np.zeros(api.vx_dino_block_qkv_bytes() // 2, np.uint16)
+    L.vx_check(api.vx_dino_block_pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, pm.ctypes.data))
+    L.vx_check(api.vx_dino_block_pack_qkv(wq.ctypes.data, pq.ctypes.data))
+    vm = np.concatenate([rng.standard_normal(384) * .1, np.full(384, .1), np.ones(384), np.zeros(384), rng.standard_normal(1536) * .1,
+                         rng.standard_normal(384) * .1, np.full(384, .1)]).astype(np.float32)
+    vq = np.concatenate([np.ones(384), np.zeros(384), rng.standard_normal(1152) * .1]).astype(np.float32)
+    vt = np.concatenate([np.ones(384), np.zeros(384)]).astype(np.float32)
+    bufs = [DeviceBuffer.from_numpy(a) for a in (pm, pq, vm, vq, vt)]
+    x = DeviceBuffer.from_numpy(rng.standard_normal((M, D)).astype(np.float32))
+    att = DeviceBuffer.from_numpy(f16(M, D))
+    feat = DeviceBuffer(M * D * 2)
+    q, k, v = (DeviceBuffer(M * D * 2) for _ in range(3))
+    a = L.DinoBlockArgs()
+    a.x, a.M, a.T, a.H, a.q_scale, a.eps = x.ptr, M, T, H, 0.125, 1e-6
+    if mlp:
+        a.att, a.w_mlp, a.vec_mlp = att.ptr, bufs[0].ptr, bufs[2].ptr
+    if tap:
+        a.feat, a.vec_tap = feat.ptr, bufs[4].ptr
+    if qkv:
+        a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, bufs[1].ptr, bufs[3].ptr
+    ms = timeit(lambda: L.vx_check(api.vx_dino_block_f16(C.byref(a), stream)))
+    flops = 2.0 * M * D * ((D + 2 * HID) * mlp + 3 * D * qkv)
+    print(f"dino_block B={B} M={M} mlp={int(mlp)} tap={int(tap)} qkv={int(qkv)}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  ({-(-M // 128)} workgroups)", flush=True)
+    return ms
+
+
+if __name__ == "__main__":
+    for rnd in range(2):
+        block_case(23)          # 247 workgroups: one round on 256 CUs
+        block_case(32)          # 343 workgroups: the north-star batch, two rounds
+        block_case(32, tap=True)
+        block_case(32, mlp=False)
+        block_case(32, qkv=False, tap=True)
+    if "--gemms" in sys.argv:
+        M = 32 * T
+        gemm_case("qkv", M, 1152, 384, L.EPI_QKV, 0)
+        gemm_case("fc1_gelu", M, 1536, 384, L.EPI_F16_GELU, 0)
+        gemm_case("fc2_resid", M, 384, 1536, L.EPI_RESID_F32, 0)
+        gemm_case("out_resid", M, 384, 384, L.EPI_RESID_F32, 0)

@@ -69,6 +69,14 @@ class GemmArgs(ctypes.Structure):  # == vx_gemm_args
     ]
 
 
+class DinoBlockArgs(ctypes.Structure):  # == vx_dino_block_args
+    _fields_ = [
+        ("att", c_void_p), ("x", c_void_p), ("w_mlp", c_void_p), ("vec_mlp", c_void_p), ("w_qkv", c_void_p), ("vec_qkv", c_void_p),
+        ("vec_tap", c_void_p), ("feat", c_void_p), ("q", c_void_p), ("k", c_void_p), ("v", c_void_p),
+        ("M", c_int), ("T", c_int), ("H", c_int), ("q_scale", c_float), ("eps", c_float), ("cap_x1", c_void_p),
+    ]
+
+
 EPI_F16, EPI_F16_GELU, EPI_F16_RELU, EPI_RESID_F32, EPI_TOKENS, EPI_QKV, EPI_PIXSHUF, EPI_F16_ADD, EPI_HEAD_OUT = range(9)
 
 import os
@@ -103,6 +111,7 @@ KERNEL_SYMBOLS = [
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
     "vx_dconv3x3_f16", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
     "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_mbconv_dw_pw_supported", "vx_mbconv_pack_w3", "vx_mbconv_dw_pw_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
+    "vx_dino_block_supported", "vx_dino_block_mlp_bytes", "vx_dino_block_qkv_bytes", "vx_dino_block_pack_mlp", "vx_dino_block_pack_qkv", "vx_dino_block_f16",
 ]
 
 
@@ -234,6 +243,14 @@ def init() -> ctypes.CDLL:
     lib.vx_esrgan_tiles_out.argtypes = [c_void_p, c_int, POINTER(TileLayout), c_void_p, c_void_p, c_void_p]
     for name in KERNEL_SYMBOLS[1:]:
         getattr(lib, name).restype = c_int
+    lib.vx_dino_block_supported.argtypes = [c_int, c_int, c_int]
+    lib.vx_dino_block_mlp_bytes.argtypes = []
+    lib.vx_dino_block_mlp_bytes.restype = c_size_t
+    lib.vx_dino_block_qkv_bytes.argtypes = []
+    lib.vx_dino_block_qkv_bytes.restype = c_size_t
+    lib.vx_dino_block_pack_mlp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.vx_dino_block_pack_qkv.argtypes = [c_void_p, c_void_p]
+    lib.vx_dino_block_f16.argtypes = [POINTER(DinoBlockArgs), c_void_p]
     return lib
 
 

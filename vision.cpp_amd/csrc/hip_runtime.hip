@@ -3,6 +3,8 @@
 #include "vx_common.h"
 
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_vx_error[512];
 
@@ -11,6 +13,27 @@ void vx_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_vx_error, sizeof g_vx_error, fmt, ap);
     va_end(ap);
+}
+
+hipError_t vx_ensure_dynamic_lds(const void* kernel, int bytes) {
+    // (kernel, device) pairs already raised to `bytes`; a handful of kernels x up to 8 devices
+    struct entry { const void* kernel; int device; int bytes; };
+    static std::mutex mu;
+    static std::vector<entry> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (entry& d : done)
+        if (d.kernel == kernel && d.device == dev) {
+            if (d.bytes >= bytes) return hipSuccess;
+            e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess) d.bytes = bytes;
+            return e;
+        }
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.push_back({kernel, dev, bytes});
+    return e;
 }
 
 extern "C" {

@@ -664,12 +664,8 @@ constexpr int dconv_smem_bytes() { return HSV * (5 * NW * 1024) + (RES ? RES : 2
 template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2)>
 int prepare_variant() { // > 64 KB of dynamic LDS needs the attribute; set once, outside any stream capture
     static_assert(dconv_smem_bytes<COUT, RES, HSV>() <= 160 * 1024, "variant does not fit the LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, dconv_smem_bytes<COUT, RES, HSV>()));
-        attr_set = true;
-    }
+    VX_CHECK(vx_ensure_dynamic_lds(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV>),
+                                   dconv_smem_bytes<COUT, RES, HSV>())); // per (kernel, device), not per process
     return 1;
 }
 

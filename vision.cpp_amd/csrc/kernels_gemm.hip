@@ -443,13 +443,7 @@ int launch(const vx_gemm_args& a, hipStream_t s) {
     constexpr int out_stage = epi_is_f16_tile(EPI) ? 128 * BN * 2 : 0;
     constexpr int smem = (ring > out_stage ? ring : out_stage) + 2 * BN * 4 + (EPI == VX_EPI_F16_ADD ? BM * 4 : 0); // + bias / lambda (+ pixel row) side buffers
     auto kern = gemm_kernel<BM, BN, WM, WN, STAGES, EPI, CONV>;
-    if constexpr (smem > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            VX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
-        }
-    }
+    if constexpr (smem > 48 * 1024) VX_CHECK(vx_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem)); // per (kernel, device)
     int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * (BM / WM) * (BN / WN)), smem, s, a);
     VX_LAUNCH_CHECK();
