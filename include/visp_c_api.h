@@ -103,6 +103,9 @@ VISP_API int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* 
 /* capture the launch sequence of the current reserved shape into a hipGraph and replay it on
  * every later compute of that shape (enable = 0 turns it off) */
 VISP_API int32_t visp_depthany_use_graph(visp_model* m, int32_t enable);
+/* encoder schedule: 0 = one launch per op group (default), 1 = one attention + one token-stationary block launch per layer
+ * (csrc/kernels_block.hip; models with embed dim 384 / mlp 1536 / head dim 64 only). Results agree to f16 rounding. */
+VISP_API int32_t visp_depthany_set_schedule(visp_model* m, int32_t schedule);
 
 /* Named intermediate tensors of the last compute, converted to f32 on the host (parity tests;
  * the reference's counterpart is the workbench capture, tests/workbench.cpp:754-760).

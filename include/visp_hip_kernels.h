@@ -223,6 +223,7 @@ typedef struct {
     int M, T, H;
     float q_scale, eps;
     float* cap_x1; /* tests only: f32 [M, 384] copy of x after the attention half; NULL in the product path */
+    void* stamps;  /* diagnostics only: u64 [workgroups][16] s_memtime at the phase boundaries; NULL in the product path */
 } vx_dino_block_args;
 VX_API int vx_dino_block_supported(int embed_dim, int hidden, int head_dim);
 VX_API size_t vx_dino_block_mlp_bytes(void);

@@ -86,6 +86,32 @@ def test_mini_every_module_boundary(mini):
         assert np.abs(out[b] - norm).mean() < 1e-3, "north-star bar: MAE < 1e-3 on the normalised depth"
 
 
+def test_short_every_module_boundary(device, tmp_path):
+    """The block-kernel schedule (embed dim 384: csrc/kernels_block.hip, one launch per layer between two attentions)
+    at every encoder boundary, as the mini test does for the GEMM schedule; two taps name the last layer."""
+    cfg = synth.SHORT
+    model = vision.Model.load(synth.write_gguf(tmp_path / "short.gguf", cfg, seed=8), device)
+    om, params = _oracle(cfg, 8)
+    imgs = synth.images(3, 112, 112, seed=21)
+    plain = model.compute_batch(imgs)  # default schedule (GEMM launches)
+    model.set_schedule(1)
+    model.enable_captures(True)
+    out, raw = model.compute_batch(imgs, return_raw=True)
+    model.enable_captures(False)
+    names = ["tokens"] + [f"layer_{i}" for i in range(3)] + [f"dino_layer_{i}" for i in range(3)] + [f"fusion_{i}" for i in range(4)] + ["depth"]
+    for b in range(3):
+        caps = {n: 1 << 22 for n in names}
+        depth, want = om.predict(params, _pre(imgs[b]), caps)
+        for n in names:
+            err = _rel(model.read_capture(n)[b].ravel(), want[n])
+            assert err < 2e-2, f"{n} image {b}: rel err {err}"
+        assert np.abs(out[b] - oracle.image_normalize(depth)).mean() < 1e-3
+    # the two schedules agree to f16 rounding of the intermediates
+    assert np.abs(plain - out).mean() < 5e-4
+    model.set_schedule(0)
+    np.testing.assert_array_equal(model.compute_batch(imgs), plain)
+
+
 def test_mini_matches_huggingface_fixture(mini, golden_dir):
     g = np.load(golden_dir / "depthany_mini.npz")
     img = synth.images(1, 112, 112, seed=int(g["image_seed"]))

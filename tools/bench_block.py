@@ -45,7 +45,7 @@ def block_case(B, mlp=True, tap=False, qkv=True):
     return ms
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--stamps" not in sys.argv:
     for rnd in range(2):
         block_case(23)          # 247 workgroups: one round on 256 CUs
         block_case(32)          # 343 workgroups: the north-star batch, two rounds
@@ -58,3 +58,52 @@ if __name__ == "__main__":
         gemm_case("fc1_gelu", M, 1536, 384, L.EPI_F16_GELU, 0)
         gemm_case("fc2_resid", M, 384, 1536, L.EPI_RESID_F32, 0)
         gemm_case("out_resid", M, 384, 384, L.EPI_RESID_F32, 0)
+
+
+def block_stamps(B):
+    """Per-workgroup phase anatomy from in-kernel s_memtime stamps (diagnostic)."""
+    M = B * T
+    rng = np.random.default_rng(0)
+    f16 = lambda *s, sc=1.0: np.ascontiguousarray((rng.standard_normal(s) * sc).astype(np.float16))  # noqa: E731
+    wo, w1, w2, wq = f16(D, D, sc=D ** -0.5), f16(HID, D, sc=D ** -0.5), f16(D, HID, sc=HID ** -0.5), f16(3 * D, D, sc=D ** -0.5)
+    pm = np.zeros(api.vx_dino_block_mlp_bytes() // 2, np.uint16)
+    pq = np.zeros(api.vx_dino_block_qkv_bytes() // 2, np.uint16)
+    L.vx_check(api.vx_dino_block_pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, pm.ctypes.data))
+    L.vx_check(api.vx_dino_block_pack_qkv(wq.ctypes.data, pq.ctypes.data))
+    vm = np.concatenate([np.zeros(384), np.full(384, .1), np.ones(384), np.zeros(384), np.zeros(1536), np.zeros(384), np.full(384, .1)]).astype(np.float32)
+    vq = np.concatenate([np.ones(384), np.zeros(384), np.zeros(1152)]).astype(np.float32)
+    bufs = [DeviceBuffer.from_numpy(a) for a in (pm, pq, vm, vq)]
+    x = DeviceBuffer.from_numpy(rng.standard_normal((M, D)).astype(np.float32))
+    att = DeviceBuffer.from_numpy(f16(M, D))
+    q, k, v = (DeviceBuffer(M * D * 2) for _ in range(3))
+    nblk = -(-M // 128)
+    st = DeviceBuffer(nblk * 128)
+    st.zero()
+    a = L.DinoBlockArgs()
+    a.x, a.M, a.T, a.H, a.q_scale, a.eps = x.ptr, M, T, H, 0.125, 1e-6
+    a.att, a.w_mlp, a.vec_mlp = att.ptr, bufs[0].ptr, bufs[2].ptr
+    a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, bufs[1].ptr, bufs[3].ptr
+    for _ in range(50):
+        L.vx_check(api.vx_dino_block_f16(C.byref(a), stream))
+    a.stamps = st.ptr
+    L.vx_check(api.vx_dino_block_f16(C.byref(a), stream))
+    L.vx_check(api.vx_stream_sync(stream))
+    t = st.to_numpy(np.uint64, (nblk, 16)).astype(np.int64)
+    names = ["prologue (att, vectors, slabs 0-3)", "to first tile", "out-proj 12 tiles", "LN2", "MLP 96 slabs", "fc2 epilogue (x re-read, write)",
+             "LN stats", "(tap)", "LN1 -> frags", "QKV 36 tiles"]
+    print(f"--- dino_block B={B}: {nblk} workgroups; span {t[:, 10].max() - t[:, 0].min()} ticks")
+    for i, nm in enumerate(names):
+        d = t[:, i + 1] - t[:, i]
+        print(f"   {nm:36s} median {np.median(d):9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}")
+    life = t[:, 10] - t[:, 0]
+    print(f"   {'workgroup lifetime':36s} median {np.median(life):9.0f}  p10 {np.percentile(life, 10):9.0f}  p90 {np.percentile(life, 90):9.0f}")
+    rt = (t[:, 15] - t[:, 14]).astype(np.float64)
+    ok = rt > 0
+    print(f"   shader clock: median {np.median(life[ok] / rt[ok] * 100.0):.0f} MHz")
+    starts = np.sort(t[:, 0] - t[:, 0].min())
+    print("   start ticks (deciles):", [int(np.percentile(starts, p)) for p in range(0, 101, 10)])
+
+
+if __name__ == "__main__" and "--stamps" in sys.argv:
+    block_stamps(23)
+    block_stamps(32)

@@ -73,7 +73,7 @@ class DinoBlockArgs(ctypes.Structure):  # == vx_dino_block_args
     _fields_ = [
         ("att", c_void_p), ("x", c_void_p), ("w_mlp", c_void_p), ("vec_mlp", c_void_p), ("w_qkv", c_void_p), ("vec_qkv", c_void_p),
         ("vec_tap", c_void_p), ("feat", c_void_p), ("q", c_void_p), ("k", c_void_p), ("v", c_void_p),
-        ("M", c_int), ("T", c_int), ("H", c_int), ("q_scale", c_float), ("eps", c_float), ("cap_x1", c_void_p),
+        ("M", c_int), ("T", c_int), ("H", c_int), ("q_scale", c_float), ("eps", c_float), ("cap_x1", c_void_p), ("stamps", c_void_p),
     ]
 
 
@@ -91,7 +91,7 @@ C_API_SYMBOLS = [
     "visp_model_destroy", "visp_model_compute",
     "visp_hip_device_init", "visp_model_load_ex", "visp_depthany_weights_arena", "visp_depthany_weights_ready",
     "visp_depthany_get_info", "visp_depthany_image_extent", "visp_depthany_reserve",
-    "visp_depthany_compute_batch_device", "visp_depthany_compute_batch_host", "visp_depthany_use_graph",
+    "visp_depthany_compute_batch_device", "visp_depthany_compute_batch_host", "visp_depthany_use_graph", "visp_depthany_set_schedule",
     "visp_depthany_enable_captures", "visp_depthany_read_capture", "visp_depthany_enable_timing",
     "visp_depthany_read_timing",
     "visp_esrgan_get_info", "visp_esrgan_set_tile_group", "visp_esrgan_weights_arena", "visp_esrgan_weights_ready",
@@ -160,6 +160,7 @@ def init() -> ctypes.CDLL:
     lib.visp_depthany_compute_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.visp_depthany_compute_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.visp_depthany_use_graph.argtypes = [c_void_p, c_int32]
+    lib.visp_depthany_set_schedule.argtypes = [c_void_p, c_int32]
     lib.visp_depthany_enable_captures.argtypes = [c_void_p, c_int32]
     lib.visp_depthany_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
     lib.visp_depthany_enable_timing.argtypes = [c_void_p, c_int32]

@@ -272,6 +272,19 @@ int32_t visp_depthany_use_graph(visp_model* m, int32_t enable) {
     });
 }
 
+int32_t visp_depthany_set_schedule(visp_model* m, int32_t schedule) {
+    return handle_errors([&]() {
+        depthany_model& dm = as_depthany(m);
+        if (schedule != 0 && schedule != 1) throw except("visp_depthany_set_schedule: unknown schedule %d (0 = GEMM launches, 1 = token-stationary block kernel)", schedule);
+        if (schedule == 1 && !dm.weights.use_block) throw except("visp_depthany_set_schedule: the block kernel is built for embed dim 384 / mlp 1536 / head dim 64 only");
+        dm.force_block = schedule == 1;
+        if (dm.ws.graph_exec) { // the captured launch sequence belongs to the other schedule
+            vx_graph_destroy(dm.ws.graph_exec);
+            dm.ws.graph_exec = nullptr;
+        }
+    });
+}
+
 int32_t visp_depthany_enable_captures(visp_model* m, int32_t enable) {
     return handle_errors([&]() { as_depthany(m).captures = enable != 0; });
 }

@@ -160,6 +160,31 @@ struct packer {
         return matrix(with_data ? wf.data() : nullptr, N, K, b && with_data ? bf.data() : nullptr, b ? N : 0, n_align);
     }
 
+    // unpadded f16 rows [N][K] of a linear weight (as stored in the file when it is f16) and its f32 bias
+    void linear_rows(std::string const& prefix, std::vector<uint16_t>& rows, std::vector<float>& bias, int& N, int& K) {
+        gguf_tensor const& w = file.tensor(prefix + ".weight");
+        K = (int)w.ne[0]; N = (int)w.ne[1];
+        if (!with_data) return;
+        std::vector<float> wf = to_f32(w), bf = to_f32(file.tensor(prefix + ".bias"));
+        size_t r0 = rows.size();
+        rows.resize(r0 + wf.size());
+        for (size_t i = 0; i < wf.size(); ++i) rows[r0 + i] = f32_to_f16(wf[i]);
+        bias.insert(bias.end(), bf.begin(), bf.end());
+    }
+    void append_vec(std::vector<float>& dst, std::string const& name) {
+        if (!with_data) return;
+        std::vector<float> v = to_f32(file.tensor(name));
+        dst.insert(dst.end(), v.begin(), v.end());
+    }
+    size_t put_floats(std::vector<float> const& v, size_t n) {
+        size_t off = ab.alloc(n * 4);
+        if (with_data) {
+            if (v.size() != n) throw except("internal: packed vector has %zu floats, expected %zu", v.size(), n);
+            memcpy(ab.data.data() + off, v.data(), n * 4);
+        }
+        return off;
+    }
+
     // three linears concatenated along N (fused QKV projection)
     packed_gemm linear3(std::string const& a, std::string const& b, std::string const& c) {
         gguf_tensor const& wa = file.tensor(a + ".weight");
@@ -300,6 +325,43 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
     }
     Wt.final_ln_w = pk.vec("backbone.layernorm.weight");
     Wt.final_ln_b = pk.vec("backbone.layernorm.bias");
+    // second packing of the encoder for the block kernel (kernels_block.hip): slab streams in the kernel's order of use
+    Wt.use_block = P.dino.n_layers > 0 && vx_dino_block_supported(D, Wt.layers[0].fc1.n_real, D / P.dino.n_heads) != 0;
+    if (Wt.use_block) {
+        for (int i = 0; i < P.dino.n_layers; ++i) {
+            std::string p = "backbone.encoder.layer." + std::to_string(i);
+            dino_layer_weights& L = Wt.layers[i];
+            std::vector<uint16_t> wo, w1, w2, wqkv;
+            std::vector<float> bo, b1, b2, bqkv, vm, vq;
+            int N, K;
+            pk.linear_rows(p + ".attention.output.dense", wo, bo, N, K);
+            pk.linear_rows(p + ".mlp.fc1", w1, b1, N, K);
+            pk.linear_rows(p + ".mlp.fc2", w2, b2, N, K);
+            for (const char* n : {".attention.attention.query", ".attention.attention.key", ".attention.attention.value"}) pk.linear_rows(p + n, wqkv, bqkv, N, K);
+            L.blk_mlp = ab.alloc(vx_dino_block_mlp_bytes());
+            L.blk_qkv = ab.alloc(vx_dino_block_qkv_bytes());
+            if (with_data) {
+                VX(vx_dino_block_pack_mlp(wo.data(), w1.data(), w2.data(), ab.data.data() + L.blk_mlp));
+                VX(vx_dino_block_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
+                vm = bo;
+                pk.append_vec(vm, p + ".layer_scale1.lambda1");
+                pk.append_vec(vm, p + ".norm2.weight");
+                pk.append_vec(vm, p + ".norm2.bias");
+                vm.insert(vm.end(), b1.begin(), b1.end());
+                vm.insert(vm.end(), b2.begin(), b2.end());
+                pk.append_vec(vm, p + ".layer_scale2.lambda1");
+                pk.append_vec(vq, p + ".norm1.weight");
+                pk.append_vec(vq, p + ".norm1.bias");
+                vq.insert(vq.end(), bqkv.begin(), bqkv.end());
+            }
+            L.vec_mlp = pk.put_floats(vm, (size_t)7 * D + Wt.layers[0].fc1.n_real - D); // bo l1 g2 b2 | b1 | bfc2 l2
+            L.vec_qkv = pk.put_floats(vq, (size_t)5 * D);
+        }
+        std::vector<float> vt;
+        pk.append_vec(vt, "backbone.layernorm.weight");
+        pk.append_vec(vt, "backbone.layernorm.bias");
+        Wt.vec_tap = pk.put_floats(vt, (size_t)2 * D);
+    }
 
     const std::string r = "neck.reassemble_stage.layers.";
     for (int i = 0; i < 4; ++i) {
@@ -707,7 +769,74 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         tap_due = -1;
         tap_due_n = 0;
     };
-    for (int i = 0; i < P.dino.n_layers; ++i) {
+    // Token-stationary schedule (kernels_block.hip): per layer one attention launch and ONE block launch that does the
+    // output projection, both residual updates, LN2 + MLP, the tap's final LayerNorm and the next layer's LN1 + QKV for
+    // 128 token rows per workgroup with everything but the weights in registers. Parity-green but, measured on MI355X, not yet
+    // faster than the GEMM schedule (381 vs 363 us per layer at batch 32, profiles/r02_block_kernel_anatomy.txt): opt-in with
+    // VISP_BLOCK=1 or visp_depthany_set_schedule(model, 1).
+    static const bool block_on = getenv("VISP_BLOCK") != nullptr;
+    const bool use_block = Wt.use_block && (block_on || m.force_block);
+    if (use_block) {
+        const int hid = Wt.layers[0].fc1.n_real;
+        auto block = [&](int li_mlp, int li_qkv, void* feat, const char* group) {
+            vx_dino_block_args a;
+            memset(&a, 0, sizeof a);
+            a.x = x; a.M = (int)M; a.T = T; a.H = NH; a.q_scale = q_scale; a.eps = 1e-6f;
+            double flops = 0, bytes = 0;
+            if (li_mlp >= 0) {
+                a.att = c.buf("att");
+                a.w_mlp = c.wptr(Wt.layers[li_mlp].blk_mlp);
+                a.vec_mlp = reinterpret_cast<const float*>(c.wptr(Wt.layers[li_mlp].vec_mlp));
+                flops += 2.0 * M * D * (D + 2.0 * hid);
+                bytes += (double)M * D * (2 + 4 * 4); // att in; x read, written, re-read, written
+            } else {
+                bytes += (double)M * D * 4;
+            }
+            if (li_qkv >= 0) {
+                a.q = c.buf("q"); a.k = c.buf("k"); a.v = c.buf("vt");
+                a.w_qkv = c.wptr(Wt.layers[li_qkv].blk_qkv);
+                a.vec_qkv = reinterpret_cast<const float*>(c.wptr(Wt.layers[li_qkv].vec_qkv));
+                flops += 2.0 * M * D * 3.0 * D;
+                bytes += (double)M * D * 2 * 3;
+            }
+            if (feat) {
+                a.feat = feat;
+                a.vec_tap = reinterpret_cast<const float*>(c.wptr(Wt.vec_tap));
+                bytes += (double)M * D * 2;
+            }
+            c.mark(group, 1, flops, bytes);
+            VX(vx_dino_block_f16(&a, stream));
+        };
+        block(-1, 0, nullptr, "block_qkv0");
+        int tap = 0;
+        for (int i = 0; i < P.dino.n_layers; ++i) {
+            c.mark("attention", 1, 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
+            VX(vx_attention_f16(c.buf("q"), c.buf("k"), c.buf("vt"), c.buf("att"), B, NH, T, stream));
+            // get_intermediate_layers (dino.cpp:100-107): every tap that names this layer (the first one is written by the kernel)
+            void* first = nullptr;
+            int tap0 = tap;
+            for (int f = 0; f < 4; ++f)
+                if (P.feature_layers[f] == i && tap < 4) {
+                    std::string fb = "feat" + std::to_string(tap++);
+                    if (!first) first = c.buf(fb.c_str());
+                }
+            block(i, i + 1 < P.dino.n_layers ? i + 1 : -1, first, "block");
+            for (int t2 = tap0 + 1; t2 < tap; ++t2) {
+                std::string fb = "feat" + std::to_string(t2);
+                VX(vx_memcpy_d2d(c.buf(fb.c_str()), first, (size_t)M * D * 2, stream));
+            }
+            if (m.captures) {
+                std::string nm = "layer_" + std::to_string(i);
+                c.capture(nm.c_str(), x, {B, T, D, 1}, false);
+                for (int t2 = tap0; t2 < tap; ++t2) {
+                    std::string fb = "feat" + std::to_string(t2), dn = "dino_layer_" + std::to_string(i);
+                    c.capture(dn.c_str(), c.buf(fb.c_str()), {B, T, D, 1}, true);
+                }
+            }
+        }
+        if (tap != 4) throw except("depthany: expected 4 feature layers, found %d", tap);
+    }
+    for (int i = 0; i < (use_block ? 0 : P.dino.n_layers); ++i) {
         dino_layer_weights const& L = Wt.layers[i];
         layernorm(c.fptr(L.ln1_w), c.fptr(L.ln1_b), ln); // applies the previous layer's fc2 residual
         if (tap_due >= 0) run_tap();                        // x of the tapped previous layer is complete now
@@ -745,7 +874,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
             if (!pending || i + 1 == P.dino.n_layers) run_tap();
         }
     }
-    if (tap != 4) throw except("depthany: expected 4 feature layers, found %d", tap);
+    if (!use_block && tap != 4) throw except("depthany: expected 4 feature layers, found %d", tap);
 
     // ---- dpt::neck reassemble (depth-anything.cpp:44-64)
     const int lh[4] = {4 * ph, 2 * ph, ph, (ph + 2 - 3) / 2 + 1};

@@ -58,6 +58,9 @@ struct packed_vec { size_t off = SIZE_MAX; int n = 0; }; // f32 vector
 struct dino_layer_weights {
     packed_vec ln1_w, ln1_b, ln2_w, ln2_b, lambda1, lambda2;
     packed_gemm qkv, out, fc1, fc2;
+    // operands of the token-stationary block kernel (kernels_block.hip), when the model has its shape: weight slab streams
+    // (out-proj + mlp; qkv) and the per-feature vectors bo|lambda1|ln2.w|ln2.b|b1|b2|lambda2 and ln1.w|ln1.b|bqkv
+    size_t blk_mlp = SIZE_MAX, blk_qkv = SIZE_MAX, vec_mlp = SIZE_MAX, vec_qkv = SIZE_MAX;
 };
 struct fusion_weights {
     packed_gemm proj, rl1_c1, rl1_c2, rl2_c1, rl2_c2;
@@ -68,6 +71,8 @@ struct depthany_weights {
     int pos_tokens = 0;
     std::vector<dino_layer_weights> layers;
     packed_vec final_ln_w, final_ln_b;
+    bool use_block = false;   // embed dim 384 / mlp 1536 / head dim 64: one launch per layer between two attentions
+    size_t vec_tap = SIZE_MAX; // final layernorm w|b for the block kernel's tap
     std::array<packed_gemm, 4> re_proj;
     packed_gemm re_up0, re_up1, re_down3; // convT k4s4, convT k2s2, conv3x3 s2
     std::array<int, 4> neck_c{};          // real channel counts of the reassembled maps
@@ -110,6 +115,7 @@ struct depthany_model : model_base { // vision.h:339-347 counterpart
     bool weights_uploaded = false;
     depthany_workspace ws;
     bool use_graph = false, captures = false, timing = false;
+    bool force_block = false; // run the encoder through the token-stationary block kernel (experimental schedule)
     std::map<std::string, capture_entry> capture_bufs;
     std::vector<timing_entry> last_timing;
     // the four reassemble/neck-conv branches are independent until the fusion stage: they run on side

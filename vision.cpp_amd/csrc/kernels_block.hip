@@ -28,6 +28,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -85,8 +86,16 @@ __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
 // output tile). __builtin_amdgcn_sched_barrier(0) closes every slot: left alone, hipcc issues ds_read -> wait ->
 // MFMA with a single fragment register set and puts all VALU work after the MFMAs.
 constexpr int PF = 4;
-constexpr int SMEM_RING = 3 * SLAB;
+constexpr int SMEM_RING = 4 * SLAB;
 constexpr int SMEM_BYTES = SMEM_RING + V_TOTAL * 4;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>). The slot schedule below is written with
+// `if constexpr` on these indices; a plain unrolled loop left thousands of unfolded branches and put the register arrays in scratch.
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+#define CI(x) (decltype(x)::value)
 
 template <bool MLP, bool QKV, bool TAP, int DBG = 0> // DBG: diagnostic builds only (tools/bench_block.py): 1 no global weight loads, 2 no ring writes, 4 no MFMA, 8 no fragment reads
 __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_args args) {
@@ -96,6 +105,12 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
     const float* const a_vmlp = args.vec_mlp; const float* const a_vqkv = args.vec_qkv; const float* const a_vtap = args.vec_tap;
     void* const a_feat = args.feat; void* const a_q = args.q; void* const a_k = args.k; void* const a_v = args.v; float* const a_cap = args.cap_x1;
     const int a_M = args.M, a_T = args.T, a_H = args.H; const float a_qs = args.q_scale, a_eps = args.eps;
+    unsigned long long* const a_stamps = reinterpret_cast<unsigned long long*>(args.stamps);
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (a_stamps && threadIdx.x == 0) a_stamps[(size_t)blockIdx.x * 16 + slot] = slot == 15 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    if (a_stamps && threadIdx.x == 0) a_stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
     float* const vec = reinterpret_cast<float*>(smem + SMEM_RING);
@@ -120,7 +135,10 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x, xoff + (32 * t + 8 * g) * 4, 0, 0);
     };
 
-    // ---- weight slab stream: global -> registers (slab k+4 while slab k is consumed) -> LDS ring (slab k+2) -> fragments
+    // ---- weight slab stream: global -> registers (one step ahead) -> LDS ring (4 stages: the pair in use, the pair being
+    // written) -> fragments. A STEP consumes two slabs behind one barrier as two interleaved MFMA streams X (even slab) and
+    // Y (odd slab): two dependent MFMAs with VALU work between them run at ~64 cycles per MFMA (measured), so a tile's
+    // 24-MFMA accumulation chain alternates with an independent stream (another tile's chain, or fc2's 12 accumulators).
     const u32x4* const src_mlp = reinterpret_cast<const u32x4*>(a_wmlp) + wave * PIECES * 64 + lane;
     const u32x4* const src_qkv = reinterpret_cast<const u32x4*>(a_wqkv) + wave * PIECES * 64 + lane;
     auto slab_src = [&](int k) __attribute__((always_inline)) -> const u32x4* {
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
         else if constexpr (MLP) return src_mlp + (long)kk * (SLAB / 16);
         else return src_qkv + (long)kk * (SLAB / 16);
     };
-    u32x4 G0[PIECES], G1[PIECES];
+    u32x4 G0[PIECES], G1[PIECES]; // staged pieces of the next even / odd slab
     unsigned char* const wr0 = ring + wave * PIECES * 1024 + lane * 16; // this lane's first piece inside stage 0
     const unsigned char* const rd0 = ring + lane * 16;                  // this lane's 16 bytes of fragment 0 inside stage 0
 
@@ -153,58 +171,60 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
         for (int z = 0; z < PIECES; ++z) { G0[z] = s2[z * 64]; G1[z] = s3[z * 64]; }
     }
 
-    int k = 0, st = 0;            // slab in flight and its ring stage (k % 3)
-    const unsigned char *cur = rd0, *nxt = rd0 + SLAB;
+    int k = 0, st = 0;            // first slab of the step in flight and its ring stage (0 or 2)
+    const unsigned char *curx = rd0, *cury = rd0 + SLAB;
     unsigned char* wr = wr0 + 2 * SLAB;
-    const u32x4* gsrc = slab_src(4);
-    f16x8 wf[PF];                 // fragment window: fragment s of the slab in flight lives in wf[s % PF]
+    const u32x4 *gsrc0 = slab_src(4), *gsrc1 = slab_src(5);
+    f16x8 wfx[PF], wfy[PF];       // fragment windows of the two streams: fragment f lives in w?[f % PF]
 
-    // slab k starts: every wave is done with slab k-1 (its stage becomes the write target) and slab k+1 is visible
-    auto slab_open = [&]() __attribute__((always_inline)) {
-        __syncthreads();
-        const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
-        cur = rd0 + st * SLAB;
-        nxt = rd0 + st1 * SLAB;
-        wr = wr0 + st2 * SLAB;
-        gsrc = slab_src(k + 4);
-        st = st1;
-        ++k;
-    };
-    // slot s of a slab of parity PAR: one sixth of the feed every second slot
-    auto feed = [&](auto par_c, int s) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_c)::value;
-        if (s % 4 == 1 && !(DBG & 2)) {
-            if constexpr (PAR == 0) *reinterpret_cast<u32x4*>(wr + (s / 4) * 1024) = G0[s / 4];
-            else *reinterpret_cast<u32x4*>(wr + (s / 4) * 1024) = G1[s / 4];
-        }
-        if (s % 4 == 3 && !(DBG & 1)) {
-            if constexpr (PAR == 0) G0[s / 4] = gsrc[(s / 4) * 64];
-            else G1[s / 4] = gsrc[(s / 4) * 64];
-        }
-    };
-    auto refill = [&](int s) __attribute__((always_inline)) {
-        if constexpr (!(DBG & 8)) wf[s % PF] = *reinterpret_cast<const f16x8*>((s + PF < KS ? cur : nxt) + ((s + PF) % KS) * 1024);
-    };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    // one 32-feature tile over the embed dim: 24 chained MFMAs; side(s) = the slot's VALU / memory side work
-    auto tile_slab = [&](auto par_c, f32x16& c, const f16x8(&b)[KS], auto&& side) __attribute__((always_inline)) {
-        slab_open();
+    // step (k, k+1) starts: every wave is done with the previous pair (its stages become the write target), this pair is visible
+    auto step_open = [&]() __attribute__((always_inline)) {
+        if constexpr (!(DBG & 64)) __syncthreads();
+        curx = rd0 + st * SLAB;
+        cury = curx + SLAB;
+        wr = wr0 + (st ^ 2) * SLAB;
+        gsrc0 = slab_src(k + 4);
+        gsrc1 = slab_src(k + 5);
+        st ^= 2;
+        k += 2;
+        if constexpr (!(DBG & 8)) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if constexpr (!(DBG & 4)) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % PF], b[s], c, 0, 0, 0);
-            else asm volatile("" : "+v"(c) : "v"(wf[s % PF]), "v"(b[s]));
-            refill(s);
-            feed(par_c, s);
-            side(s);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < PF; ++i) {
+                wfx[i] = *reinterpret_cast<const f16x8*>(curx + i * 1024);
+                wfy[i] = *reinterpret_cast<const f16x8*>(cury + i * 1024);
+            }
         }
     };
-    auto no_side = [](int) {};
+    // 48 slots: slot i runs fragment i/2 of stream X (i even) or Y (i odd), refills that window, moves one twelfth of the
+    // next pair from registers to LDS or requests one twelfth of the pair after it, and runs the slot's side work
+    auto step = [&](auto&& xm, auto&& ym, auto&& side) __attribute__((always_inline)) {
+        step_open();
+        static_for<2 * KS>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = CI(ic), f = i >> 1;
+            if constexpr ((i & 1) == 0) {
+                xm(std::integral_constant<int, f>{}, wfx[f % PF]);
+                if constexpr (f + PF < KS && !(DBG & 8)) wfx[f % PF] = *reinterpret_cast<const f16x8*>(curx + (f + PF) * 1024);
+            } else {
+                ym(std::integral_constant<int, f>{}, wfy[f % PF]);
+                if constexpr (f + PF < KS && !(DBG & 8)) wfy[f % PF] = *reinterpret_cast<const f16x8*>(cury + (f + PF) * 1024);
+            }
+            constexpr int z = i >> 2; // piece 0..11 of the pair: 0..5 even slab, 6..11 odd slab
+            if constexpr (i % 4 == 1 && !(DBG & 2)) {
+                if constexpr (z < PIECES) *reinterpret_cast<u32x4*>(wr + z * 1024) = G0[z];
+                else *reinterpret_cast<u32x4*>(wr + SLAB + (z - PIECES) * 1024) = G1[z - PIECES];
+            }
+            if constexpr (i % 4 == 3 && !(DBG & 1)) {
+                if constexpr (z < PIECES) G0[z] = gsrc0[z * 64];
+                else G1[z - PIECES] = gsrc1[(z - PIECES) * 64];
+            }
+            side(ic);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto no_side = [](auto) {};
 
     __syncthreads(); // slabs 0 and 1 and the vectors are in LDS
-#pragma unroll
-    for (int i = 0; i < PF; ++i) wf[i] = *reinterpret_cast<const f16x8*>(rd0 + i * 1024);
+    stamp(1);
 
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // accumulator tile initialised with a per-feature vector (bias folded into the MFMA chain): 4 LDS reads, no VALU
@@ -217,9 +237,20 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
         }
         return c;
     };
+    // a finished tile is copied out of the accumulator registers in one burst (hipcc keeps MFMA results in AGPRs; the asm
+    // pins the copy, so the VALU code of the following slots works on VGPRs)
+    auto to_vgprs = [&](const f32x16& src, float(&dst)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dst[e] = src[e]; asm volatile("" : "+v"(dst[e])); }
+    };
 
     f16x8 xb[KS];    // token fragments (B operand) of the product in flight
     f32x16 acc[NT];  // this lane's half of 32 token rows: row-resident residual stream / fc2 accumulators
+    auto chain = [&](f32x16& c) __attribute__((always_inline)) { // a tile's accumulation chain over the embed dim as a stream
+        return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
+            if constexpr (!(DBG & 4)) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xb[CI(fc)], c, 0, 0, 0);
+        };
+    };
 
     // LayerNorm over the row held by lanes (r, 0) and (r, 1); two passes in registers (nn.cpp:14-19)
     float mean = 0.f, rstd = 0.f;
@@ -268,38 +299,44 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
 #pragma unroll
             for (int s = 0; s < KS; ++s) xb[s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff + 32 * s, 0, 0));
         }
-        // tile t: MFMAs of tile t, the residual update of tile t-1 (4 groups of 4 features) and the x loads of tile t
-        f32x16 cp = zero;  // finished tile awaiting its epilogue
-        f32x4 xin[4], xpv[4];
+        stamp(2);
+        // the residual stream rows go straight into acc (the youngest loads in the queue: nothing waits for them before the
+        // first epilogue, one step of MFMAs later)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x16 c = vec_tile(vec + V_BO + 32 * t);
-            auto side = [&](int s) __attribute__((always_inline)) {
-                if (s < 4) xin[s] = ld_x(t, s);
-                if (t > 0 && s >= 8 && s % 4 == 0) { // s = 8, 12, 16, 20: group g of tile t-1
-                    const int g = s / 4 - 2;
-                    const float4 lm = *reinterpret_cast<const float4*>(vec + V_LAM1 + 32 * (t - 1) + 8 * g + 4 * h);
-                    f32x4 o = {fmaf(cp[4 * g + 0], lm.x, xpv[g][0]), fmaf(cp[4 * g + 1], lm.y, xpv[g][1]),
-                               fmaf(cp[4 * g + 2], lm.z, xpv[g][2]), fmaf(cp[4 * g + 3], lm.w, xpv[g][3])};
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[t - 1][4 * g + i] = o[i];
-                    st_x(t - 1, g, o); // re-read by the fc2 epilogue below
-                }
-            };
-            if (t & 1) tile_slab(P1{}, c, xb, side); else tile_slab(P0{}, c, xb, side);
-            cp = c;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = ld_x(t, g);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) xpv[g] = xin[g];
-        }
+                for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = v[i];
+            }
+        // step j: tiles 2j (stream X) and 2j+1 (stream Y); side work = the residual update of tiles 2j-2 and 2j-1
+        f32x16 cpa = zero, cpb = zero; // finished pair awaiting its epilogue
+        float ct[16];
+        auto resid_group = [&](int t, int g) __attribute__((always_inline)) {
+            const float4 lm = *reinterpret_cast<const float4*>(vec + V_LAM1 + 32 * t + 8 * g + 4 * h);
+            f32x4 o = {fmaf(ct[4 * g + 0], lm.x, acc[t][4 * g + 0]), fmaf(ct[4 * g + 1], lm.y, acc[t][4 * g + 1]),
+                       fmaf(ct[4 * g + 2], lm.z, acc[t][4 * g + 2]), fmaf(ct[4 * g + 3], lm.w, acc[t][4 * g + 3])};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 lm = *reinterpret_cast<const float4*>(vec + V_LAM1 + 32 * (NT - 1) + 8 * g + 4 * h);
-            f32x4 o = {fmaf(cp[4 * g + 0], lm.x, xpv[g][0]), fmaf(cp[4 * g + 1], lm.y, xpv[g][1]),
-                       fmaf(cp[4 * g + 2], lm.z, xpv[g][2]), fmaf(cp[4 * g + 3], lm.w, xpv[g][3])};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[NT - 1][4 * g + i] = o[i];
-            st_x(NT - 1, g, o);
-        }
+            for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = o[i];
+            st_x(t, g, o); // re-read by the fc2 epilogue below
+        };
+        auto resid_side = [&](auto t0c, auto ic) __attribute__((always_inline)) { // tile t0 in slots 6..21, tile t0+1 in slots 26..41
+            constexpr int t0 = CI(t0c), i = CI(ic);
+            if constexpr (i == 6) to_vgprs(cpa, ct);
+            if constexpr (i >= 8 && i < 24 && i % 4 == 0) resid_group(t0, i / 4 - 2);
+            if constexpr (i == 26) to_vgprs(cpb, ct);
+            if constexpr (i >= 28 && i < 44 && i % 4 == 0) resid_group(t0 + 1, i / 4 - 7);
+        };
+        static_for<NT / 2>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = CI(jc);
+            f32x16 ca = vec_tile(vec + V_BO + 32 * (2 * j)), cb = vec_tile(vec + V_BO + 32 * (2 * j + 1));
+            step(chain(ca), chain(cb), [&](auto ic) __attribute__((always_inline)) {
+                if constexpr (j > 0) resid_side(std::integral_constant<int, (j > 0 ? 2 * j - 2 : 0)>{}, ic);
+            });
+            cpa = ca; cpb = cb;
+        });
+        static_for<2 * KS>([&](auto ic) __attribute__((always_inline)) { resid_side(std::integral_constant<int, NT - 2>{}, ic); });
         if (a_cap) { // parity captures only (tests): the residual stream after the attention half
             const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a_cap, 0, (int)((long)a_M * row_bytes_f32), 0x00020000);
 #pragma unroll
@@ -312,70 +349,90 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
         }
 
         // ---- mlp (dino.cpp:52-57). Hidden tile u (32 units) = gelu(W1[u] LN2(x)^T + b1[u]) goes from the fc1 accumulators
-        // straight into fc2's B operand. Software pipeline over u:  fc1(u+1) | GELU(u) first half   (slab W1(u+1))
-        //                                                          fc2(u-1) | GELU(u) second half  (slab W2(u-1))
-        // Slab order: W1(0), W1(1), [W1(u+1), W2(u-1)] for u = 1..46, W2(46), W2(47).
+        // straight into fc2's B operand. Software pipeline over u, one step each:
+        //     stream X: fc1(u+1) (slab W1(u+1)) | stream Y: fc2(u-1) (slab W2(u-1)) | side work: GELU(u)
+        // Slab order: [W1(0), W1(1)], [W1(u+1), W2(u-1)] for u = 1..46, [W2(46), W2(47)].
+        stamp(3);
         ln_stats();
         ln_to_frags(vec + V_G2, vec + V_B2);
+        stamp(4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = vec_tile(vec + V_BFC2 + 32 * t); // fc2 bias folded into the accumulators
 
         const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f, c3 = c1 * 0.044715f;
-        f32x16 hc, hn;       // fc1 tile being activated / being accumulated
+        f32x16 hc, hn;        // fc1 tile being activated / being accumulated
         f16x8 hbp[2], hbn[2]; // activated tile feeding fc2 / being produced
-        float gz[16], gd[16];
-        // GELU of element e of hc in three slot-sized pieces (ggml_gelu: x * sigmoid(2u), see kernels_gemm.hip)
-        auto gelu_piece = [&](int e, int stage) __attribute__((always_inline)) {
-            if (stage == 0) gz[e] = hc[e] * fmaf(hc[e] * hc[e], c3, c1);
-            if (stage == 1) gd[e] = 1.0f + __builtin_amdgcn_exp2f(gz[e]);
-            if (stage == 2) hbn[e >> 3][e & 7] = (f16)(hc[e] * __builtin_amdgcn_rcpf(gd[e]));
+        float gt[16], g1[16], g2[16];
+        // GELU (ggml_gelu: x * sigmoid(2u), see kernels_gemm.hip) of the copied tile, 7 dependent operations per element.
+        // Dependent VALU instructions issued back to back cost ~8 cycles each beside this wave's MFMAs (measured), so an
+        // element's operations sit in 7 CONSECUTIVE SLOTS and a slot mixes operations of up to three different elements:
+        // element e starts in slot 1 + (5 e) / 2.
+        auto gelu_op = [&](auto ec, auto opc) __attribute__((always_inline)) {
+            constexpr int e = CI(ec), op = CI(opc);
+            if constexpr (DBG & 32) { if constexpr (op == 6) hbn[e >> 3][e & 7] = (f16)gt[e]; return; }
+            if constexpr (op == 0) g1[e] = gt[e] * gt[e];
+            if constexpr (op == 1) g1[e] = fmaf(g1[e], c3, c1);
+            if constexpr (op == 2) g1[e] = gt[e] * g1[e];
+            if constexpr (op == 3) g2[e] = __builtin_amdgcn_exp2f(g1[e]);
+            if constexpr (op == 4) g2[e] = 1.0f + g2[e];
+            if constexpr (op == 5) g2[e] = __builtin_amdgcn_rcpf(g2[e]);
+            if constexpr (op == 6) hbn[e >> 3][e & 7] = (f16)(gt[e] * g2[e]);
         };
-        auto fc2_slab = [&](auto par_c, const f16x8(&hb)[2], auto&& side) __attribute__((always_inline)) {
-            slab_open();
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { // fragment s = (k-step s / 12 of the hidden tile, feature tile s % 12)
-                if constexpr (!(DBG & 4)) acc[s % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % PF], hb[s / NT], acc[s % NT], 0, 0, 0);
-                else asm volatile("" : "+v"(acc[s % NT]) : "v"(wf[s % PF]), "v"(hb[s / NT]));
-                refill(s);
-                feed(par_c, s);
-                side(s);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        auto gelu_side = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = CI(ic);
+            if constexpr (i == 0) to_vgprs(hc, gt);
+            static_for<16>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int op = i - (1 + (5 * CI(ec)) / 2);
+                if constexpr (op >= 0 && op < 7) gelu_op(ec, std::integral_constant<int, (op >= 0 && op < 7 ? op : 0)>{});
+            });
+        };
+        auto fc2_stream = [&](const f16x8(&hb)[2]) __attribute__((always_inline)) { // fragment f = (k-step f / 12 of the hidden tile, feature tile f % 12)
+            return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
+                constexpr int f = CI(fc);
+                if constexpr (!(DBG & 4)) acc[f % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, hb[f / NT], acc[f % NT], 0, 0, 0);
+            };
         };
         hc = vec_tile(vec + V_B1);
-        tile_slab(P0{}, hc, xb, no_side);                                               // W1(0)
         hn = vec_tile(vec + V_B1 + 32);
-        tile_slab(P1{}, hn, xb, [&](int s) __attribute__((always_inline)) { gelu_piece(s / 3, s % 3); });    // W1(1) | GELU(0) 0..7
-#pragma unroll
-        for (int s = 0; s < KS; ++s) gelu_piece(8 + s / 3, s % 3);                      //         GELU(0) 8..15
+        step(chain(hc), chain(hn), no_side);                                    // [W1(0), W1(1)]
+        static_for<2 * KS>(gelu_side);                                          // GELU(0), no cover
         hbp[0] = hbn[0]; hbp[1] = hbn[1];
         hc = hn;
 #pragma unroll 1
         for (int u = 1; u < HID / 32 - 1; ++u) {
             hn = vec_tile(vec + V_B1 + 32 * (u + 1));
-            tile_slab(P0{}, hn, xb, [&](int s) __attribute__((always_inline)) { gelu_piece(s / 3, s % 3); });      // W1(u+1) | GELU(u) 0..7
-            fc2_slab(P1{}, hbp, [&](int s) __attribute__((always_inline)) { gelu_piece(8 + s / 3, s % 3); });    // W2(u-1) | GELU(u) 8..15
+            step(chain(hn), fc2_stream(hbp), gelu_side);                        // [W1(u+1), W2(u-1)] | GELU(u)
             hbp[0] = hbn[0]; hbp[1] = hbn[1];
             hc = hn;
         }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) gelu_piece(s / 3, s % 3);                          // GELU(47) 0..7
-        fc2_slab(P0{}, hbp, [&](int s) __attribute__((always_inline)) { gelu_piece(8 + s / 3, s % 3); });        // W2(46) | GELU(47) 8..15
-        fc2_slab(P1{}, hbn, no_side);                                                   // W2(47)
+        // hc = fc1(47), hbp = gelu(46)
+        {
+            f16x8 hb46[2] = {hbp[0], hbp[1]};
+            static_for<2 * KS>(gelu_side);                                      // GELU(47), no cover
+            step(fc2_stream(hb46), fc2_stream(hbn), no_side);                   // [W2(46), W2(47)]
+        }
 
-        // ---- x += lambda2 * (fc2 + b2)   (dino.cpp:85-87)
+        stamp(5);
+        // ---- x += lambda2 * (fc2 + b2)   (dino.cpp:85-87). All 48 re-reads of x are issued before the first use: one memory
+        // round trip for the whole epilogue (loads interleaved with the stores waited for every store's acknowledgement)
+        {
+            f32x4 xi[NT][4];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 xi = ld_x(t, g);
-                const float4 lm = *reinterpret_cast<const float4*>(vec + V_LAM2 + 32 * t + 8 * g + 4 * h);
-                f32x4 o = {fmaf(acc[t][4 * g + 0], lm.x, xi[0]), fmaf(acc[t][4 * g + 1], lm.y, xi[1]),
-                           fmaf(acc[t][4 * g + 2], lm.z, xi[2]), fmaf(acc[t][4 * g + 3], lm.w, xi[3])};
+                for (int g = 0; g < 4; ++g) xi[t][g] = ld_x(t, g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = o[i];
-                st_x(t, g, o);
-            }
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 lm = *reinterpret_cast<const float4*>(vec + V_LAM2 + 32 * t + 8 * g + 4 * h);
+                    f32x4 o = {fmaf(acc[t][4 * g + 0], lm.x, xi[t][g][0]), fmaf(acc[t][4 * g + 1], lm.y, xi[t][g][1]),
+                               fmaf(acc[t][4 * g + 2], lm.z, xi[t][g][2]), fmaf(acc[t][4 * g + 3], lm.w, xi[t][g][3])};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = o[i];
+                    st_x(t, g, o);
+                }
+        }
     } else {
         // QKV-only instance (first layer): the residual stream comes from memory
 #pragma unroll
@@ -388,7 +445,9 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
             }
     }
 
+    stamp(6);
     if constexpr (TAP || QKV) ln_stats(); // both LayerNorms below normalise the same row: shared statistics
+    stamp(7);
 
     if constexpr (TAP) {
         // ---- get_intermediate_layers: feat = LN_final(x), f16 rows (dino.cpp:100-107)
@@ -413,57 +472,61 @@ __global__ __launch_bounds__(256, 1) void dino_block_kernel(const vx_dino_block_
 
     if constexpr (QKV) {
         // ---- next layer: q, k, v = LN1(x) Wqkv^T + b, head-major [B, H, T, 64], q pre-scaled (dino.cpp:59-66, nn.cpp:210-216)
+        stamp(8);
         ln_to_frags(vec + V_GN, vec + V_BN);
+        stamp(9);
         const int b = m / a_T, tok = m - b * a_T;
         const int qkv_bytes = (int)((long)a_M * row_bytes_f16); // each of q, k, v: [B, H, T, 64] f16 = M * 384 * 2 bytes
         // rows past M get an offset beyond any buffer (and far from wrapping): the range check drops their stores
         const unsigned tok_off = m < a_M ? ((unsigned)b * a_H * a_T + tok) * 128 + 16 * h : 0x80000000u;
         const unsigned head_stride = (unsigned)a_T * 128;
-        // One part per output tensor (W = 0 q, 1 k, 2 v: its descriptor and scale are compile-time choices), 12 tiles each.
-        // The epilogue of a tile (scale, round to f16, pair the lane halves into 16-byte stores) runs in the slots of the
-        // next tile's MFMAs; the last tile of a part is flushed without cover.
+        // One part per output tensor (W = 0 q, 1 k, 2 v: its descriptor and scale are compile-time choices), 12 tiles = 6 steps
+        // each. The epilogue of a pair of tiles (scale, round to f16, pair the lane halves into 16-byte stores) runs in the
+        // slots of the next step; the last pair of a part is flushed without cover.
         auto qkv_part = [&](auto wc, void* base) __attribute__((always_inline)) {
             constexpr int W = decltype(wc)::value;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, qkv_bytes, 0x00020000);
             const float sc = W == 0 ? a_qs : 1.0f;
-            f32x16 cp = zero;
-            int hp = 0; // tile (inside the part) that cp belongs to
+            f32x16 cpa = zero, cpb = zero;
+            int hp = 0; // first tile (inside the part) of the finished pair
             u32x2 pk[4];
-            auto epi_piece = [&](int s) __attribute__((always_inline)) {
-                if (s >= 4 && s < 8) {
-                    const int g = s - 4;
-                    pk[g] = pack4(cp[4 * g + 0] * sc, cp[4 * g + 1] * sc, cp[4 * g + 2] * sc, cp[4 * g + 3] * sc);
+            float ct[16];
+            auto epi_tile = [&](auto i0c, auto ic, const f32x16& c, int hv) __attribute__((always_inline)) { // slots i0 .. i0+12
+                constexpr int i0 = CI(i0c), i = CI(ic);
+                if constexpr (i == i0) to_vgprs(c, ct);
+                if constexpr (i >= i0 + 2 && i < i0 + 6) {
+                    constexpr int g = i - i0 - 2;
+                    pk[g] = pack4(ct[4 * g + 0] * sc, ct[4 * g + 1] * sc, ct[4 * g + 2] * sc, ct[4 * g + 3] * sc);
                 }
-                if (s == 10 || s == 14) {
-                    const int pr = (s - 10) / 4;
-                    const unsigned off = tok_off + (unsigned)(hp >> 1) * head_stride + (hp & 1) * 64 + 32 * pr;
+                if constexpr (i == i0 + 8 || i == i0 + 12) {
+                    constexpr int pr = (i - i0 - 8) / 4;
+                    const unsigned off = tok_off + (unsigned)(hv >> 1) * head_stride + (hv & 1) * 64 + 32 * pr;
                     __builtin_amdgcn_raw_buffer_store_b128(widen_pair(pk[2 * pr], pk[2 * pr + 1]), rs, off, 0, 0);
                 }
             };
+            auto epi_side = [&](auto ic) __attribute__((always_inline)) {
+                epi_tile(std::integral_constant<int, 4>{}, ic, cpa, hp);
+                epi_tile(std::integral_constant<int, 26>{}, ic, cpb, hp + 1);
+            };
             {
-                f32x16 c0 = vec_tile(vec + V_BQKV + 32 * (W * NT));
-                tile_slab(P0{}, c0, xb, no_side);
-                cp = c0; hp = 0;
-                f32x16 c1 = vec_tile(vec + V_BQKV + 32 * (W * NT + 1));
-                tile_slab(P1{}, c1, xb, epi_piece);
-                cp = c1; hp = 1;
+                f32x16 ca = vec_tile(vec + V_BQKV + 32 * (W * NT)), cb = vec_tile(vec + V_BQKV + 32 * (W * NT + 1));
+                step(chain(ca), chain(cb), no_side);
+                cpa = ca; cpb = cb; hp = 0;
             }
 #pragma unroll 1
-            for (int i = 2; i < NT; i += 2) {
-                f32x16 c0 = vec_tile(vec + V_BQKV + 32 * (W * NT + i));
-                tile_slab(P0{}, c0, xb, epi_piece);
-                cp = c0; hp = i;
-                f32x16 c1 = vec_tile(vec + V_BQKV + 32 * (W * NT + i + 1));
-                tile_slab(P1{}, c1, xb, epi_piece);
-                cp = c1; hp = i + 1;
+            for (int i2 = 2; i2 < NT; i2 += 2) {
+                f32x16 ca = vec_tile(vec + V_BQKV + 32 * (W * NT + i2)), cb = vec_tile(vec + V_BQKV + 32 * (W * NT + i2 + 1));
+                step(chain(ca), chain(cb), epi_side);
+                cpa = ca; cpb = cb; hp = i2;
             }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) epi_piece(s);
+            static_for<2 * KS>(epi_side);
         };
         qkv_part(std::integral_constant<int, 0>{}, a_q);
         qkv_part(std::integral_constant<int, 1>{}, a_k);
         qkv_part(std::integral_constant<int, 2>{}, a_v);
     }
+    stamp(10);
+    stamp(15);
 }
 
 template <bool MLP, bool QKV, bool TAP, int DBG = 0>
@@ -550,6 +613,12 @@ int vx_dino_block_f16(const vx_dino_block_args* args, void* stream) {
             case 7: return launch_block<true, true, false, 7>(a, s);
             case 11: return launch_block<true, true, false, 11>(a, s);
             case 15: return launch_block<true, true, false, 15>(a, s);
+            case 43: return launch_block<true, true, false, 43>(a, s);
+            case 171: return launch_block<true, true, false, 171>(a, s);
+            case 427: return launch_block<true, true, false, 427>(a, s);
+            case 555: return launch_block<true, true, false, 555>(a, s);
+            case 1067: return launch_block<true, true, false, 1067>(a, s);
+            case 32: return launch_block<true, true, false, 32>(a, s);
             default: break;
         }
 #endif

@@ -150,6 +150,10 @@ class Model:
     def use_graph(self, enable: bool = True):
         check(self._api.visp_depthany_use_graph(self._handle, int(enable)))
 
+    def set_schedule(self, schedule: int):
+        """0 = GEMM launches per op group (default); 1 = token-stationary block kernel per layer (embed dim 384 models)."""
+        check(self._api.visp_depthany_set_schedule(self._handle, int(schedule)))
+
     def compute_batch(self, images: np.ndarray, return_raw: bool = False):
         """images: uint8 [B, h, w, 3] on the host -> float32 [B, h, w] in [0, 1]."""
         imgs = np.ascontiguousarray(images, dtype=np.uint8)
