@@ -131,6 +131,10 @@ VISP_API int32_t visp_esrgan_set_tile_group(visp_model* m, int32_t tiles);
 VISP_API int32_t visp_esrgan_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes);
 VISP_API int32_t visp_esrgan_weights_ready(visp_model* m);
 /* tile_scale(tile_layout(extent, 224, 16), scale): out8 = image w,h, overlap x,y, n_tiles x,y, tile w,h (image.cpp:612-629) */
+/* host-only image_scale of the reference (src/visp/image.cpp:328-356: stb_image_resize semantics, csrc/image_resize.cpp):
+ * any supported format; the result is owned by *out_data (visp_image_destroy) */
+VISP_API int32_t visp_image_scale(visp_image_view const* src, int32_t width, int32_t height, visp_image_view* out_image,
+                                  visp_image_data** out_data);
 VISP_API int32_t visp_esrgan_tile_layout(int32_t w, int32_t h, int32_t scale, int32_t out8[8]);
 /* img: u8 [B,h,w,channels(format)] (rgba/bgra/argb/rgb), out: rgba_u8 [B, h*scale, w*scale, 4]; device pointers;
  * stream = hipStream_t or NULL (NULL: the device's stream, synchronised before returning) */

@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
         L.vo_image_u8_to_f32.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int]
         L.vo_image_f32_to_u8.argtypes = [fp, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_float, C.c_float]
         L.vo_image_normalize.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.vo_image_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.vo_depthany_image_extent.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vo_transfer_tensor.argtypes = [C.POINTER(Tensor), C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
         L.vo_linear.argtypes = [fp, C.c_int64, C.c_int64, fp, fp, C.c_int64, fp]
@@ -153,6 +154,15 @@ def image_normalize(src: np.ndarray, mn=0.0, mx=1.0) -> np.ndarray:
     ch = 1 if src.ndim == 2 else src.shape[2]
     out = np.empty_like(src)
     lib().vo_image_normalize(_fp(src), _fp(out), w, h, ch, mn, mx)
+    return out
+
+
+def image_scale(src: np.ndarray, fmt: int, ow: int, oh: int) -> np.ndarray:
+    """image.cpp:328-356 (stb_image_resize semantics). src: [h, w, ch] (or [h, w]) u8 / f32 in `fmt`."""
+    src = np.ascontiguousarray(src)
+    h, w = src.shape[:2]
+    out = np.empty((oh, ow) + src.shape[2:], src.dtype)
+    _check(lib().vo_image_scale(src.ctypes.data, w, h, fmt, out.ctypes.data, ow, oh))
     return out
 
 

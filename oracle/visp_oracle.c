@@ -206,6 +206,173 @@ void vo_image_normalize(const float* src, float* dst, int w, int h, int channels
         for (int c = 0; c < channels; ++c) dst[i * channels + c] = src[i * channels + c] * scale[c] + offset[c];
 }
 
+/* src/visp/image.cpp:328-356 image_scale = stbir_resize_{uint8,float}_generic(alpha_channel(format), flags 0,
+ * STBIR_EDGE_CLAMP, STBIR_FILTER_DEFAULT, STBIR_COLORSPACE_SRGB (u8) / LINEAR (float)). stb is a network fetch of the
+ * reference's build (depend/stb/CMakeLists.txt: nothings/stb @ 5736b15f = stb_image_resize.h v0.97), absent here: this is
+ * a restatement of that file's published algorithm in its own structure (one contributor + coefficient list per axis:
+ * indexed by OUTPUT pixel when enlarging, by INPUT pixel incl. margin when reducing), pinned by the reference's vector
+ * tests/test-image.cpp:186-203. */
+static float stbir_catmullrom(float x) {
+    x = fabsf(x);
+    if (x < 1.0f) return 1 - x * x * (2.5f - 1.5f * x);
+    if (x < 2.0f) return 2 - x * (4 + x * (0.5f * x - 2.5f));
+    return 0.0f;
+}
+static float stbir_mitchell(float x) {
+    x = fabsf(x);
+    if (x < 1.0f) return (16 + x * x * (21 * x - 36)) / 18;
+    if (x < 2.0f) return (32 + x * (-60 + x * (36 - 7 * x))) / 18;
+    return 0.0f;
+}
+typedef struct { int n0, n1; } stbir_contrib;
+/* resamples n_lines lines of in_size pixels (line stride ls, pixel stride ps floats, ch channels) to out_size pixels */
+static void stbir_axis(const float* in, int in_size, float* out, int out_size, int n_lines, int64_t ls_in, int64_t ls_out, int64_t ps, int ch) {
+    float scale = (float)out_size / (float)in_size;
+    if (scale > 1.0f) { /* upsample: gather, STBIR_DEFAULT_FILTER_UPSAMPLE = Catmull-Rom, support 2 */
+        float out_radius = 2.0f * scale;
+        int cw = (int)ceilf(2.0f * 2) + 1; /* coefficient width (+1 slack) */
+        float* coef = (float*)malloc((size_t)cw * sizeof(float) * 2);
+        for (int n = 0; n < out_size; ++n) {
+            float centre = (float)n + 0.5f;
+            int first = (int)floorf((centre - out_radius) / scale + 0.5f), last = (int)floorf((centre + out_radius) / scale - 0.5f);
+            float in_centre = centre / scale, total = 0;
+            int cnt = 0;
+            for (int i = 0; i <= last - first; ++i) {
+                float c = stbir_catmullrom(in_centre - ((float)(i + first) + 0.5f));
+                if (cnt == 0 && c == 0.0f) { ++first; --i; continue; }
+                coef[cnt++] = c;
+                total += c;
+            }
+            for (int i = 0; i < cnt; ++i) coef[i] *= 1 / total;
+            while (cnt > 0 && coef[cnt - 1] == 0.0f) --cnt;
+            for (int l = 0; l < n_lines; ++l)
+                for (int c = 0; c < ch; ++c) {
+                    float acc = 0;
+                    for (int i = 0; i < cnt; ++i) {
+                        int p = first + i;
+                        p = p < 0 ? 0 : (p >= in_size ? in_size - 1 : p); /* STBIR_EDGE_CLAMP */
+                        acc += in[l * ls_in + p * ps + c] * coef[i];
+                    }
+                    out[l * ls_out + n * ps + c] = acc;
+                }
+        }
+        free(coef);
+        return;
+    }
+    /* downsample: scatter, STBIR_DEFAULT_FILTER_DOWNSAMPLE = Mitchell with its argument in output pixels */
+    int width = (int)ceilf(2.0f * 2 / scale), margin = width / 2;
+    int nc = in_size + 2 * margin, cw = (int)ceilf(2.0f * 2) + 2;
+    stbir_contrib* ct = (stbir_contrib*)malloc((size_t)nc * sizeof *ct);
+    float* coef = (float*)calloc((size_t)nc * cw, sizeof(float));
+    float in_radius = 2.0f / scale;
+    for (int j = 0; j < nc; ++j) {
+        float centre = (float)(j - margin) + 0.5f, out_centre = centre * scale;
+        ct[j].n0 = (int)floorf((centre - in_radius) * scale + 0.5f);
+        ct[j].n1 = (int)floorf((centre + in_radius) * scale - 0.5f);
+        for (int i = 0; i <= ct[j].n1 - ct[j].n0 && i < cw; ++i) coef[j * cw + i] = stbir_mitchell(((float)(i + ct[j].n0) + 0.5f) - out_centre) * scale;
+    }
+    for (int i = 0; i < out_size; ++i) { /* stbir__normalize_downsample_coefficients */
+        float total = 0;
+        for (int j = 0; j < nc; ++j) {
+            if (i >= ct[j].n0 && i <= ct[j].n1) total += coef[j * cw + i - ct[j].n0];
+            else if (i < ct[j].n0) break;
+        }
+        float norm = 1 / total;
+        for (int j = 0; j < nc; ++j) {
+            if (i >= ct[j].n0 && i <= ct[j].n1) coef[j * cw + i - ct[j].n0] *= norm;
+            else if (i < ct[j].n0) break;
+        }
+    }
+    for (int l = 0; l < n_lines; ++l) {
+        for (int n = 0; n < out_size; ++n)
+            for (int c = 0; c < ch; ++c) out[l * ls_out + n * ps + c] = 0.0f;
+        for (int j = 0; j < nc; ++j) { /* ascending input pixel, as stb's horizontal and vertical downsample loops */
+            int p = j - margin;
+            p = p < 0 ? 0 : (p >= in_size ? in_size - 1 : p);
+            for (int k = ct[j].n0; k <= ct[j].n1; ++k) {
+                if (k < 0 || k >= out_size) continue;
+                float w = coef[j * cw + k - ct[j].n0];
+                if (w == 0.0f) continue;
+                for (int c = 0; c < ch; ++c) out[l * ls_out + k * ps + c] += in[l * ls_in + p * ps + c] * w;
+            }
+        }
+    }
+    free(ct);
+    free(coef);
+}
+static unsigned char stbir_linear_to_srgb_uchar(float in) { /* fp32 -> sRGB8 table conversion of stb_image_resize.h */
+    static const uint32_t tab[104] = {
+        0x0073000d, 0x007a000d, 0x0080000d, 0x0087000d, 0x008d000d, 0x0094000d, 0x009a000d, 0x00a1000d, 0x00a7001a, 0x00b4001a, 0x00c1001a,
+        0x00ce001a, 0x00da001a, 0x00e7001a, 0x00f4001a, 0x0101001a, 0x010e0033, 0x01280033, 0x01410033, 0x015b0033, 0x01750033, 0x018f0033,
+        0x01a80033, 0x01c20033, 0x01dc0067, 0x020f0067, 0x02430067, 0x02760067, 0x02aa0067, 0x02dd0067, 0x03110067, 0x03440067, 0x037800ce,
+        0x03df00ce, 0x044600ce, 0x04ad00ce, 0x051400ce, 0x057b00c5, 0x05dd00bc, 0x063b00b5, 0x06970158, 0x07420142, 0x07e30130, 0x087b0120,
+        0x090b0112, 0x09940106, 0x0a1700fc, 0x0a9500f2, 0x0b0f01cb, 0x0bf401ae, 0x0ccb0195, 0x0d950180, 0x0e56016e, 0x0f0d015e, 0x0fbc0150,
+        0x10630143, 0x11070264, 0x1238023e, 0x1357021d, 0x14660201, 0x156601e9, 0x165a01d3, 0x174401c0, 0x182401af, 0x18fe0331, 0x1a9602fe,
+        0x1c1502d2, 0x1d7e02ad, 0x1ed4028d, 0x201a0270, 0x21520256, 0x227d0240, 0x239f0443, 0x25c003fe, 0x27bf03c4, 0x29a10392, 0x2b6a0367,
+        0x2d1d0341, 0x2ebe031f, 0x304d0300, 0x31d105b0, 0x34a80555, 0x37520507, 0x39d504c5, 0x3c37048b, 0x3e7c0458, 0x40a8042a, 0x42bd0401,
+        0x44c20798, 0x488e071e, 0x4c1c06b6, 0x4f76065d, 0x52a50610, 0x55ac05cc, 0x5892058f, 0x5b590559, 0x5e0c0a23, 0x631c0980, 0x67db08f6,
+        0x6c55087f, 0x70940818, 0x74a007bd, 0x787d076c, 0x7c330723};
+    union { float f; uint32_t u; } almostone = {.u = 0x3f7fffffu}, minval = {.u = (127u - 13u) << 23}, v;
+    if (!(in > minval.f)) in = minval.f;
+    if (in > almostone.f) in = almostone.f;
+    v.f = in;
+    uint32_t t = tab[(v.u - minval.u) >> 20];
+    return (unsigned char)((((t >> 16) << 9) + (t & 0xffff) * ((v.u >> 12) & 0xff)) >> 16);
+}
+static int vo_alpha_channel(int format) { /* src/visp/image.cpp:57-67 */
+    switch (format) {
+        case VO_BGRA_U8: return 3;
+        case VO_ARGB_U8: return 0;
+        case VO_ALPHA_U8: case VO_ALPHA_F32: return 0;
+        case VO_RGB_U8: case VO_RGB_F32: return -1;
+        default: return 3;
+    }
+}
+int vo_image_scale(const void* src, int w, int h, int format, void* dst, int ow, int oh) {
+    int ch = fmt_channels(format), ac = vo_alpha_channel(format), fl = format >= VO_RGBA_F32;
+    if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0 || ch <= 0) return 0;
+    int64_t n = (int64_t)w * h;
+    float* dec = (float*)malloc((size_t)n * ch * 4);
+    float* mid = (float*)malloc((size_t)ow * h * ch * 4);
+    float* res = (float*)malloc((size_t)ow * oh * ch * 4);
+    float alpha_eps = (float)1 / (1 << 20) / (1 << 20) / (1 << 20) / (1 << 20); /* STBIR_ALPHA_EPSILON */
+    for (int64_t i = 0; i < n; ++i) { /* stbir__decode_scanline */
+        for (int c = 0; c < ch; ++c) {
+            if (fl) dec[i * ch + c] = ((const float*)src)[i * ch + c];
+            else {
+                unsigned char v = ((const unsigned char*)src)[i * ch + c];
+                double s = v / 255.0;
+                dec[i * ch + c] = c == ac ? (float)v / 255.0f : (float)(s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4));
+            }
+        }
+        if (ac >= 0) { /* flags 0: not premultiplied, not STBIR_FLAG_ALPHA_USES_COLORSPACE */
+            float a = dec[i * ch + ac];
+            if (!fl) { a += alpha_eps; dec[i * ch + ac] = a; }
+            for (int c = 0; c < ch; ++c)
+                if (c != ac) dec[i * ch + c] *= a;
+        }
+    }
+    stbir_axis(dec, w, mid, ow, h, (int64_t)w * ch, (int64_t)ow * ch, ch, ch);     /* horizontal */
+    stbir_axis(mid, h, res, oh, ow, ch, ch, (int64_t)ow * ch, ch);                  /* vertical: lines = columns */
+    for (int64_t i = 0; i < (int64_t)ow * oh; ++i) { /* stbir__encode_scanline */
+        float* p = res + i * ch;
+        if (ac >= 0) {
+            float a = p[ac], ra = a ? 1.0f / a : 0;
+            for (int c = 0; c < ch; ++c)
+                if (c != ac) p[c] *= ra;
+        }
+        for (int c = 0; c < ch; ++c) {
+            if (fl) ((float*)dst)[i * ch + c] = p[c];
+            else if (c == ac) {
+                float v = p[c] < 0 ? 0 : (p[c] > 1 ? 1 : p[c]);
+                ((unsigned char*)dst)[i * ch + c] = (unsigned char)(int)(v * 255.0f + 0.5f);
+            } else ((unsigned char*)dst)[i * ch + c] = stbir_linear_to_srgb_uchar(p[c]);
+        }
+    }
+    free(dec); free(mid); free(res);
+    return 1;
+}
+
 /* src/visp/arch/depth-anything.cpp:112-117, src/util/math.h:16-18,59-61 */
 void vo_depthany_image_extent(int w, int h, int image_size, int image_multiple, int* ow, int* oh) {
     int min_side = w < h ? w : h;

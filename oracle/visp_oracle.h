@@ -93,6 +93,8 @@ int vo_image_f32_to_u8(const float* src, int w, int h, int sformat, uint8_t* dst
                        float scale, float offset);
 /* image.cpp:537-576 */
 void vo_image_normalize(const float* src, float* dst, int w, int h, int channels, float mn, float mx);
+/* image.cpp:328-356 (stb_image_resize v0.97 semantics, see the .c); src / dst tightly packed in `format`; returns 1 on success */
+int vo_image_scale(const void* src, int w, int h, int format, void* dst, int ow, int oh);
 /* depth-anything.cpp:112-117 */
 void vo_depthany_image_extent(int w, int h, int image_size, int image_multiple, int* ow, int* oh);
 

@@ -241,3 +241,34 @@ def test_mobile_sam_converter_writes_the_reference_contract(tmp_path):
     assert fam.value == 0
     with pytest.raises(ValueError, match="not a MobileSAM"):
         convert.convert_sam({"foo": np.zeros(3, np.float32)}, tmp_path / "x.gguf")
+
+
+def test_image_scale_matches_oracle_and_reference_vector():
+    """visp_image_scale (host code of the product, csrc/image_resize.cpp) against the oracle's restatement of
+    stb_image_resize (exact for u8, 1e-6 for f32) and against the reference's vector tests/test-image.cpp:186-203."""
+    import numpy as np
+
+    from oracle import oracle
+    from visioncpp_amd import vision
+
+    img = np.zeros((8, 8, 4), np.uint8)
+    for i in range(64):
+        img[i // 8, i % 8] = [255, 4 * (i // 8), 4 * (i % 8), 255]
+    res = vision.image_scale(img, 4, 4, vision.ImageFormat.rgba_u8)
+    for i in range(16):
+        assert list(res[i // 4, i % 4]) == [255, 2 + 8 * (i // 4), 2 + 8 * (i % 4), 255]
+    rng = np.random.default_rng(0)
+    F = vision.ImageFormat
+    for fmt, ofmt, ch in ((F.rgb_u8, oracle.RGB_U8, 3), (F.rgba_u8, oracle.RGBA_U8, 4), (F.bgra_u8, oracle.BGRA_U8, 4), (F.argb_u8, oracle.ARGB_U8, 4),
+                          (F.alpha_u8, oracle.ALPHA_U8, 1), (F.rgba_f32, oracle.RGBA_F32, 4), (F.rgb_f32, oracle.RGB_F32, 3), (F.alpha_f32, oracle.ALPHA_F32, 1)):
+        for (h, w, oh, ow) in ((33, 47, 70, 90), (64, 48, 17, 23), (20, 30, 20, 30), (100, 37, 37, 100), (5, 7, 70, 56)):
+            is_f = fmt.value >= F.rgba_f32.value
+            a = (rng.random((h, w, ch)).astype(np.float32) * 2 - 0.5) if is_f else rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+            a = a if ch > 1 else a[..., 0]
+            got, want = vision.image_scale(a, ow, oh, fmt), oracle.image_scale(a, ofmt, ow, oh)
+            if is_f:
+                assert np.abs(got - want).max() < 1e-6, (fmt, h, w)
+            else:
+                np.testing.assert_array_equal(got, want)
+    with pytest.raises(Exception, match="resize"):
+        vision.image_scale(np.zeros((4, 4, 3), np.uint8), 0, 4)

@@ -178,11 +178,17 @@ def test_reference_c_api_compute(small):
     # bgra input of the same pixels gives the same answer (channel map, image.cpp get_channel_map)
     bgra = np.concatenate([img[..., ::-1], np.full((518, 518, 1), 255, np.uint8)], axis=-1)
     np.testing.assert_array_equal(small.compute(bgra, vision.ImageFormat.bgra_u8), got)
-    # non-square input: exercises image_extent + pos-embed interpolation; compare with the oracle on the
-    # same resized pixels is not possible bit-exactly (stb resize), so check shape/finite/range
+    # non-square input whose extent is not the model's (640x480 -> 700x518): depthany_process_input's image_scale, the pos-embed
+    # interpolation, and depthany_process_output's resize back -- the whole reference call against the oracle's restatement
     wide = synth.images(1, 640, 480, seed=10)[0]
     res = small.compute(wide)
     assert res.shape == (480, 640) and res.min() == 0 and res.max() >= 254  # uint8(0.99999994*255) truncates, as in the reference
+    ew, eh = small.image_extent(640, 480)
+    want_n, _ = om.compute(params, oracle.image_scale(wide, oracle.RGB_U8, ew, eh))       # vision.cpp:147-160
+    back = oracle.image_scale(want_n, oracle.ALPHA_F32, 640, 480)                          # depthany_process_output, vision.cpp:162-166
+    want_wide = oracle.image_f32_to_u8(oracle.image_normalize(back)[..., None], oracle.ALPHA_F32, oracle.ALPHA_U8)[..., 0]  # c-api.cpp:72-77
+    d = np.abs(res.astype(int) - want_wide.astype(int))
+    assert d.max() <= 3 and d.mean() < 0.5, (d.max(), d.mean())
 
 
 def test_non_square_extent_vs_oracle(small):

@@ -66,6 +66,41 @@ def test_image_normalize_reference_vectors():
 
 # ---- literal vectors from the reference's tests/test-ml.cpp ---------------------------------
 
+def test_image_scale_reference_vector():
+    """tests/test-image.cpp:186-203 (VISP_TEST(image_scale)): an 8x8 rgba ramp reduced to 4x4 by stb_image_resize
+    (Mitchell, sRGB-correct, alpha-weighted) gives exactly 2 + 8 * index."""
+    img = np.zeros((8, 8, 4), np.uint8)
+    for i in range(64):
+        img[i // 8, i % 8] = [255, 4 * (i // 8), 4 * (i % 8), 255]
+    res = oracle.image_scale(img, oracle.RGBA_U8, 4, 4)
+    want = np.zeros((4, 4, 4), np.uint8)
+    for i in range(16):
+        want[i // 4, i % 4] = [255, 2 + 8 * (i // 4), 2 + 8 * (i % 4), 255]
+    np.testing.assert_array_equal(res, want)
+
+
+def test_image_scale_properties():
+    """Properties of the stb semantics the vector does not cover: constant images stay constant in every format (weights
+    sum to 1, the sRGB tables round-trip all 256 codes); scale 1 is NOT the identity (stb filters with Mitchell at ratio 1);
+    a 4x reduction of a step edge is a real low-pass: one intermediate sample, plateaus kept up to Mitchell's 1-level ringing."""
+    for fmt, ch in ((oracle.RGB_U8, 3), (oracle.RGBA_U8, 4), (oracle.ALPHA_U8, 1)):
+        for v in (0, 1, 17, 128, 254, 255):
+            img = np.full((9, 13, ch), v, np.uint8)
+            for (ow, oh) in ((13, 9), (5, 4), (30, 20)):
+                assert (oracle.image_scale(img, fmt, ow, oh) == v).all(), (fmt, v, ow, oh)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)
+    same = oracle.image_scale(noise, oracle.RGB_U8, 16, 16)
+    assert (same != noise).any() and np.abs(same.astype(int) - noise).mean() < 40
+    step = np.zeros((8, 64, 3), np.uint8)
+    step[:, 30:] = 200
+    red = oracle.image_scale(step, oracle.RGB_U8, 16, 2)[0, :, 0].astype(int)
+    assert (red[:7] == 0).all() and 0 < red[7] < 200 and (np.abs(red[8:] - 200) <= 1).all()
+    f = rng.random((11, 7)).astype(np.float32)
+    up = oracle.image_scale(f, oracle.ALPHA_F32, 21, 33)
+    assert up.shape == (33, 21) and up.min() > -0.2 and up.max() < 1.2  # Catmull-Rom overshoot is bounded
+
+
 def test_transfer_type_conversion():
     assert oracle.transfer_tensor(np.array([4, -1], np.int32), False).ravel().tolist() == [4, -1]
     assert oracle.transfer_tensor(np.array([2.5, -0.5], np.float16), False).ravel().tolist() == [2.5, -0.5]

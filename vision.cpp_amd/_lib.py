@@ -99,7 +99,7 @@ C_API_SYMBOLS = [
     "visp_esrgan_generate_host", "visp_esrgan_enable_timing", "visp_esrgan_read_timing",
     "visp_sam_encode", "visp_sam_read_embedding", "visp_sam_encode_batch_device", "visp_sam_encode_batch_host",
     "visp_sam_weights_arena", "visp_sam_weights_ready", "visp_sam_enable_timing", "visp_sam_read_timing",
-    "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks",
+    "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks", "visp_image_scale",
 ]
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
@@ -187,6 +187,7 @@ def init() -> ctypes.CDLL:
     lib.visp_sam_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
     lib.visp_sam_enable_timing.argtypes = [c_void_p, c_int32]
     lib.visp_sam_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
+    lib.visp_image_scale.argtypes = [POINTER(ImageView), c_int32, c_int32, POINTER(ImageView), POINTER(c_void_p)]
     for name in C_API_SYMBOLS[15:]:
         getattr(lib, name).restype = c_int32
 

@@ -117,6 +117,17 @@ char const* visp_get_last_error(void) { return g_error; }
 
 void visp_image_destroy(visp_image_data* img) { delete img; }
 
+// host-only: the reference's image_scale (src/visp/image.cpp:328-356, what depthany_compute / sam_encode apply to inputs whose
+// extent is not the model's); no device involved
+int32_t visp_image_scale(visp_image_view const* src, int32_t width, int32_t height, visp_image_view* out_image, visp_image_data** out_data) {
+    return handle_errors([&]() {
+        if (!src || !src->data || !out_image || !out_data) throw except("visp_image_scale: null argument");
+        if (src->format < 0 || src->format > int32_t(image_format::alpha_f32)) throw except("Unsupported image format [%d]", src->format);
+        image_view v{i32x2{{src->width, src->height}}, src->stride, image_format(src->format), src->data};
+        return_image(image_scale(v, i32x2{{width, height}}), out_image, out_data);
+    });
+}
+
 int32_t visp_backend_load_all(char const*) { return 1; } // single built-in backend, nothing to load
 
 int32_t visp_device_init(int32_t type, visp_device** out_device) {

@@ -109,38 +109,6 @@ image_data image_normalize(image_view const& src, float min, float max) {
     return dst;
 }
 
-image_data image_scale(image_view const& img, i32x2 target) {
-    int ch = n_channels(img.format);
-    bool fl = is_float(img.format);
-    image_data dst = image_alloc(target, img.format);
-    float sx = float(img.extent[0]) / float(target[0]), sy = float(img.extent[1]) / float(target[1]);
-    for (int y = 0; y < target[1]; ++y) {
-        float fy = (y + 0.5f) * sy - 0.5f;
-        int y0 = (int)std::floor(fy);
-        float ty = fy - y0;
-        int y1 = std::clamp(y0 + 1, 0, img.extent[1] - 1);
-        y0 = std::clamp(y0, 0, img.extent[1] - 1);
-        for (int x = 0; x < target[0]; ++x) {
-            float fx = (x + 0.5f) * sx - 0.5f;
-            int x0 = (int)std::floor(fx);
-            float tx = fx - x0;
-            int x1 = std::clamp(x0 + 1, 0, img.extent[0] - 1);
-            x0 = std::clamp(x0, 0, img.extent[0] - 1);
-            for (int c = 0; c < ch; ++c) {
-                auto at = [&](int xx, int yy) -> float {
-                    if (fl) return reinterpret_cast<const float*>(static_cast<const uint8_t*>(img.data) + (size_t)yy * img.stride)[xx * ch + c];
-                    return float((static_cast<const uint8_t*>(img.data) + (size_t)yy * img.stride)[xx * ch + c]);
-                };
-                float v = at(x0, y0) * (1 - tx) * (1 - ty) + at(x1, y0) * tx * (1 - ty) + at(x0, y1) * (1 - tx) * ty + at(x1, y1) * tx * ty;
-                size_t o = ((size_t)y * target[0] + x) * ch + c;
-                if (fl) reinterpret_cast<float*>(dst.data.get())[o] = v;
-                else dst.data.get()[o] = uint8_t(std::clamp(v + 0.5f, 0.0f, 255.0f));
-            }
-        }
-    }
-    return dst;
-}
-
 image_data image_to_rgb_u8(image_view const& img) {
     if (is_float(img.format)) throw except("Unsupported image format [%d]", int(img.format));
     int sch = n_channels(img.format);

@@ -45,8 +45,8 @@ image_data image_u8_to_f32(image_view const& src, image_format format, const flo
 image_data image_f32_to_u8(image_view const& src, image_format format, float scale = 1, float offset = 0);
 // image.cpp:537-582
 image_data image_normalize(image_view const& img, float min = 0, float max = 1);
-// Bilinear resize (pixel-centre aligned, edge clamp). The reference calls stb_image_resize
-// (image.cpp:328-356); stb is absent here, results are close but not bit-identical.
+// image.cpp:328-356: stb_image_resize v1 semantics (Catmull-Rom enlarging, Mitchell reducing, sRGB-correct for u8, alpha-weighted,
+// edge clamp), restated in image_resize.cpp
 image_data image_scale(image_view const& img, i32x2 target);
 // converts any supported u8 format to tightly packed rgb_u8 (channel map of image.cpp get_channel_map)
 image_data image_to_rgb_u8(image_view const& img);

@@ -73,7 +73,7 @@ class Device:
             self._handle = None
 
 
-_CHANNELS = {0: 4, 1: 4, 2: 4, 3: 3, 4: 1}
+_CHANNELS = {0: 4, 1: 4, 2: 4, 3: 3, 4: 1, 5: 4, 6: 3, 7: 1}
 
 
 class Model:
@@ -262,6 +262,25 @@ class Model:
 
     def sam_encode_batch_device(self, rgb_dev: int, batch: int, out_dev: int, stream: int | None = None):
         check(self._api.visp_sam_encode_batch_device(self._handle, rgb_dev, batch, out_dev, stream))
+
+
+def image_scale(image: np.ndarray, width: int, height: int, format: ImageFormat = ImageFormat.rgb_u8) -> np.ndarray:
+    """The reference's image_scale (src/visp/image.cpp:328-356) on the host: [h, w, ch] u8 or f32 -> [height, width, ch]."""
+    api = lib.get_lib()
+    is_f32 = format.value >= ImageFormat.rgba_f32.value
+    img = np.ascontiguousarray(image, dtype=np.float32 if is_f32 else np.uint8)
+    h, w = img.shape[:2]
+    ch = _CHANNELS[format.value]
+    view = lib.ImageView(w, h, w * ch * img.itemsize, format.value, img.ctypes.data)
+    out_view, out_data = lib.ImageView(), c_void_p()
+    check(api.visp_image_scale(byref(view), width, height, byref(out_view), byref(out_data)))
+    try:
+        n = out_view.height * out_view.stride
+        buf = (ctypes.c_uint8 * n).from_address(out_view.data)
+        res = np.frombuffer(buf, img.dtype).reshape(out_view.height, out_view.width, ch).copy()
+    finally:
+        api.visp_image_destroy(out_data)
+    return res[..., 0] if ch == 1 else res
 
 
 def esrgan_tile_layout(w: int, h: int, scale: int = 1) -> dict:
