@@ -100,6 +100,18 @@ VISP_API int32_t visp_depthany_compute_batch_device(visp_model* m, void const* r
 /* same with host buffers (H2D + compute + D2H on the model's stream, blocking) */
 VISP_API int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w,
                                                   int32_t h, float* out, float* raw_out);
+/* Overlapped host pipeline (the reference's benchmark loop -- upload, compute, download per call, tests/benchmark.cpp:55-91 --
+ * with the transfers hidden): n_slots (2..8) slots of pinned staging + device buffers; submit() chains H2D (copy stream) ->
+ * forward (the model's stream) -> D2H (second copy stream) by events and returns at once with a ticket; wait() blocks until
+ * that batch's normalised depth maps [batch, h, w] f32 are in pinned host memory and returns them (valid until the slot is
+ * reused, i.e. for n_slots - 1 further submits). input() = the next slot's pinned rgb buffer [batch, h, w, 3] to fill in
+ * place (then submit(NULL)); submit(ptr) copies from pageable memory. One thread per pipeline. */
+typedef struct visp_depthany_pipeline visp_depthany_pipeline;
+VISP_API int32_t visp_depthany_pipeline_create(visp_model* m, int32_t batch, int32_t w, int32_t h, int32_t n_slots, visp_depthany_pipeline** out);
+VISP_API void visp_depthany_pipeline_destroy(visp_depthany_pipeline* p);
+VISP_API int32_t visp_depthany_pipeline_input(visp_depthany_pipeline* p, uint8_t** out_pinned);
+VISP_API int32_t visp_depthany_pipeline_submit(visp_depthany_pipeline* p, uint8_t const* rgb_u8_or_null, int32_t* out_ticket);
+VISP_API int32_t visp_depthany_pipeline_wait(visp_depthany_pipeline* p, int32_t ticket, float const** out_pinned);
 /* capture the launch sequence of the current reserved shape into a hipGraph and replay it on
  * every later compute of that shape (enable = 0 turns it off) */
 VISP_API int32_t visp_depthany_use_graph(visp_model* m, int32_t enable);
@@ -131,6 +143,9 @@ VISP_API int32_t visp_esrgan_set_tile_group(visp_model* m, int32_t tiles);
 VISP_API int32_t visp_esrgan_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes);
 VISP_API int32_t visp_esrgan_weights_ready(visp_model* m);
 /* tile_scale(tile_layout(extent, 224, 16), scale): out8 = image w,h, overlap x,y, n_tiles x,y, tile w,h (image.cpp:612-629) */
+/* host-only: read a GGUF file completely (header, key/values, tensor infos, bounds of every tensor's data) as visp_model_load
+ * does before it packs weights; 0 + error message if the file is malformed */
+VISP_API int32_t visp_gguf_validate(char const* filepath, int32_t* out_n_tensors);
 /* host-only image_scale of the reference (src/visp/image.cpp:328-356: stb_image_resize semantics, csrc/image_resize.cpp):
  * any supported format; the result is owned by *out_data (visp_image_destroy) */
 VISP_API int32_t visp_image_scale(visp_image_view const* src, int32_t width, int32_t height, visp_image_view* out_image,

@@ -33,6 +33,12 @@ VX_API int vx_memset(void* ptr, int value, size_t bytes, void* stream);
 VX_API int vx_memcpy_h2d(void* dst, const void* host_src, size_t bytes, void* stream);
 VX_API int vx_memcpy_d2h(void* host_dst, const void* src, size_t bytes, void* stream);
 VX_API int vx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+/* pinned host memory + copies that do NOT synchronise (the overlapped host pipeline: H2D / compute / D2H on three streams) */
+VX_API int vx_malloc_host(void** ptr, size_t bytes);
+VX_API int vx_free_host(void* ptr);
+VX_API int vx_memcpy_h2d_async(void* dst, const void* pinned_src, size_t bytes, void* stream);
+VX_API int vx_memcpy_d2h_async(void* pinned_dst, const void* src, size_t bytes, void* stream);
+VX_API int vx_event_sync(void* ev);
 VX_API int vx_stream_create(void** stream);
 VX_API int vx_stream_destroy(void* stream);
 VX_API int vx_stream_sync(void* stream);

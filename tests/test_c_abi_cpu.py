@@ -272,3 +272,45 @@ def test_image_scale_matches_oracle_and_reference_vector():
                 np.testing.assert_array_equal(got, want)
     with pytest.raises(Exception, match="resize"):
         vision.image_scale(np.zeros((4, 4, 3), np.uint8), 0, 4)
+
+
+def test_gguf_tensor_infos_are_validated(tmp_path):
+    """Crafted headers (64-bit offsets / dims are untrusted): offsets that wrap, dims of 0 or with an overflowing
+    product, unaligned offsets and truncated data are refused with an error, never turned into a pointer."""
+    import struct
+
+    api = L.get_lib()
+    good = tmp_path / "good.gguf"
+    w = gguf.GGUFWriter(good, "depthanything")
+    w.add_tensor("a", np.arange(16, dtype=np.float32))
+    w.add_tensor("b", np.arange(8, dtype=np.float32))
+    w.write()
+    n = C.c_int32()
+    L.check(api.visp_gguf_validate(str(good).encode(), C.byref(n)))
+    assert n.value == 2
+    raw = bytearray(good.read_bytes())
+    # tensor info of "a": name (u64 len + bytes), u32 n_dims, u64 dims[n], u32 type, u64 offset
+    pos = raw.index(b"\x01\x00\x00\x00\x00\x00\x00\x00a") + 9
+    assert struct.unpack_from("<I", raw, pos)[0] == 1 and struct.unpack_from("<Q", raw, pos + 4)[0] == 16
+    dim_at, off_at = pos + 4, pos + 4 + 8 + 4
+
+    def variant(name, at, value):
+        b = bytearray(raw)
+        struct.pack_into("<Q", b, at, value)
+        p = tmp_path / name
+        p.write_bytes(b)
+        return api.visp_gguf_validate(str(p).encode(), None), api.visp_get_last_error()
+
+    for name, at, value, msg in [
+        ("wrap.gguf", off_at, 2 ** 64 - 32, b"out of bounds"),       # base + offset + size wraps
+        ("far.gguf", off_at, 1 << 40, b"out of bounds"),
+        ("unaligned.gguf", off_at, 4, b"out of bounds"),
+        ("zero_dim.gguf", dim_at, 0, b"bad dimension"),
+        ("huge_dim.gguf", dim_at, 2 ** 63, b"bad dimension"),
+        ("big.gguf", dim_at, 1 << 40, b"out of bounds"),              # 4 TiB of f32
+    ]:
+        ok, err = variant(name, at, value)
+        assert ok == 0 and msg in err, (name, err)
+    trunc = tmp_path / "trunc.gguf"
+    trunc.write_bytes(bytes(raw[:-8]))
+    assert api.visp_gguf_validate(str(trunc).encode(), None) == 0 and b"out of bounds" in api.visp_get_last_error()

@@ -259,6 +259,24 @@ def test_upscale_x4_batch_properties(x4):
     assert np.array_equal(regroup, out)
 
 
+def test_upscale_x4_baseline_batch_16(x4):
+    """BASELINE.json configs[2] at its full size: Real-ESRGAN-4x, 256x256 -> 1024x1024, batch 16 (64 tiles of 144 through the
+    23-block net in one call). One image against the oracle, size-independent properties on the rest: every image equals
+    its single-image run, duplicated inputs give identical outputs, alpha is opaque."""
+    from visioncpp_amd import synth
+    m, om, cfg = x4
+    imgs = synth.images(16, 256, 256, seed=16)
+    imgs[9] = imgs[2]
+    out = m.upscale_batch(imgs)
+    assert out.shape == (16, 1024, 1024, 4) and (out[..., 3] == 255).all()
+    assert np.array_equal(out[9], out[2])
+    ref = O.esrgan_compute(om, cfg.scale, cfg.num_blocks, imgs[15], O.RGB_U8)
+    d = np.abs(out[15].astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 3 and d.mean() < 0.25, (d.max(), d.mean())
+    for i in (0, 7):
+        assert np.array_equal(m.upscale_batch(imgs[i:i + 1])[0], out[i])
+
+
 def test_c_api_compute_esrgan(tiny):
     """visp_model_compute family 4 (c-api.cpp:103-106): one image view in, rgba_u8 image at extent*scale out."""
     from visioncpp_amd import synth

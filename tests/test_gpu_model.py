@@ -202,6 +202,32 @@ def test_non_square_extent_vs_oracle(small):
     assert _rel(raw[0], want_raw) < 3e-2
 
 
+def test_overlapped_host_pipeline_is_bit_identical(small):
+    """visp_depthany_pipeline_*: batches streamed through 3 slots (upload / compute / download overlapped on three streams)
+    give exactly the synchronous entry point's results, in submission order, from pageable and from pinned input; a slot
+    cannot be reused before its result was read."""
+    imgs = synth.images(8, 518, 518, seed=91)
+    want = small.compute_batch(imgs)
+    small.use_graph(True)
+    pipe = vision.DepthPipeline(small, 2, 518, 518, n_slots=3)
+    tickets = [pipe.submit(imgs[0:2]), pipe.submit(imgs[2:4])]
+    got = [pipe.wait(tickets[0])]
+    pipe.input_view()[...] = imgs[4:6]       # fill the pinned staging buffer in place
+    tickets.append(pipe.submit(None))
+    tickets.append(pipe.submit(imgs[6:8]))
+    got += [pipe.wait(t) for t in tickets[1:]]
+    np.testing.assert_array_equal(np.concatenate(got), want)
+    a, b, c = pipe.submit(imgs[0:2]), pipe.submit(imgs[2:4]), pipe.submit(imgs[4:6])
+    with pytest.raises(L.Error, match="still holds an unread result"):
+        pipe.submit(imgs[6:8])
+    for t, lo in ((a, 0), (b, 2), (c, 4)):
+        np.testing.assert_array_equal(pipe.wait(t), want[lo:lo + 2])
+    with pytest.raises(L.Error, match="nothing in flight"):
+        pipe.wait(a)
+    pipe.close()
+    small.use_graph(False)
+
+
 def test_pkg_check_smoke(small):
     """The reference's installed-package smoke test (scripts/pkg-check/main.cpp:22-44): a 64x64 zero image,
     output extent equals input extent and the mean is finite."""

@@ -240,6 +240,26 @@ def test_batch_is_independent_of_position_and_size(sam):
     assert np.array_equal(alone[0], sam["got"][1]) and np.array_equal(three[2], alone[0]) and np.array_equal(three[0], sam["got"][0])
 
 
+def test_encoder_batch_16(sam):
+    """A batch of 16 images at 1024x1024 (the per-launch batch the bench's throughput figure was tuned at; configs[4] shards a
+    1k-image batch over ranks): first and last image against the f32 oracle, the rest by batch independence."""
+    from visioncpp_amd import synth
+    m = sam["model"]
+    imgs = synth.images(16, 1024, 1024, seed=160)
+    imgs[11] = imgs[3]
+    got = m.sam_encode_batch(imgs)
+    assert got.shape == (16, 64, 64, 256) and np.isfinite(got).all()
+    assert np.array_equal(got[11], got[3])
+    cfg = sam["cfg"]
+    params = O.tinyvit_params(cfg.img_size, cfg.layers())
+    for i in (0, 15):
+        x = (imgs[i].astype(np.float32) / np.float32(255.0) - MEAN) / STD
+        want = O.tinyvit_encode(sam["om"], params, x)
+        err = np.abs(got[i] - want.reshape(got[i].shape))
+        assert err.mean() < 6e-3 and err.max() < 0.1, (i, err.mean(), err.max())
+    assert np.array_equal(m.sam_encode_batch(imgs[5:6])[0], got[5])
+
+
 def test_sam_encode_pads_by_edge_replication(sam):
     """sam_process_input (mobile-sam.cpp:533-547): longest side already 1024 -> no resize, the square is filled with
     clamped source coordinates. Also exercises the bgra channel map."""
@@ -351,6 +371,50 @@ def test_decoder_matches_oracle_on_the_same_embedding(sam_full, prompt):
     assert got.shape == want.shape == (1024, 1024) and set(np.unique(got)) <= {0, 255}
     if int(np.argmax(iou[:3])) == int(np.argmax(wiou[:3])):
         assert (got != want).mean() < 5e-3 and _iou(got, want) > 0.99, ((got != want).mean(), _iou(got, want))
+
+
+def test_near_tied_iou_predictions_and_arena_only_load(tmp_path):
+    """(1) The iou head decides which mask sam_compute returns (vision.cpp:80-82). With rows 0 and 1 of its last layer equal
+    and biases 1e-4 apart the two predictions differ by a fifth of an f16 ulp (4.9e-4 near 0.9): the host-side f32 head must still rank them
+    (an all-f16 decoder returned the other mask). (2) A model loaded WITHOUT data whose arena is then filled from another
+    model's (the RCCL broadcast path) runs sam_compute with the same result: the prompt-encoder tables and the iou head
+    are rebuilt from the arena in sam_weights_ready."""
+    import ctypes as C
+
+    from visioncpp_amd import _lib as L
+    from visioncpp_amd import synth, vision
+    cfg = synth.TINYVIT_5M
+    enc_sd, dec_sd = synth.tinyvit_state_dict(cfg, 2), synth.sam_decoder_state_dict(11)
+    wk = [k for k in dec_sd if k.endswith("iou_prediction_head.layers.2.weight")][0]
+    bk = wk.replace("weight", "bias")
+    dec_sd[wk][1] = dec_sd[wk][0]
+    dec_sd[wk][2] = dec_sd[wk][0]
+    dec_sd[bk][1] = dec_sd[bk][0] + np.float32(1e-4)
+    dec_sd[bk][2] = dec_sd[bk][0] - np.float32(0.25)
+    path = synth.write_mobile_sam_gguf(tmp_path / "tie.gguf", cfg, enc_sd=enc_sd, dec_sd=dec_sd)
+    dev = vision.Device.init(vision.Backend.gpu)
+    model = vision.Model.load(path, dev)
+    model.enable_captures(True)
+    img = synth.images(1, 1024, 1024, seed=31)[0]
+    embed = model.sam_encode(img)
+    got = model.sam_compute([700, 300])
+    masks, iou = model.sam_read_masks()
+    tensors, conv2d = synth.mobile_sam_gguf_tensors(enc_sd, dec_sd)
+    want, wiou, wmasks = O.sam_compute(O.Model(tensors, conv2d, "whcn"), embed, 1024, 1024, [700, 300], return_all=True)
+    assert abs((wiou[1] - wiou[0]) - 1e-4) < 1e-5 and abs(wiou[0]) > 0.5  # a fifth of the f16 spacing at this magnitude
+    assert iou[1] > iou[0] > iou[2] and abs((iou[1] - iou[0]) - 1e-4) < 3e-5
+    assert int(np.argmax(iou[:3])) == int(np.argmax(wiou[:3])) == 1
+    assert (got != want).mean() < 5e-3
+
+    other = vision.Model.load(path, dev, vision.Arch.sam, no_upload=True)
+    src, n = model.weights_arena()
+    dst, n2 = other.weights_arena()
+    assert n == n2
+    L.vx_check(L.get_lib().vx_memcpy_d2d(dst, src, n, None))
+    L.vx_check(L.get_lib().vx_stream_sync(None))
+    other.weights_ready()
+    other.sam_encode(img)
+    np.testing.assert_array_equal(other.sam_compute([700, 300]), got)
 
 
 def test_model_compute_is_encode_plus_compute(sam_full):

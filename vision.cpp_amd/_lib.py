@@ -92,6 +92,7 @@ C_API_SYMBOLS = [
     "visp_hip_device_init", "visp_model_load_ex", "visp_depthany_weights_arena", "visp_depthany_weights_ready",
     "visp_depthany_get_info", "visp_depthany_image_extent", "visp_depthany_reserve",
     "visp_depthany_compute_batch_device", "visp_depthany_compute_batch_host", "visp_depthany_use_graph", "visp_depthany_set_schedule",
+    "visp_depthany_pipeline_create", "visp_depthany_pipeline_destroy", "visp_depthany_pipeline_input", "visp_depthany_pipeline_submit", "visp_depthany_pipeline_wait",
     "visp_depthany_enable_captures", "visp_depthany_read_capture", "visp_depthany_enable_timing",
     "visp_depthany_read_timing",
     "visp_esrgan_get_info", "visp_esrgan_set_tile_group", "visp_esrgan_weights_arena", "visp_esrgan_weights_ready",
@@ -99,11 +100,11 @@ C_API_SYMBOLS = [
     "visp_esrgan_generate_host", "visp_esrgan_enable_timing", "visp_esrgan_read_timing",
     "visp_sam_encode", "visp_sam_read_embedding", "visp_sam_encode_batch_device", "visp_sam_encode_batch_host",
     "visp_sam_weights_arena", "visp_sam_weights_ready", "visp_sam_enable_timing", "visp_sam_read_timing",
-    "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks", "visp_image_scale",
+    "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks", "visp_image_scale", "visp_gguf_validate",
 ]
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
-    "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
+    "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_malloc_host", "vx_free_host", "vx_memcpy_h2d_async", "vx_memcpy_d2h_async", "vx_event_sync", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
     "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_stream_wait_event", "vx_graph_begin_capture",
     "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_conv3x3_supported", "vx_conv3x3_f16",
     "vx_attention_f16",
@@ -161,6 +162,12 @@ def init() -> ctypes.CDLL:
     lib.visp_depthany_compute_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.visp_depthany_use_graph.argtypes = [c_void_p, c_int32]
     lib.visp_depthany_set_schedule.argtypes = [c_void_p, c_int32]
+    lib.visp_depthany_pipeline_create.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+    lib.visp_depthany_pipeline_destroy.argtypes = [c_void_p]
+    lib.visp_depthany_pipeline_destroy.restype = None
+    lib.visp_depthany_pipeline_input.argtypes = [c_void_p, POINTER(c_void_p)]
+    lib.visp_depthany_pipeline_submit.argtypes = [c_void_p, c_void_p, POINTER(c_int32)]
+    lib.visp_depthany_pipeline_wait.argtypes = [c_void_p, c_int32, POINTER(c_void_p)]
     lib.visp_depthany_enable_captures.argtypes = [c_void_p, c_int32]
     lib.visp_depthany_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
     lib.visp_depthany_enable_timing.argtypes = [c_void_p, c_int32]
@@ -187,9 +194,11 @@ def init() -> ctypes.CDLL:
     lib.visp_sam_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
     lib.visp_sam_enable_timing.argtypes = [c_void_p, c_int32]
     lib.visp_sam_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
+    lib.visp_gguf_validate.argtypes = [c_char_p, POINTER(c_int32)]
     lib.visp_image_scale.argtypes = [POINTER(ImageView), c_int32, c_int32, POINTER(ImageView), POINTER(c_void_p)]
     for name in C_API_SYMBOLS[15:]:
         getattr(lib, name).restype = c_int32
+    lib.visp_depthany_pipeline_destroy.restype = None
 
     lib.vx_last_error.restype = c_char_p
     lib.vx_device_info.argtypes = [c_int, c_char_p, c_int, c_char_p, c_int, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_int)]

@@ -157,6 +157,14 @@ int32_t visp_model_detect_family(char const* filepath, int32_t* out_family) {
     });
 }
 
+// host-only: parses the whole file (header AND tensor data ranges) without touching a device; what visp_model_load checks first
+int32_t visp_gguf_validate(char const* filepath, int32_t* out_n_tensors) {
+    return handle_errors([&]() {
+        model_file file = model_load(filepath, /*header_only=*/false);
+        if (out_n_tensors) *out_n_tensors = (int32_t)file.tensors.size();
+    });
+}
+
 int32_t visp_model_load_ex(char const* filepath, visp_device const* dev, int32_t arch, int32_t flags, visp_model** out) {
     return handle_errors([&]() {
         if (!dev) throw except("device handle is null");
@@ -269,6 +277,29 @@ int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb, int3
     return handle_errors([&]() {
         if (!rgb || !out) throw except("depthany: null input/output pointer");
         depthany_compute_batch_host(as_depthany(m), rgb, batch, w, h, out, raw_out);
+    });
+}
+
+int32_t visp_depthany_pipeline_create(visp_model* m, int32_t batch, int32_t w, int32_t h, int32_t n_slots, visp_depthany_pipeline** out) {
+    return handle_errors([&]() { *out = reinterpret_cast<visp_depthany_pipeline*>(depthany_pipeline_create(as_depthany(m), batch, w, h, n_slots)); });
+}
+void visp_depthany_pipeline_destroy(visp_depthany_pipeline* p) { delete reinterpret_cast<depthany_pipeline*>(p); }
+int32_t visp_depthany_pipeline_input(visp_depthany_pipeline* p, uint8_t** out_pinned) {
+    return handle_errors([&]() {
+        if (!p || !out_pinned) throw except("depthany pipeline: null argument");
+        *out_pinned = depthany_pipeline_input(*reinterpret_cast<depthany_pipeline*>(p));
+    });
+}
+int32_t visp_depthany_pipeline_submit(visp_depthany_pipeline* p, uint8_t const* rgb_u8, int32_t* out_ticket) {
+    return handle_errors([&]() {
+        if (!p || !out_ticket) throw except("depthany pipeline: null argument");
+        *out_ticket = depthany_pipeline_submit(*reinterpret_cast<depthany_pipeline*>(p), rgb_u8);
+    });
+}
+int32_t visp_depthany_pipeline_wait(visp_depthany_pipeline* p, int32_t ticket, float const** out_pinned) {
+    return handle_errors([&]() {
+        if (!p || !out_pinned) throw except("depthany pipeline: null argument");
+        *out_pinned = depthany_pipeline_wait(*reinterpret_cast<depthany_pipeline*>(p), ticket);
     });
 }
 

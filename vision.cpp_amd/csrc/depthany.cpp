@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 #include "../../include/visp_hip_kernels.h"
 #include "visp_util.h"
@@ -1062,6 +1063,82 @@ void depthany_compute_batch_host(depthany_model& m, uint8_t const* rgb, int batc
     m.use_graph = g;
     VX(vx_memcpy_d2h(out, m.ws.buf["out"], out_bytes, s));
     if (raw_out) VX(vx_memcpy_d2h(raw_out, m.ws.buf["depth"], out_bytes, s));
+}
+
+//
+// overlapped host pipeline
+
+depthany_pipeline* depthany_pipeline_create(depthany_model& m, int batch, int w, int h, int n_slots) {
+    if (n_slots < 2 || n_slots > 8) throw except("depthany pipeline: %d slots (2..8)", n_slots);
+    VX(vx_set_device(m.backend->index));
+    depthany_reserve(m, batch, w, h);
+    auto p = std::make_unique<depthany_pipeline>();
+    p->model = &m; p->batch = batch; p->w = w; p->h = h; p->n_slots = n_slots;
+    p->in_bytes = (size_t)batch * h * w * 3;
+    p->out_bytes = (size_t)batch * h * w * 4;
+    VX(vx_stream_create(&p->h2d_stream));
+    VX(vx_stream_create(&p->d2h_stream));
+    p->slots.resize((size_t)n_slots);
+    for (auto& s : p->slots) {
+        VX(vx_malloc_host(&s.pin_in, p->in_bytes));
+        VX(vx_malloc_host(&s.pin_out, p->out_bytes));
+        VX(vx_malloc(&s.dev_in, p->in_bytes));
+        VX(vx_malloc(&s.dev_out, p->out_bytes));
+        VX(vx_event_create(&s.uploaded));
+        VX(vx_event_create(&s.computed));
+        VX(vx_event_create(&s.downloaded));
+    }
+    return p.release();
+}
+
+depthany_pipeline::~depthany_pipeline() {
+    if (model) vx_set_device(model->backend->index);
+    for (auto& s : slots) {
+        if (s.busy) vx_event_sync(s.downloaded);
+        vx_free_host(s.pin_in); vx_free_host(s.pin_out);
+        vx_free(s.dev_in); vx_free(s.dev_out);
+        vx_event_destroy(s.uploaded); vx_event_destroy(s.computed); vx_event_destroy(s.downloaded);
+    }
+    if (h2d_stream) vx_stream_destroy(h2d_stream);
+    if (d2h_stream) vx_stream_destroy(d2h_stream);
+}
+
+uint8_t* depthany_pipeline_input(depthany_pipeline& p) {
+    auto& s = p.slots[(size_t)p.next];
+    if (s.busy) throw except("depthany pipeline: slot %d still holds an unread result (wait for its ticket first)", p.next);
+    return static_cast<uint8_t*>(s.pin_in);
+}
+
+int depthany_pipeline_submit(depthany_pipeline& p, uint8_t const* rgb) {
+    depthany_model& m = *p.model;
+    VX(vx_set_device(m.backend->index));
+    const int ticket = p.next;
+    auto& s = p.slots[(size_t)ticket];
+    if (s.busy) throw except("depthany pipeline: slot %d still holds an unread result (wait for its ticket first)", ticket);
+    if (m.ws.B != p.batch || m.ws.W != p.w || m.ws.H != p.h) depthany_reserve(m, p.batch, p.w, p.h);
+    if (rgb && rgb != s.pin_in) memcpy(s.pin_in, rgb, p.in_bytes);
+    void* cs = m.backend->stream;
+    VX(vx_memcpy_h2d_async(s.dev_in, s.pin_in, p.in_bytes, p.h2d_stream));
+    VX(vx_event_record(s.uploaded, p.h2d_stream));
+    VX(vx_stream_wait_event(cs, s.uploaded));
+    depthany_compute_batch_device(m, s.dev_in, p.batch, p.w, p.h, s.dev_out, nullptr, cs);
+    VX(vx_event_record(s.computed, cs));
+    VX(vx_stream_wait_event(p.d2h_stream, s.computed));
+    VX(vx_memcpy_d2h_async(s.pin_out, s.dev_out, p.out_bytes, p.d2h_stream));
+    VX(vx_event_record(s.downloaded, p.d2h_stream));
+    s.busy = true;
+    p.next = (p.next + 1) % p.n_slots;
+    return ticket;
+}
+
+float const* depthany_pipeline_wait(depthany_pipeline& p, int ticket) {
+    if (ticket < 0 || ticket >= p.n_slots) throw except("depthany pipeline: bad ticket %d", ticket);
+    auto& s = p.slots[(size_t)ticket];
+    if (!s.busy) throw except("depthany pipeline: ticket %d has nothing in flight", ticket);
+    VX(vx_set_device(p.model->backend->index));
+    VX(vx_event_sync(s.downloaded));
+    s.busy = false;
+    return static_cast<float const*>(s.pin_out);
 }
 
 // reference src/visp/vision.cpp:147-167

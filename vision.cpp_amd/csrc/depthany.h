@@ -136,6 +136,33 @@ void depthany_reserve(depthany_model&, int batch, int w, int h);
 void depthany_compute_batch_device(depthany_model&, void const* rgb_dev, int batch, int w, int h, void* out_dev,
                                    void* raw_out_dev, void* stream);
 void depthany_compute_batch_host(depthany_model&, uint8_t const* rgb, int batch, int w, int h, float* out, float* raw_out);
+
+// Overlapped host pipeline: batches of `batch` images of one extent flow through n_slots slots; for slot k the upload of its
+// input (pinned staging -> HBM on a copy stream), the forward (the model's compute stream) and the download of its output
+// (HBM -> pinned, second copy stream) are chained by events, so the upload of batch k+1 and the download of batch k-1 run
+// under the compute of batch k. The reference times upload + compute + download per call (tests/benchmark.cpp:55-91); this
+// is that loop with the transfers hidden.
+struct depthany_pipeline {
+    depthany_model* model = nullptr;
+    int batch = 0, w = 0, h = 0, n_slots = 0;
+    size_t in_bytes = 0, out_bytes = 0;
+    struct slot {
+        void *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr;
+        void *uploaded = nullptr, *computed = nullptr, *downloaded = nullptr; // events
+        bool busy = false;
+    };
+    std::vector<slot> slots;
+    void *h2d_stream = nullptr, *d2h_stream = nullptr;
+    int next = 0;
+    ~depthany_pipeline();
+};
+depthany_pipeline* depthany_pipeline_create(depthany_model&, int batch, int w, int h, int n_slots);
+// next slot's pinned input buffer (fill it, then submit(nullptr)) -- or pass pageable memory to submit and it is copied in
+uint8_t* depthany_pipeline_input(depthany_pipeline&);
+int depthany_pipeline_submit(depthany_pipeline&, uint8_t const* rgb_or_null); // returns the ticket (= slot index)
+// blocks until that batch is back in pinned host memory; returns it (valid until the slot is submitted again)
+float const* depthany_pipeline_wait(depthany_pipeline&, int ticket);
+
 // reference API: any extent, any u8 colour format, batch 1 (vision.cpp:147-167) -> alpha_f32 at the input extent
 image_data depthany_compute(depthany_model&, image_view image);
 

@@ -1,3 +1,4 @@
+#include <cstdint>
 #include "gguf.h"
 
 #include <cstring>
@@ -111,24 +112,37 @@ model_file model_load(const char* filepath, bool header_only) {
         t.name = r.str();
         uint32_t nd = r.get<uint32_t>();
         if (nd > 4) throw except("Failed to load GGUF model: %s (tensor %s has %u dims)", filepath, t.name.c_str(), nd);
-        for (uint32_t d = 0; d < nd; ++d) t.ne[d] = (int64_t)r.get<uint64_t>();
+        // untrusted 64-bit header fields: every dimension >= 1 and the element / byte counts overflow-checked
+        uint64_t n_elem = 1;
+        for (uint32_t d = 0; d < nd; ++d) {
+            const uint64_t ne = r.get<uint64_t>();
+            if (ne == 0 || ne > (uint64_t)INT64_MAX || n_elem > (uint64_t)INT64_MAX / ne)
+                throw except("Failed to load GGUF model: %s (tensor %s: bad dimension %u)", filepath, t.name.c_str(), d);
+            n_elem *= ne;
+            t.ne[d] = (int64_t)ne;
+        }
         t.type = (int32_t)r.get<uint32_t>();
         offsets[i] = r.get<uint64_t>();
         size_t ts = type_size(t.type);
         if (ts == 0) throw except("Failed to load GGUF model: %s (tensor %s: unsupported type %d)", filepath, t.name.c_str(), t.type);
-        t.n_bytes = (size_t)t.n_elements() * ts;
+        if (n_elem > (uint64_t)SIZE_MAX / ts) throw except("Failed to load GGUF model: %s (tensor %s: size overflows)", filepath, t.name.c_str());
+        t.n_bytes = (size_t)n_elem * ts;
         f.index.emplace(t.name, (int)i);
     }
     uint64_t align = 32;
     if (const gguf_value* a = f.find_key("general.alignment")) align = a->u ? a->u : 32;
+    if (align > (1u << 20) || (align & (align - 1)) != 0) throw except("Failed to load GGUF model: %s (bad general.alignment)", filepath);
     size_t base = (size_t)(r.p - f.buffer.data());
     base = (base + align - 1) / align * align;
     if (!header_only) {
+        if (base > f.buffer.size()) throw except("Failed to load GGUF model: %s (truncated before the tensor data)", filepath);
+        const size_t avail = f.buffer.size() - base;
         for (uint64_t i = 0; i < n_tensors; ++i) {
             gguf_tensor& t = f.tensors[i];
-            if (base + offsets[i] + t.n_bytes > f.buffer.size())
+            // no sum of untrusted values: offset <= avail, size <= avail - offset, offset aligned
+            if (offsets[i] > avail || t.n_bytes > avail - (size_t)offsets[i] || offsets[i] % align != 0)
                 throw except("Failed to load GGUF model: %s (tensor %s out of bounds)", filepath, t.name.c_str());
-            t.data = f.buffer.data() + base + offsets[i];
+            t.data = f.buffer.data() + base + (size_t)offsets[i];
         }
     }
     return f;

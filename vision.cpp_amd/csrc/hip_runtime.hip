@@ -96,6 +96,26 @@ int vx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
     VX_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
     return 1;
 }
+int vx_malloc_host(void** ptr, size_t bytes) {
+    VX_CHECK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return 1;
+}
+int vx_free_host(void* ptr) {
+    if (ptr) VX_CHECK(hipHostFree(ptr));
+    return 1;
+}
+int vx_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* stream) {
+    VX_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return 1;
+}
+int vx_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream) {
+    VX_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return 1;
+}
+int vx_event_sync(void* ev) {
+    VX_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)));
+    return 1;
+}
 int vx_stream_create(void** stream) {
     hipStream_t s;
     VX_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));

@@ -328,6 +328,14 @@ sam_model* sam_load_model(char const* filepath, backend_device const& dev, int f
             for (int l = 0; l < 3; ++l) D.hyper[i][l] = pk.linear("dec.output_hypernetworks_mlps." + std::to_string(i) + ".layers." + std::to_string(l));
         for (int l = 0; l < 3; ++l) D.iou_head[l] = pk.linear("dec.iou_prediction_head.layers." + std::to_string(l));
         if (D.hyper[0][2].n_real != D.up_c2 || D.iou_head[2].n_real != 4) throw except("mobile-sam: hypernetwork / iou head output widths do not match");
+        D.tables_off = ab.alloc((size_t)11 * dim * 4);
+        if (with_data) {
+            float* tb = reinterpret_cast<float*>(ab.data.data() + D.tables_off);
+            memcpy(tb, D.gaussian.data(), (size_t)dim * 4);
+            for (int i = 0; i < 4; ++i) memcpy(tb + (size_t)(1 + i) * dim, D.point_embed[i].data(), (size_t)dim * 4);
+            memcpy(tb + (size_t)5 * dim, D.not_a_point.data(), (size_t)dim * 4);
+            memcpy(tb + (size_t)6 * dim, D.output_tokens.data(), (size_t)5 * dim * 4);
+        }
     }
 
     VX(vx_set_device(dev.index));
@@ -336,12 +344,39 @@ sam_model* sam_load_model(char const* filepath, backend_device const& dev, int f
     if (with_data) {
         VX(vx_memcpy_h2d(model->weight_arena.ptr, ab.data.data(), ab.data.size(), dev.stream));
         VX(vx_stream_sync(dev.stream));
-        model->weights_uploaded = true;
+        sam_weights_ready(*model);
     }
     return model.release();
 }
 
-void sam_weights_ready(sam_model& m) { m.weights_uploaded = true; }
+// The arena is complete (uploaded here, or received from the rank that read the file): rebuild everything the host computes
+// with from it -- the prompt encoder's tables and the f32 copy of the iou head (vision.cpp:80-82 picks a mask by its output).
+void sam_weights_ready(sam_model& m) {
+    samdec_weights& D = m.dec;
+    if (D.present) {
+        VX(vx_set_device(m.backend->index));
+        void* s = m.backend->stream;
+        const uint8_t* wa = static_cast<const uint8_t*>(m.weight_arena.ptr);
+        const int dim = D.dim;
+        std::vector<float> tb((size_t)11 * dim);
+        VX(vx_memcpy_d2h(tb.data(), wa + D.tables_off, tb.size() * 4, s));
+        D.gaussian.assign(tb.begin(), tb.begin() + dim);
+        for (int i = 0; i < 4; ++i) D.point_embed[i].assign(tb.begin() + (size_t)(1 + i) * dim, tb.begin() + (size_t)(2 + i) * dim);
+        D.not_a_point.assign(tb.begin() + (size_t)5 * dim, tb.begin() + (size_t)6 * dim);
+        D.output_tokens.assign(tb.begin() + (size_t)6 * dim, tb.end());
+        for (int l = 0; l < 3; ++l) {
+            packed_gemm const& g = D.iou_head[l];
+            std::vector<uint16_t> w16((size_t)g.N * g.K);
+            VX(vx_memcpy_d2h(w16.data(), wa + g.w, w16.size() * 2, s));
+            D.iou_w[l].resize((size_t)g.n_real * g.k_real);
+            for (int n = 0; n < g.n_real; ++n)
+                for (int k = 0; k < g.k_real; ++k) D.iou_w[l][(size_t)n * g.k_real + k] = f16_to_f32(w16[(size_t)n * g.K + k]);
+            D.iou_b[l].assign((size_t)g.n_real, 0.0f);
+            if (g.b != SIZE_MAX) VX(vx_memcpy_d2h(D.iou_b[l].data(), wa + g.b, (size_t)g.n_real * 4, s));
+        }
+    }
+    m.weights_uploaded = true;
+}
 
 sam_model::~sam_model() {
     vx_free(ws.ptr);
@@ -756,19 +791,32 @@ image_data sam_compute(sam_model& m, int const* prompt, int n_prompt) {
     }
     // masks[i][pixel] = <upscaled[pixel], hyper_in[i]> (mobile-sam.cpp:472-473): M = 16 Nk pixels, K = up_c2, 4 of 8 stored columns real
     raw_gemm(u2, 16 * Nk, D.up_c2, hy, nullptr, 32, 64, 8, masks_d, 8, VX_EPI_F16);
-    // iou prediction head on the iou token
-    linear(D.iou_head[0], Q, 1, ha, VX_EPI_F16_RELU);
-    linear(D.iou_head[1], ha, 1, hb, VX_EPI_F16_RELU);
+    // iou prediction head on the iou token (mobile-sam.cpp:476-481): three small linears on ONE token whose output decides
+    // which mask is returned (vision.cpp:80-82), so it runs in f32 on the host from the token's values: an f16 pipeline
+    // (ulp 5e-4 near 1) can flip the choice between near-tied predictions and return an entirely different mask
+    const size_t n_px = (size_t)mask_size * mask_size;
+    (void)iou_d;
     {
-        packed_gemm const& g = D.iou_head[2];
-        raw_gemm(hb, 1, g.k_real, wa + g.w, bias_of(g), g.N, g.K, 8, iou_d, 8, VX_EPI_F16);
+        std::vector<uint16_t> t16((size_t)dim);
+        VX(vx_memcpy_d2h(t16.data(), Q, t16.size() * 2, s));
+        VX(vx_stream_sync(s));
+        std::vector<float> cur((size_t)dim), nxt;
+        for (int i = 0; i < dim; ++i) cur[(size_t)i] = f16_to_f32(t16[(size_t)i]);
+        for (int l = 0; l < 3; ++l) {
+            packed_gemm const& g = D.iou_head[l];
+            nxt.assign((size_t)g.n_real, 0.0f);
+            for (int n = 0; n < g.n_real; ++n) {
+                float acc = 0.0f;
+                const float* wr = D.iou_w[l].data() + (size_t)n * g.k_real;
+                for (int k = 0; k < g.k_real; ++k) acc += wr[k] * cur[(size_t)k];
+                acc += D.iou_b[l][(size_t)n];
+                nxt[(size_t)n] = l < 2 ? std::max(acc, 0.0f) : acc;
+            }
+            cur.swap(nxt);
+        }
+        for (int i = 0; i < 4; ++i) m.last_iou[i] = cur[(size_t)i];
     }
     // the decoder's only host decision: best of the FIRST THREE masks by predicted iou (vision.cpp:80-82)
-    const size_t n_px = (size_t)mask_size * mask_size;
-    std::vector<uint16_t> ih(8);
-    VX(vx_memcpy_d2h(ih.data(), iou_d, 16, s));
-    VX(vx_stream_sync(s));
-    for (int i = 0; i < 4; ++i) m.last_iou[i] = f16_to_f32(ih[i]);
     const int idx = int(std::max_element(m.last_iou, m.last_iou + 3) - m.last_iou);
     // sam_process_mask (mobile-sam.cpp:556-583): mask -> image_size^2, crop to the scaled extent, resize to the image, threshold
     const i32x2 target = m.image_extent;

@@ -54,6 +54,11 @@ struct samdec_weights {
     packed_vec up_norm_w, up_norm_b;
     int up_c1 = 0, up_c2 = 0;
     packed_gemm hyper[4][3], iou_head[3];
+    // The prompt encoder's tables above and the iou head are host arithmetic: their f32 values ALSO live in the weight arena
+    // (tables_off: gaussian | point_embed[4] | not_a_point | output_tokens = 11 dim floats; the iou head as its packed GEMMs),
+    // so that a rank whose arena arrived by RCCL broadcast (load_no_upload) rebuilds them in sam_weights_ready.
+    size_t tables_off = SIZE_MAX;
+    std::vector<float> iou_w[3], iou_b[3]; // host f32 copies [n][k] of the f16-rounded iou head weights, biases
 };
 
 struct sam_model : model_base { // vision.h sam_model counterpart (encoder part)

@@ -264,6 +264,48 @@ class Model:
         check(self._api.visp_sam_encode_batch_device(self._handle, rgb_dev, batch, out_dev, stream))
 
 
+class DepthPipeline:
+    """Overlapped host pipeline over visp_depthany_pipeline_* (include/visp_c_api.h): submit() returns a ticket at once, wait()
+    returns that batch's [batch, h, w] f32 depth maps; up to n_slots - 1 batches may be in flight."""
+
+    def __init__(self, model: "Model", batch: int, w: int, h: int, n_slots: int = 3):
+        self._api, self._model = model._api, model
+        self.batch, self.w, self.h, self.n_slots = batch, w, h, n_slots
+        p = c_void_p()
+        check(self._api.visp_depthany_pipeline_create(model._handle, batch, w, h, n_slots, byref(p)))
+        self._p = p
+
+    def input_view(self) -> np.ndarray:
+        """The next slot's pinned input buffer as a writable [batch, h, w, 3] uint8 array (fill it, then submit(None))."""
+        ptr = c_void_p()
+        check(self._api.visp_depthany_pipeline_input(self._p, byref(ptr)))
+        n = self.batch * self.h * self.w * 3
+        return np.frombuffer((ctypes.c_uint8 * n).from_address(ptr.value), np.uint8).reshape(self.batch, self.h, self.w, 3)
+
+    def submit(self, images: np.ndarray | None) -> int:
+        t = ctypes.c_int32()
+        if images is not None:
+            images = np.ascontiguousarray(images, dtype=np.uint8)
+            assert images.shape == (self.batch, self.h, self.w, 3)
+        check(self._api.visp_depthany_pipeline_submit(self._p, images.ctypes.data if images is not None else None, byref(t)))
+        return t.value
+
+    def wait(self, ticket: int, copy: bool = True) -> np.ndarray:
+        ptr = c_void_p()
+        check(self._api.visp_depthany_pipeline_wait(self._p, ticket, byref(ptr)))
+        n = self.batch * self.h * self.w
+        a = np.frombuffer((ctypes.c_float * n).from_address(ptr.value), np.float32).reshape(self.batch, self.h, self.w)
+        return a.copy() if copy else a
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._api.visp_depthany_pipeline_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        self.close()
+
+
 def image_scale(image: np.ndarray, width: int, height: int, format: ImageFormat = ImageFormat.rgb_u8) -> np.ndarray:
     """The reference's image_scale (src/visp/image.cpp:328-356) on the host: [h, w, ch] u8 or f32 -> [height, width, ch]."""
     api = lib.get_lib()
