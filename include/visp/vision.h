@@ -1,0 +1,201 @@
+// visp/vision.h -- the source-level C++ API of the MI355X backend, shaped like the reference's public header
+// (reference include/visp/vision.h:124-347, include/visp/image.h:17-110, include/visp/ml.h:32-64): same namespace, type and
+// function names, argument meaning and error behaviour (exceptions carrying the library's message), so that a C++ caller of
+// the reference's high-level API -- scripts/pkg-check/main.cpp:22-44 is the model -- builds against this backend unchanged.
+// Header-only over the binary-stable C ABI (include/visp_c_api.h, lib/libvisioncpp.so): link with -lvisioncpp.
+//
+// Covered: backend_init / backend_device, image_view / image_data / image_alloc / image_clear / image_scale, and per family
+// *_load_model + *_compute for depth_anything, esrgan and sam (sam_encode + sam_compute with a point or a box).
+// Not covered (this backend has no graph IR): the ml.h layer -- compute_graph, model_ref, tensor -- and
+// the *_process_input / *_predict graph pieces built on it; birefnet_* and migan_* (families not built).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <span>
+#include <string>
+#include <utility>
+
+#include "../visp_c_api.h"
+
+namespace visp {
+
+struct exception : std::exception { // reference src/util/... visp::exception: what() = the library's message
+    std::string message;
+    explicit exception(std::string m) : message(std::move(m)) {}
+    char const* what() const noexcept override { return message.c_str(); }
+};
+namespace detail {
+inline void check(int32_t ok) {
+    if (!ok) throw exception(visp_get_last_error());
+}
+} // namespace detail
+
+//
+// images (include/visp/image.h)
+
+struct i32x2 {
+    int32_t v[2] = {0, 0};
+    constexpr i32x2() = default;
+    constexpr i32x2(int32_t x, int32_t y) : v{x, y} {}
+    constexpr int32_t& operator[](int i) { return v[i]; }
+    constexpr int32_t operator[](int i) const { return v[i]; }
+    friend constexpr bool operator==(i32x2 a, i32x2 b) { return a.v[0] == b.v[0] && a.v[1] == b.v[1]; }
+    friend constexpr bool operator!=(i32x2 a, i32x2 b) { return !(a == b); }
+};
+struct box_2d { i32x2 top_left, bottom_right; }; // sam_compute box prompt (vision.h:139-160)
+
+enum class image_format : int32_t { rgba_u8, bgra_u8, argb_u8, rgb_u8, alpha_u8, rgba_f32, rgb_f32, alpha_f32 };
+constexpr int n_channels(image_format f) {
+    switch (f) {
+        case image_format::rgb_u8: case image_format::rgb_f32: return 3;
+        case image_format::alpha_u8: case image_format::alpha_f32: return 1;
+        default: return 4;
+    }
+}
+constexpr bool is_float(image_format f) { return int(f) >= int(image_format::rgba_f32); }
+constexpr int n_bytes(image_format f) { return n_channels(f) * (is_float(f) ? 4 : 1); }
+
+struct image_data;
+struct image_view { // include/visp/image.h:37-41: non-owning
+    i32x2 extent;
+    int32_t stride = 0;
+    image_format format = image_format::rgba_u8;
+    void const* data = nullptr;
+
+    image_view() = default;
+    image_view(i32x2 e, image_format f, void const* d) : extent(e), stride(e[0] * n_bytes(f)), format(f), data(d) {}
+    image_view(i32x2 e, int32_t s, image_format f, void const* d) : extent(e), stride(s), format(f), data(d) {}
+    image_view(image_data const& img);
+    std::span<uint8_t const> as_bytes() const { return {static_cast<uint8_t const*>(data), size_t(stride) * size_t(extent[1])}; }
+    std::span<float const> as_floats() const { return {static_cast<float const*>(data), size_t(extent[0]) * size_t(extent[1]) * size_t(n_channels(format))}; }
+};
+struct image_data { // owning; include/visp/image.h:60-64
+    i32x2 extent;
+    image_format format = image_format::rgba_u8;
+    std::unique_ptr<uint8_t[]> data;
+};
+inline image_view::image_view(image_data const& img) : image_view(img.extent, img.format, img.data.get()) {}
+
+inline image_data image_alloc(i32x2 extent, image_format format) {
+    size_t n = size_t(extent[0]) * size_t(extent[1]) * size_t(n_bytes(format));
+    return image_data{extent, format, std::unique_ptr<uint8_t[]>(new uint8_t[n ? n : 1])};
+}
+inline void image_clear(image_data& img) { std::memset(img.data.get(), 0, size_t(img.extent[0]) * size_t(img.extent[1]) * size_t(n_bytes(img.format))); }
+
+namespace detail {
+inline visp_image_view c_view(image_view const& v) { return {v.extent[0], v.extent[1], v.stride, int32_t(v.format), const_cast<void*>(v.data)}; }
+inline image_data take(visp_image_view const& v, visp_image_data* owner) { // copies the library-owned result into an image_data
+    image_data out = image_alloc({v.width, v.height}, image_format(v.format));
+    const size_t row = size_t(v.width) * size_t(n_bytes(out.format));
+    for (int y = 0; y < v.height; ++y) std::memcpy(out.data.get() + y * row, static_cast<uint8_t const*>(v.data) + size_t(y) * size_t(v.stride), row);
+    visp_image_destroy(owner);
+    return out;
+}
+} // namespace detail
+
+inline image_data image_scale(image_view const& img, i32x2 target) { // src/visp/image.cpp:352-356 (stb_image_resize semantics)
+    visp_image_view in = detail::c_view(img), out{};
+    visp_image_data* owner = nullptr;
+    detail::check(visp_image_scale(&in, target[0], target[1], &out, &owner));
+    return detail::take(out, owner);
+}
+
+//
+// backend (include/visp/ml.h:32-64)
+
+enum class backend_type : int32_t { cpu = 1, gpu = 2, vulkan = gpu | 1 << 8 };
+
+struct backend_device {
+    visp_device* handle = nullptr;
+    backend_device() = default;
+    explicit backend_device(visp_device* h) : handle(h) {}
+    backend_device(backend_device&& o) noexcept : handle(std::exchange(o.handle, nullptr)) {}
+    backend_device& operator=(backend_device&& o) noexcept { std::swap(handle, o.handle); return *this; }
+    ~backend_device() { if (handle) visp_device_destroy(handle); }
+    backend_type type() const { return backend_type(visp_device_type(handle)); }
+    char const* name() const { return visp_device_name(handle); }
+    char const* description() const { return visp_device_description(handle); }
+};
+inline backend_device backend_init() { // first available device (here: the first gfx950 GPU)
+    visp_device* d = nullptr;
+    detail::check(visp_device_init(VISP_BACKEND_AUTO, &d));
+    return backend_device(d);
+}
+inline backend_device backend_init(backend_type t) { // backend_type::cpu throws: this build has no CPU backend
+    visp_device* d = nullptr;
+    detail::check(visp_device_init(int32_t(t), &d));
+    return backend_device(d);
+}
+inline bool backend_is_available(backend_type t) { return t == backend_type::gpu; }
+
+//
+// models (include/visp/vision.h)
+
+namespace detail {
+template <int Family>
+struct model_handle {
+    visp_model* handle = nullptr;
+    model_handle() = default;
+    explicit model_handle(visp_model* h) : handle(h) {}
+    model_handle(model_handle&& o) noexcept : handle(std::exchange(o.handle, nullptr)) {}
+    model_handle& operator=(model_handle&& o) noexcept { std::swap(handle, o.handle); return *this; }
+    ~model_handle() { if (handle) visp_model_destroy(handle, Family); }
+};
+template <int Family>
+inline visp_model* load(char const* filepath, backend_device const& dev) {
+    visp_model* m = nullptr;
+    check(visp_model_load(filepath, dev.handle, Family, &m));
+    return m;
+}
+template <int Family>
+inline image_data compute(visp_model* m, image_view const& image, int32_t* args = nullptr, int32_t n_args = 0) {
+    visp_image_view in = c_view(image), out{};
+    visp_image_data* owner = nullptr;
+    check(visp_model_compute(m, Family, &in, 1, args, n_args, &out, &owner));
+    return take(out, owner);
+}
+} // namespace detail
+
+// Depth-Anything (vision.h:224-252, 339-347). The device must outlive the model.
+using depthany_model = detail::model_handle<VISP_DEPTH_ANYTHING>;
+inline depthany_model depthany_load_model(char const* filepath, backend_device const& dev) { return depthany_model(detail::load<VISP_DEPTH_ANYTHING>(filepath, dev)); }
+inline image_data depthany_compute(depthany_model& model, image_view image) { // -> alpha_f32 in [0, 1] at the input extent (vision.cpp:147-167)
+    visp_image_view in = detail::c_view(image), out{};
+    visp_image_data* owner = nullptr;
+    detail::check(visp_depthany_compute_f32(model.handle, &in, &out, &owner));
+    return detail::take(out, owner);
+}
+
+// ESRGAN (vision.h:284-304): any size, tiled, -> rgba_u8 at scale x the input extent (vision.cpp:220-253)
+using esrgan_model = detail::model_handle<VISP_ESRGAN>;
+inline esrgan_model esrgan_load_model(char const* filepath, backend_device const& dev) { return esrgan_model(detail::load<VISP_ESRGAN>(filepath, dev)); }
+inline image_data esrgan_compute(esrgan_model& model, image_view image) { return detail::compute<VISP_ESRGAN>(model.handle, image); }
+
+// MobileSAM (vision.h:139-160): sam_encode once per image, then any number of prompts (vision.cpp:26-92) -> alpha_u8 mask
+using sam_model = detail::model_handle<VISP_SAM>;
+inline sam_model sam_load_model(char const* filepath, backend_device const& dev) { return sam_model(detail::load<VISP_SAM>(filepath, dev)); }
+inline void sam_encode(sam_model& model, image_view image) {
+    visp_image_view in = detail::c_view(image);
+    detail::check(visp_sam_encode(model.handle, &in));
+}
+namespace detail {
+inline image_data sam_prompt(sam_model& model, int32_t const* prompt, int32_t n) {
+    visp_image_view out{};
+    visp_image_data* owner = nullptr;
+    check(visp_sam_compute(model.handle, prompt, n, &out, &owner));
+    return take(out, owner);
+}
+} // namespace detail
+inline image_data sam_compute(sam_model& model, i32x2 point) {
+    int32_t p[2] = {point[0], point[1]};
+    return detail::sam_prompt(model, p, 2);
+}
+inline image_data sam_compute(sam_model& model, box_2d box) {
+    int32_t p[4] = {box.top_left[0], box.top_left[1], box.bottom_right[0], box.bottom_right[1]};
+    return detail::sam_prompt(model, p, 4);
+}
+
+} // namespace visp

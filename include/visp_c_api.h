@@ -5,8 +5,8 @@
  * reference's C API (reference src/visp/c-api.cpp:145-253), i.e. exactly what the reference's
  * ctypes binding (bindings/python/visioncpp/_lib.py:118-171) binds. Return value 1 = ok,
  * 0 = error with the message available from visp_get_last_error() (thread-local,
- * c-api.cpp:6-21). Only the Depth-Anything family is implemented behind it; the other
- * families return an error ("not built in this backend").
+ * c-api.cpp:6-21). Built behind it: depth_anything, esrgan and sam (MobileSAM: image encoder + prompt encoder / mask decoder);
+ * birefnet and migan return an error ("not built in this backend").
  *
  * Part 2 is the batched, device-resident extension the reference does not have (its
  * depthany_compute is batch 1, src/visp/vision.cpp:155): it is what bench.py and a
@@ -97,6 +97,9 @@ VISP_API int32_t visp_depthany_reserve(visp_model* m, int32_t batch, int32_t w, 
  * NULL = the model's own stream, in which case the call returns after synchronising). */
 VISP_API int32_t visp_depthany_compute_batch_device(visp_model* m, void const* rgb_u8_dev, int32_t batch, int32_t w,
                                                     int32_t h, void* out_dev, void* raw_out_dev, void* stream);
+/* the reference's C++ depthany_compute (vision.cpp:147-167): one image of any extent / u8 colour format -> alpha_f32 in [0, 1] at
+ * the caller's extent (visp_model_compute returns the same map as alpha_u8, c-api.cpp:72-77); result owned by *out_data */
+VISP_API int32_t visp_depthany_compute_f32(visp_model* m, visp_image_view const* image, visp_image_view* out_image, visp_image_data** out_data);
 /* same with host buffers (H2D + compute + D2H on the model's stream, blocking) */
 VISP_API int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w,
                                                   int32_t h, float* out, float* raw_out);

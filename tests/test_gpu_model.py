@@ -235,6 +235,21 @@ def test_pkg_check_smoke(small):
     assert res.shape == (64, 64) and np.isfinite(res.astype(np.float32).mean())
 
 
+def test_public_cpp_header_pkg_check(tmp_path):
+    """include/visp/vision.h (the reference-shaped C++ API over the C ABI) in a caller that mirrors the reference's
+    scripts/pkg-check/main.cpp:22-44; built by __graft_entry__.build(), exit code 0 = extent and finite-mean checks passed."""
+    import subprocess
+    from pathlib import Path
+
+    exe = Path(__file__).resolve().parents[1] / "vision.cpp_amd" / "lib" / "pkg_check"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    path = synth.write_gguf(tmp_path / "mini.gguf", synth.MINI, seed=4)
+    r = subprocess.run([str(exe), str(path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "pkg-check ok" in r.stdout, (r.stdout, r.stderr)
+    r = subprocess.run([str(exe), str(tmp_path / "missing.gguf")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "Failed to load GGUF model" in r.stderr
+
+
 def test_errors(small, device, tmp_path):
     api = L.get_lib()
     with pytest.raises(L.Error, match="multiple of the patch size"):

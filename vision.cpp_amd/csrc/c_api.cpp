@@ -272,6 +272,14 @@ int32_t visp_depthany_compute_batch_device(visp_model* m, void const* rgb, int32
     });
 }
 
+int32_t visp_depthany_compute_f32(visp_model* m, visp_image_view const* image, visp_image_view* out_image, visp_image_data** out_data) {
+    return handle_errors([&]() {
+        if (!image || !image->data || !out_image || !out_data) throw except("depthany: null argument");
+        image_view in{i32x2{{image->width, image->height}}, image->stride, image_format(image->format), image->data};
+        return_image(depthany_compute(as_depthany(m), in), out_image, out_data);
+    });
+}
+
 int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb, int32_t batch, int32_t w, int32_t h, float* out,
                                          float* raw_out) {
     return handle_errors([&]() {

@@ -1,7 +1,7 @@
 // TinyViT image encoder of MobileSAM on the MI355X backend (BASELINE.json configs[4]): model
 // load (mobile-sam GGUF -> packed f16 weights), static schedule, batched executor. Mirrors sam_load_model / sam_encode
-// (reference src/visp/vision.cpp:26-52; graph src/visp/arch/mobile-sam.cpp:20-215, sam_process_input :533-547). The prompt
-// encoder / mask decoder (sam_compute) are not built yet: this row ends at the image embedding [256, 64, 64].
+// (reference src/visp/vision.cpp:26-52; graph src/visp/arch/mobile-sam.cpp:20-215, sam_process_input :533-547), and the
+// prompt encoder + mask decoder + mask post-processing behind sam_compute (vision.cpp:54-92, mobile-sam.cpp:207-583).
 #pragma once
 #include <vector>
 
