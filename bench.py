@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--min-seconds", type=float, default=10.0, help="soak: after the K timed steps keep stepping for this long and report that rate too (0 = skip)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the upload + compute + download (host pipeline) figure")
-    ap.add_argument("--schedule", type=int, default=0, help="depthany encoder schedule: 0 = GEMM launches, 1 = token-stationary block kernel")
+    ap.add_argument("--schedule", type=int, default=-1, help="depthany encoder schedule: -1 = the library's default (block kernel), 0 = GEMM launches, 1 = token-stationary block kernel")
     ap.add_argument("--cpu-images", type=int, default=32, help="bounded CPU-baseline sample (about 10 s at 16 threads)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (one GPU's share of the host)")
     ap.add_argument("--profile-groups", action="store_true", help="print the per-kernel-group table to stderr")
@@ -115,7 +115,7 @@ def main():
     compute_stream = torch.cuda.Stream()  # a real (non-null) stream: required for hipGraph capture
     stream = compute_stream.cuda_stream
     model.reserve(B, W, H)
-    if args.schedule:
+    if args.schedule >= 0:
         model.set_schedule(args.schedule)
 
     def step():
@@ -241,7 +241,7 @@ def main():
             "config": {"workload": "Depth-Anything-V2-Small f16 (DINOv2-S ViT) 518x518 batch=32 per MI355X (BASELINE.json configs[1])",
                        "images_per_gpu_per_step": B, "global_batch": world * B, "weights": "random-init synthetic GGUF (seed 0)",
                        "parallelism": f"dp{world} (image shards, no data-path collective)", "hip_graph": not args.no_graph,
-                       "encoder_schedule": "block kernel" if args.schedule else "gemm launches"},
+                       "encoder_schedule": "gemm launches" if args.schedule == 0 else "attention + token-stationary block kernel per layer, 3 sub-batches on parallel streams"},
             "value_soak": soak,
             "value_incl_h2d_d2h": incl,
             "model_tflops": round(value * GFLOP_PER_IMAGE / 1e3, 2),

@@ -103,6 +103,12 @@ VISP_API int32_t visp_depthany_compute_f32(visp_model* m, visp_image_view const*
 /* same with host buffers (H2D + compute + D2H on the model's stream, blocking) */
 VISP_API int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w,
                                                   int32_t h, float* out, float* raw_out);
+/* Multi-GPU from C: models[i] is a depth_anything model loaded on its own device (visp_hip_device_init(i) + visp_model_load);
+ * the batch is cut into n_models contiguous shards (sizes differ by at most one), each shard runs on its model's device from
+ * its own host thread, outputs land at the matching offsets of `out` [batch, h, w] f32. No collective is involved: images are
+ * independent. (Per-device kernel attributes are set per (kernel, device), so several devices in one process are fine.) */
+VISP_API int32_t visp_depthany_compute_sharded(visp_model* const* models, int32_t n_models, uint8_t const* rgb_u8, int32_t batch,
+                                               int32_t w, int32_t h, float* out);
 /* Overlapped host pipeline (the reference's benchmark loop -- upload, compute, download per call, tests/benchmark.cpp:55-91 --
  * with the transfers hidden): n_slots (2..8) slots of pinned staging + device buffers; submit() chains H2D (copy stream) ->
  * forward (the model's stream) -> D2H (second copy stream) by events and returns at once with a ticket; wait() blocks until
@@ -118,8 +124,9 @@ VISP_API int32_t visp_depthany_pipeline_wait(visp_depthany_pipeline* p, int32_t 
 /* capture the launch sequence of the current reserved shape into a hipGraph and replay it on
  * every later compute of that shape (enable = 0 turns it off) */
 VISP_API int32_t visp_depthany_use_graph(visp_model* m, int32_t enable);
-/* encoder schedule: 0 = one launch per op group (default), 1 = one attention + one token-stationary block launch per layer
- * (csrc/kernels_block.hip; models with embed dim 384 / mlp 1536 / head dim 64 only). Results agree to f16 rounding. */
+/* encoder schedule: -1 = auto (default: 1 where the model has the kernel's shape), 0 = one launch per op group, 1 = one attention
+ * + one token-stationary block launch per layer (csrc/kernels_block.hip; embed dim 384 / mlp 1536 / head dim 64 only).
+ * Results agree to f16 rounding. */
 VISP_API int32_t visp_depthany_set_schedule(visp_model* m, int32_t schedule);
 
 /* Named intermediate tensors of the last compute, converted to f32 on the host (parity tests;

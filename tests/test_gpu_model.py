@@ -93,7 +93,8 @@ def test_short_every_module_boundary(device, tmp_path):
     model = vision.Model.load(synth.write_gguf(tmp_path / "short.gguf", cfg, seed=8), device)
     om, params = _oracle(cfg, 8)
     imgs = synth.images(3, 112, 112, seed=21)
-    plain = model.compute_batch(imgs)  # default schedule (GEMM launches)
+    model.set_schedule(0)
+    plain = model.compute_batch(imgs)  # GEMM launches
     model.set_schedule(1)
     model.enable_captures(True)
     out, raw = model.compute_batch(imgs, return_raw=True)
@@ -110,6 +111,8 @@ def test_short_every_module_boundary(device, tmp_path):
     assert np.abs(plain - out).mean() < 5e-4
     model.set_schedule(0)
     np.testing.assert_array_equal(model.compute_batch(imgs), plain)
+    model.set_schedule(-1)  # auto = the block kernel for this shape
+    np.testing.assert_array_equal(model.compute_batch(imgs), out)
 
 
 def test_mini_matches_huggingface_fixture(mini, golden_dir):
@@ -233,6 +236,23 @@ def test_pkg_check_smoke(small):
     output extent equals input extent and the mean is finite."""
     res = small.compute(np.zeros((64, 64, 3), np.uint8))
     assert res.shape == (64, 64) and np.isfinite(res.astype(np.float32).mean())
+
+
+def test_sharded_entry_two_models_two_threads(small, device, tmp_path):
+    """visp_depthany_compute_sharded: the C-level multi-GPU entry (one model per device, one host thread each, contiguous
+    shards). The box has one GPU, so both models sit on device 0 -- the sharding, the threading and the per-(kernel, device)
+    attribute bookkeeping are what is exercised; results equal the single-model batch bit for bit, for uneven shards too."""
+    path = synth.write_gguf(tmp_path / "small2.gguf", synth.SMALL, seed=0)
+    second = vision.Model.load(path, device)
+    imgs = synth.images(5, 518, 518, seed=33)
+    want = small.compute_batch(imgs)
+    out = np.empty((5, 518, 518), np.float32)
+    handles = (C.c_void_p * 2)(small._handle, second._handle)
+    L.check(L.get_lib().visp_depthany_compute_sharded(handles, 2, imgs.ctypes.data, 5, 518, 518, out.ctypes.data))  # shards 3 + 2
+    np.testing.assert_array_equal(out, want)
+    same = (C.c_void_p * 2)(small._handle, small._handle)
+    with pytest.raises(L.Error, match="passed twice"):
+        L.check(L.get_lib().visp_depthany_compute_sharded(same, 2, imgs.ctypes.data, 5, 518, 518, out.ctypes.data))
 
 
 def test_public_cpp_header_pkg_check(tmp_path):

@@ -91,7 +91,7 @@ C_API_SYMBOLS = [
     "visp_model_destroy", "visp_model_compute",
     "visp_hip_device_init", "visp_model_load_ex", "visp_depthany_weights_arena", "visp_depthany_weights_ready",
     "visp_depthany_get_info", "visp_depthany_image_extent", "visp_depthany_reserve",
-    "visp_depthany_compute_batch_device", "visp_depthany_compute_batch_host", "visp_depthany_compute_f32", "visp_depthany_use_graph", "visp_depthany_set_schedule",
+    "visp_depthany_compute_batch_device", "visp_depthany_compute_batch_host", "visp_depthany_compute_f32", "visp_depthany_compute_sharded", "visp_depthany_use_graph", "visp_depthany_set_schedule",
     "visp_depthany_pipeline_create", "visp_depthany_pipeline_destroy", "visp_depthany_pipeline_input", "visp_depthany_pipeline_submit", "visp_depthany_pipeline_wait",
     "visp_depthany_enable_captures", "visp_depthany_read_capture", "visp_depthany_enable_timing",
     "visp_depthany_read_timing",
@@ -161,6 +161,7 @@ def init() -> ctypes.CDLL:
     lib.visp_depthany_compute_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.visp_depthany_compute_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.visp_depthany_compute_f32.argtypes = [c_void_p, POINTER(ImageView), POINTER(ImageView), POINTER(c_void_p)]
+    lib.visp_depthany_compute_sharded.argtypes = [POINTER(c_void_p), c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]
     lib.visp_depthany_use_graph.argtypes = [c_void_p, c_int32]
     lib.visp_depthany_set_schedule.argtypes = [c_void_p, c_int32]
     lib.visp_depthany_pipeline_create.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]

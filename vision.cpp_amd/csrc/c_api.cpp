@@ -8,6 +8,9 @@
 #include <exception>
 #include <map>
 #include <memory>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/visp_hip_kernels.h"
 #include "depthany.h"
@@ -288,6 +291,42 @@ int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb, int3
     });
 }
 
+// Multi-GPU without Python: one model per device (each loaded on its own visp_hip_device_init(i) device), one host thread per
+// model, contiguous image shards whose sizes differ by at most one (the partitioning of vision.cpp_amd/dist.py::shard_range),
+// no data-path collective -- images are independent units (image_normalize is per image, reference image.cpp:537-576).
+int32_t visp_depthany_compute_sharded(visp_model* const* models, int32_t n_models, uint8_t const* rgb, int32_t batch, int32_t w, int32_t h,
+                                      float* out) {
+    return handle_errors([&]() {
+        if (!models || n_models <= 0 || !rgb || !out) throw except("depthany sharded: null / empty argument");
+        if (batch <= 0 || w <= 0 || h <= 0) throw except("depthany sharded: invalid batch/extent %d x %dx%d", batch, w, h);
+        std::vector<depthany_model*> ms;
+        for (int i = 0; i < n_models; ++i) {
+            ms.push_back(&as_depthany(models[i]));
+            for (int j = 0; j < i; ++j)
+                if (ms[(size_t)j] == ms[(size_t)i]) throw except("depthany sharded: model %d is passed twice (one model = one thread at a time)", i);
+        }
+        std::vector<std::string> errors((size_t)n_models);
+        std::vector<std::thread> threads;
+        const int base = batch / n_models, rem = batch % n_models;
+        for (int i = 0; i < n_models; ++i) {
+            const int begin = i * base + std::min(i, rem), count = base + (i < rem ? 1 : 0);
+            if (count == 0) continue;
+            threads.emplace_back([&, i, begin, count]() {
+                try {
+                    depthany_compute_batch_host(*ms[(size_t)i], rgb + (size_t)begin * h * w * 3, count, w, h, out + (size_t)begin * h * w, nullptr);
+                } catch (std::exception const& e) {
+                    errors[(size_t)i] = e.what();
+                } catch (...) {
+                    errors[(size_t)i] = "unknown error";
+                }
+            });
+        }
+        for (auto& t : threads) t.join();
+        for (int i = 0; i < n_models; ++i)
+            if (!errors[(size_t)i].empty()) throw except("depthany sharded: shard %d failed: %s", i, errors[(size_t)i].c_str());
+    });
+}
+
 int32_t visp_depthany_pipeline_create(visp_model* m, int32_t batch, int32_t w, int32_t h, int32_t n_slots, visp_depthany_pipeline** out) {
     return handle_errors([&]() { *out = reinterpret_cast<visp_depthany_pipeline*>(depthany_pipeline_create(as_depthany(m), batch, w, h, n_slots)); });
 }
@@ -325,9 +364,9 @@ int32_t visp_depthany_use_graph(visp_model* m, int32_t enable) {
 int32_t visp_depthany_set_schedule(visp_model* m, int32_t schedule) {
     return handle_errors([&]() {
         depthany_model& dm = as_depthany(m);
-        if (schedule != 0 && schedule != 1) throw except("visp_depthany_set_schedule: unknown schedule %d (0 = GEMM launches, 1 = token-stationary block kernel)", schedule);
+        if (schedule < -1 || schedule > 1) throw except("visp_depthany_set_schedule: unknown schedule %d (-1 = auto, 0 = GEMM launches, 1 = token-stationary block kernel)", schedule);
         if (schedule == 1 && !dm.weights.use_block) throw except("visp_depthany_set_schedule: the block kernel is built for embed dim 384 / mlp 1536 / head dim 64 only");
-        dm.force_block = schedule == 1;
+        dm.schedule = schedule;
         if (dm.ws.graph_exec) { // the captured launch sequence belongs to the other schedule
             vx_graph_destroy(dm.ws.graph_exec);
             dm.ws.graph_exec = nullptr;

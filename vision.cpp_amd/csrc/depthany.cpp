@@ -703,7 +703,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     exec_ctx c{m, stream, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
 
     float* x = static_cast<float*>(c.buf("x"));
-    void* ln = c.buf("ln");
+    (void)0;
     const float* pos = static_cast<const float*>(c.buf("pos"));
 
     // ---- depthany_process_input (depth-anything.cpp:130-140) fused with the patch im2col
@@ -735,8 +735,25 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     // epilogue) but the LayerNorms 0.42 ms slower (they now also write x); total traffic is the same 236 MB per
     // residual, so the read-modify-write epilogue stays the default.
     const float q_scale = 1.0f / std::sqrt((float)D / (float)NH);
+    // The encoder of images [b0, b0 + nb) on stream `strm`. Every activation buffer is image-major, so a sub-batch is a row
+    // offset into the same workspace; VISP_SPLIT=n runs n sub-batches on parallel streams (captured as parallel branches of
+    // the hipGraph) so that kernels with different bottlenecks -- HBM-bound LayerNorms, VALU-bound attention, MFMA/LDS-bound
+    // GEMMs -- of different sub-batches overlap.
+    auto run_encoder = [&](int b0, int nb, void* strm) {
+    const int B = nb;
+    const long M = (long)nb * T;
+    void* const stream = strm;
+    c.stream = strm;
+    float* const x = static_cast<float*>(c.buf("x")) + (size_t)b0 * T * D;
+    auto sub = [&](const char* name, size_t row_bytes) -> void* { return static_cast<uint8_t*>(c.buf(name)) + (size_t)b0 * T * row_bytes; };
+    void* const ln = sub("ln", (size_t)D * 2);
+    void* const qb = sub("q", (size_t)D * 2);
+    void* const kb = sub("k", (size_t)D * 2);
+    void* const vb = sub("vt", (size_t)D * 2);
+    void* const attb = sub("att", (size_t)D * 2);
+    void* const hidb = sub("hidden", (size_t)Wt.layers[0].fc1.N * 2);
     const bool defer = !m.captures && vx_layernorm_resid_supported(D) && getenv("VISP_DEFER_RESID") != nullptr;
-    void* ybuf = c.buf("y");
+    void* ybuf = sub("y", (size_t)D * 2);
     const float* pending = nullptr; // LayerScale vector of the residual still sitting in ybuf
     auto layernorm = [&](const float* w, const float* b, void* out) { // norm(x), applying a pending residual first
         c.mark("layernorm", 1, 0, (double)M * D * (pending ? 12 : 6));
@@ -764,19 +781,21 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     auto run_tap = [&]() {
         for (; tap_due_n > 0 && tap < 4; --tap_due_n, ++tap) {
             std::string fb = "feat" + std::to_string(tap);
-            layernorm(c.fptr(Wt.final_ln_w), c.fptr(Wt.final_ln_b), c.buf(fb.c_str()));
-            if (m.captures) { std::string nm = "dino_layer_" + std::to_string(tap_due); c.capture(nm.c_str(), c.buf(fb.c_str()), {B, T, D, 1}, true); }
+            layernorm(c.fptr(Wt.final_ln_w), c.fptr(Wt.final_ln_b), sub(fb.c_str(), (size_t)D * 2));
+            if (m.captures) { std::string nm = "dino_layer_" + std::to_string(tap_due); c.capture(nm.c_str(), sub(fb.c_str(), (size_t)D * 2), {B, T, D, 1}, true); }
         }
         tap_due = -1;
         tap_due_n = 0;
     };
     // Token-stationary schedule (kernels_block.hip): per layer one attention launch and ONE block launch that does the
     // output projection, both residual updates, LN2 + MLP, the tap's final LayerNorm and the next layer's LN1 + QKV for
-    // 128 token rows per workgroup with everything but the weights in registers. Parity-green but, measured on MI355X, not yet
-    // faster than the GEMM schedule (381 vs 363 us per layer at batch 32, profiles/r02_block_kernel_anatomy.txt): opt-in with
-    // VISP_BLOCK=1 or visp_depthany_set_schedule(model, 1).
-    static const bool block_on = getenv("VISP_BLOCK") != nullptr;
-    const bool use_block = Wt.use_block && (block_on || m.force_block);
+    // 128 token rows per workgroup with everything but the weights in registers. Alone it is no faster than the launches it
+    // replaces (381 vs 363 us per layer at batch 32, profiles/r02_block_kernel_anatomy.txt), but it has none of their HBM
+    // round trips and, with the sub-batches below on parallel streams, its idle second round and memory phases are filled by
+    // the other sub-batches' attention: 6.85 vs 7.21 ms per step (profiles/r02_split_streams.txt). Default where the model has
+    // the kernel's shape; visp_depthany_set_schedule(model, 0) or VISP_NO_BLOCK=1 selects the GEMM schedule.
+    static const bool block_off = getenv("VISP_NO_BLOCK") != nullptr;
+    const bool use_block = Wt.use_block && m.schedule != 0 && !(block_off && m.schedule < 0);
     if (use_block) {
         const int hid = Wt.layers[0].fc1.n_real;
         auto block = [&](int li_mlp, int li_qkv, void* feat, const char* group) {
@@ -785,7 +804,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
             a.x = x; a.M = (int)M; a.T = T; a.H = NH; a.q_scale = q_scale; a.eps = 1e-6f;
             double flops = 0, bytes = 0;
             if (li_mlp >= 0) {
-                a.att = c.buf("att");
+                a.att = attb;
                 a.w_mlp = c.wptr(Wt.layers[li_mlp].blk_mlp);
                 a.vec_mlp = reinterpret_cast<const float*>(c.wptr(Wt.layers[li_mlp].vec_mlp));
                 flops += 2.0 * M * D * (D + 2.0 * hid);
@@ -794,7 +813,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
                 bytes += (double)M * D * 4;
             }
             if (li_qkv >= 0) {
-                a.q = c.buf("q"); a.k = c.buf("k"); a.v = c.buf("vt");
+                a.q = qb; a.k = kb; a.v = vb;
                 a.w_qkv = c.wptr(Wt.layers[li_qkv].blk_qkv);
                 a.vec_qkv = reinterpret_cast<const float*>(c.wptr(Wt.layers[li_qkv].vec_qkv));
                 flops += 2.0 * M * D * 3.0 * D;
@@ -812,26 +831,26 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         int tap = 0;
         for (int i = 0; i < P.dino.n_layers; ++i) {
             c.mark("attention", 1, 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
-            VX(vx_attention_f16(c.buf("q"), c.buf("k"), c.buf("vt"), c.buf("att"), B, NH, T, stream));
+            VX(vx_attention_f16(qb, kb, vb, attb, B, NH, T, stream));
             // get_intermediate_layers (dino.cpp:100-107): every tap that names this layer (the first one is written by the kernel)
             void* first = nullptr;
             int tap0 = tap;
             for (int f = 0; f < 4; ++f)
                 if (P.feature_layers[f] == i && tap < 4) {
                     std::string fb = "feat" + std::to_string(tap++);
-                    if (!first) first = c.buf(fb.c_str());
+                    if (!first) first = sub(fb.c_str(), (size_t)D * 2);
                 }
             block(i, i + 1 < P.dino.n_layers ? i + 1 : -1, first, "block");
             for (int t2 = tap0 + 1; t2 < tap; ++t2) {
                 std::string fb = "feat" + std::to_string(t2);
-                VX(vx_memcpy_d2d(c.buf(fb.c_str()), first, (size_t)M * D * 2, stream));
+                VX(vx_memcpy_d2d(sub(fb.c_str(), (size_t)D * 2), first, (size_t)M * D * 2, stream));
             }
             if (m.captures) {
                 std::string nm = "layer_" + std::to_string(i);
                 c.capture(nm.c_str(), x, {B, T, D, 1}, false);
                 for (int t2 = tap0; t2 < tap; ++t2) {
                     std::string fb = "feat" + std::to_string(t2), dn = "dino_layer_" + std::to_string(i);
-                    c.capture(dn.c_str(), c.buf(fb.c_str()), {B, T, D, 1}, true);
+                    c.capture(dn.c_str(), sub(fb.c_str(), (size_t)D * 2), {B, T, D, 1}, true);
                 }
             }
         }
@@ -845,25 +864,25 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
             vx_gemm_args a = c.base(L.qkv, M);
             a.A = ln; a.lda = D;
             a.epi = VX_EPI_QKV;
-            a.q = c.buf("q"); a.k = c.buf("k"); a.vt = c.buf("vt");
+            a.q = qb; a.k = kb; a.vt = vb;
             a.qkv_T = T; a.qkv_Tp = 0; a.qkv_H = NH;
             a.q_scale = q_scale;
             c.mark("gemm_qkv", 1, 2.0 * M * 3 * D * D, (double)M * D * 2 * 4 + 3.0 * D * D * 2);
             c.gemm(a);
         }
         c.mark("attention", 1, 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
-        VX(vx_attention_f16(c.buf("q"), c.buf("k"), c.buf("vt"), c.buf("att"), B, NH, T, stream));
-        residual_gemm(L.out, c.buf("att"), D, L.lambda1, "gemm_out", 2.0 * M * D * D, (double)M * D * (2 + (defer ? 2 : 8)) + (double)D * D * 2);
+        VX(vx_attention_f16(qb, kb, vb, attb, B, NH, T, stream));
+        residual_gemm(L.out, attb, D, L.lambda1, "gemm_out", 2.0 * M * D * D, (double)M * D * (2 + (defer ? 2 : 8)) + (double)D * D * 2);
         layernorm(c.fptr(L.ln2_w), c.fptr(L.ln2_b), ln);
         {
             vx_gemm_args a = c.base(L.fc1, M);
             a.A = ln; a.lda = D;
             a.epi = VX_EPI_F16_GELU;
-            a.out = c.buf("hidden"); a.ldo = L.fc1.N;
+            a.out = hidb; a.ldo = L.fc1.N;
             c.mark("gemm_fc1", 1, 2.0 * M * L.fc1.n_real * D, (double)M * (D + L.fc1.N) * 2 + (double)L.fc1.N * D * 2);
             c.gemm(a);
         }
-        residual_gemm(L.fc2, c.buf("hidden"), L.fc1.N, L.lambda2, "gemm_fc2", 2.0 * M * D * L.fc2.k_real,
+        residual_gemm(L.fc2, hidb, L.fc1.N, L.lambda2, "gemm_fc2", 2.0 * M * D * L.fc2.k_real,
                       (double)M * (L.fc1.N * 2 + D * (defer ? 2 : 8)) + (double)L.fc2.K * D * 2);
         if (m.captures) { std::string nm = "layer_" + std::to_string(i); c.capture(nm.c_str(), x, {B, T, D, 1}, false); }
         // get_intermediate_layers (dino.cpp:100-107): shared final layernorm on the tapped layers. With a residual still
@@ -876,6 +895,29 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         }
     }
     if (!use_block && tap != 4) throw except("depthany: expected 4 feature layers, found %d", tap);
+    }; // run_encoder
+    {
+        // measured at batch 32 (profiles/r02_split_streams.txt): 7.70 / 7.24 / 7.21 / 7.33 ms per step for 1 / 2 / 3 / 4 sub-batches
+        static const int split_env = getenv("VISP_SPLIT") ? atoi(getenv("VISP_SPLIT")) : 0;
+        const int want = split_env > 0 ? split_env : (B >= 24 ? 3 : (B >= 8 ? 2 : 1));
+        const int n_split = (!m.timing && !m.captures && want > 1 && want <= 4 && B >= 2 * want) ? want : 1;
+        if (n_split == 1) {
+            run_encoder(0, B, stream);
+        } else {
+            VX(vx_event_record(m.fork_event, stream));
+            for (int j = 0; j < n_split; ++j) {
+                const int b0 = (int)((long)B * j / n_split), b1 = (int)((long)B * (j + 1) / n_split);
+                void* strm = j == 0 ? stream : m.aux_stream[j - 1];
+                if (j > 0) VX(vx_stream_wait_event(strm, m.fork_event));
+                run_encoder(b0, b1 - b0, strm);
+                if (j > 0) {
+                    VX(vx_event_record(m.join_event[j - 1], strm));
+                    VX(vx_stream_wait_event(stream, m.join_event[j - 1]));
+                }
+            }
+        }
+        c.stream = stream;
+    }
 
     // ---- dpt::neck reassemble (depth-anything.cpp:44-64)
     const int lh[4] = {4 * ph, 2 * ph, ph, (ph + 2 - 3) / 2 + 1};

@@ -115,7 +115,7 @@ struct depthany_model : model_base { // vision.h:339-347 counterpart
     bool weights_uploaded = false;
     depthany_workspace ws;
     bool use_graph = false, captures = false, timing = false;
-    bool force_block = false; // run the encoder through the token-stationary block kernel (experimental schedule)
+    int schedule = -1; // encoder schedule: -1 auto (block kernel where the model has its shape), 0 GEMM launches, 1 block kernel
     std::map<std::string, capture_entry> capture_bufs;
     std::vector<timing_entry> last_timing;
     // the four reassemble/neck-conv branches are independent until the fusion stage: they run on side
