@@ -87,6 +87,12 @@ def reference(w, x, att, eps, mlp, tap, qkv, T, q_scale):
     return out
 
 
+@pytest.fixture(params=["vx_dino_block_f16", "vx_dino_block2_f16"], ids=["one-wave", "wave-pair"])
+def block_fn(request):
+    """Both forms of the kernel: one wave per SIMD (kernels_block.hip) and the producer / consumer wave pair (kernels_block2.hip)."""
+    return getattr(api(), request.param)
+
+
 @pytest.mark.parametrize("M,T,mlp,tap,qkv", [
     (128, 64, True, True, True),       # one full workgroup
     (300, 75, True, False, True),      # tail workgroup: 44 valid rows, two waves with none; images straddle workgroups
@@ -94,7 +100,7 @@ def reference(w, x, att, eps, mlp, tap, qkv, T, q_scale):
     (257, 257, False, False, True),    # first layer: LN1 + QKV only
     (1370 * 2, 1370, True, True, True),  # two images of the north-star grid
 ])
-def test_block_vs_oracle(M, T, mlp, tap, qkv):
+def test_block_vs_oracle(block_fn, M, T, mlp, tap, qkv):
     rng = np.random.default_rng(M * 7 + T)
     w = make_weights(M + 1)
     x0 = (rng.standard_normal((M, D)) * 1.5 + rng.standard_normal((1, D)) * 0.5).astype(np.float32)
@@ -116,7 +122,7 @@ def test_block_vs_oracle(M, T, mlp, tap, qkv):
         a.feat, a.vec_tap = feat.ptr, v_tap.ptr
     if qkv:
         a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, d_qkv.ptr, v_qkv.ptr
-    L.vx_check(api().vx_dino_block_f16(C.byref(a), None))
+    L.vx_check(block_fn(C.byref(a), None))
     sync()
 
     got_x = xd.to_numpy(np.float32, (M, D))
@@ -135,7 +141,7 @@ def test_block_vs_oracle(M, T, mlp, tap, qkv):
             assert rel_err(got, want[name]) < 4e-3, name
 
 
-def test_block_rows_are_independent():
+def test_block_rows_are_independent(block_fn):
     """A row's results do not depend on which workgroup / wave / lane processes it: the same rows placed at another
     offset of a larger problem give bit-identical outputs (the property the batch sharding relies on)."""
     M1, M2, T = 192, 448, 64
@@ -154,7 +160,7 @@ def test_block_rows_are_independent():
         a.att, a.w_mlp, a.vec_mlp = ad.ptr, d_mlp.ptr, v_mlp.ptr
         a.feat, a.vec_tap = feat.ptr, v_tap.ptr
         a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, d_qkv.ptr, v_qkv.ptr
-        L.vx_check(api().vx_dino_block_f16(C.byref(a), None))
+        L.vx_check(block_fn(C.byref(a), None))
         sync()
         return xd.to_numpy(np.float32, (M, D)), feat.to_numpy(np.uint16, (M, D)), q.to_numpy(np.uint16, (M // T, H, T, 64))
 

@@ -112,7 +112,7 @@ KERNEL_SYMBOLS = [
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
     "vx_dconv3x3_f16", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
     "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_mbconv_dw_pw_supported", "vx_mbconv_pack_w3", "vx_mbconv_dw_pw_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
-    "vx_dino_block_supported", "vx_dino_block_mlp_bytes", "vx_dino_block_qkv_bytes", "vx_dino_block_pack_mlp", "vx_dino_block_pack_qkv", "vx_dino_block_f16",
+    "vx_dino_block_supported", "vx_dino_block_mlp_bytes", "vx_dino_block_qkv_bytes", "vx_dino_block_pack_mlp", "vx_dino_block_pack_qkv", "vx_dino_block_f16", "vx_dino_block2_f16",
 ]
 
 
@@ -264,6 +264,7 @@ def init() -> ctypes.CDLL:
     lib.vx_dino_block_pack_mlp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
     lib.vx_dino_block_pack_qkv.argtypes = [c_void_p, c_void_p]
     lib.vx_dino_block_f16.argtypes = [POINTER(DinoBlockArgs), c_void_p]
+    lib.vx_dino_block2_f16.argtypes = [POINTER(DinoBlockArgs), c_void_p]
     return lib
 
 

@@ -543,7 +543,11 @@ void depthany_reserve(depthany_model& m, int B, int W, int H) {
         m.ws.arena.bytes = L.total;
     }
     m.ws.buf.clear();
-    for (auto& it : L.items) m.ws.buf[it.first] = static_cast<uint8_t*>(m.ws.arena.ptr) + it.second.first;
+    m.ws.bytes.clear();
+    for (auto& it : L.items) {
+        m.ws.buf[it.first] = static_cast<uint8_t*>(m.ws.arena.ptr) + it.second.first;
+        m.ws.bytes[it.first] = it.second.second;
+    }
     m.ws.B = B; m.ws.W = W; m.ws.H = H;
     void* s = m.backend->stream;
 
@@ -576,7 +580,12 @@ struct exec_ctx {
 
     const void* wptr(size_t off) const { return wa + off; }
     const float* fptr(packed_vec const& v) const { return reinterpret_cast<const float*>(wa + v.off); }
-    void* buf(const char* name) { return m.ws.buf.at(name); }
+    int sub_b0 = 0; // first image of the sub-batch being scheduled: every activation buffer is image-major, so a sub-batch is an offset
+    void* buf(const char* name) {
+        uint8_t* base = static_cast<uint8_t*>(m.ws.buf.at(name));
+        if (sub_b0 == 0 || strcmp(name, "pos") == 0) return base;
+        return base + (size_t)sub_b0 * (m.ws.bytes.at(name) / (size_t)m.ws.B);
+    }
 
     void mark(const char* name, int launches, double flops, double bytes) {
         if (!m.timing) return;
@@ -739,13 +748,14 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     // offset into the same workspace; VISP_SPLIT=n runs n sub-batches on parallel streams (captured as parallel branches of
     // the hipGraph) so that kernels with different bottlenecks -- HBM-bound LayerNorms, VALU-bound attention, MFMA/LDS-bound
     // GEMMs -- of different sub-batches overlap.
-    auto run_encoder = [&](int b0, int nb, void* strm) {
+    auto run_sub = [&](int b0, int nb, void* strm) {
     const int B = nb;
-    const long M = (long)nb * T;
+    const long M = (long)nb * T, MP = (long)nb * Pn;
     void* const stream = strm;
     c.stream = strm;
-    float* const x = static_cast<float*>(c.buf("x")) + (size_t)b0 * T * D;
-    auto sub = [&](const char* name, size_t row_bytes) -> void* { return static_cast<uint8_t*>(c.buf(name)) + (size_t)b0 * T * row_bytes; };
+    c.sub_b0 = b0;
+    float* const x = static_cast<float*>(c.buf("x"));
+    auto sub = [&](const char* name, size_t) -> void* { return c.buf(name); };
     void* const ln = sub("ln", (size_t)D * 2);
     void* const qb = sub("q", (size_t)D * 2);
     void* const kb = sub("k", (size_t)D * 2);
@@ -895,29 +905,6 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         }
     }
     if (!use_block && tap != 4) throw except("depthany: expected 4 feature layers, found %d", tap);
-    }; // run_encoder
-    {
-        // measured at batch 32 (profiles/r02_split_streams.txt): 7.70 / 7.24 / 7.21 / 7.33 ms per step for 1 / 2 / 3 / 4 sub-batches
-        static const int split_env = getenv("VISP_SPLIT") ? atoi(getenv("VISP_SPLIT")) : 0;
-        const int want = split_env > 0 ? split_env : (B >= 24 ? 3 : (B >= 8 ? 2 : 1));
-        const int n_split = (!m.timing && !m.captures && want > 1 && want <= 4 && B >= 2 * want) ? want : 1;
-        if (n_split == 1) {
-            run_encoder(0, B, stream);
-        } else {
-            VX(vx_event_record(m.fork_event, stream));
-            for (int j = 0; j < n_split; ++j) {
-                const int b0 = (int)((long)B * j / n_split), b1 = (int)((long)B * (j + 1) / n_split);
-                void* strm = j == 0 ? stream : m.aux_stream[j - 1];
-                if (j > 0) VX(vx_stream_wait_event(strm, m.fork_event));
-                run_encoder(b0, b1 - b0, strm);
-                if (j > 0) {
-                    VX(vx_event_record(m.join_event[j - 1], strm));
-                    VX(vx_stream_wait_event(stream, m.join_event[j - 1]));
-                }
-            }
-        }
-        c.stream = stream;
-    }
 
     // ---- dpt::neck reassemble (depth-anything.cpp:44-64)
     const int lh[4] = {4 * ph, 2 * ph, ph, (ph + 2 - 3) / 2 + 1};
@@ -1020,7 +1007,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     c.capture("head_conv1", c.buf("h1"), {B, fh, fw, HC}, true);
     c.mark("bilinear", 1, 0, (double)B * ((double)fh * fw + (double)H * W) * HC * 2);
     VX(vx_bilinear_ac_f16(c.buf("h1"), c.buf("hup"), B, fh, fw, HC, H, W, stream));
-    float* depth = raw_out_dev ? static_cast<float*>(raw_out_dev) : static_cast<float*>(c.buf("depth"));
+    float* depth = raw_out_dev ? static_cast<float*>(raw_out_dev) + (size_t)b0 * H * W : static_cast<float*>(c.buf("depth"));
     if (Wt.head2.N == 32) {
         // conv2 (3x3 -> 32) + ReLU + conv3 (1x1 -> 1) + ReLU [* max_depth] in one kernel: the 32-channel
         // full-resolution tensor never reaches HBM
@@ -1052,7 +1039,31 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
 
     // ---- depthany_process_output (depth-anything.cpp:142-149): per-image min-max to [0,1]
     c.mark("normalize", 3, 0, (double)B * H * W * 12);
-    VX(vx_minmax_normalize(depth, static_cast<float*>(out_dev), static_cast<float*>(c.buf("minmax")), B, (int64_t)H * W, stream));
+    VX(vx_minmax_normalize(depth, static_cast<float*>(out_dev) + (size_t)b0 * H * W, static_cast<float*>(c.buf("minmax")), B, (int64_t)H * W, stream));
+    }; // run_sub
+    {
+        // measured at batch 32 (profiles/r02_split_streams.txt): 7.70 / 7.24 / 7.21 / 7.33 ms per step for 1 / 2 / 3 / 4 sub-batches (GEMM schedule)
+        static const int split_env = getenv("VISP_SPLIT") ? atoi(getenv("VISP_SPLIT")) : 0;
+        const int want = split_env > 0 ? split_env : (B >= 24 ? 3 : (B >= 8 ? 2 : 1));
+        const int n_split = (!m.timing && !m.captures && want > 1 && want <= 4 && B >= 2 * want) ? want : 1;
+        if (n_split == 1) {
+            run_sub(0, B, stream);
+        } else {
+            VX(vx_event_record(m.fork_event, stream));
+            for (int j = 0; j < n_split; ++j) {
+                const int b0 = (int)((long)B * j / n_split), b1 = (int)((long)B * (j + 1) / n_split);
+                void* strm = j == 0 ? stream : m.aux_stream[j - 1];
+                if (j > 0) VX(vx_stream_wait_event(strm, m.fork_event));
+                run_sub(b0, b1 - b0, strm);
+                if (j > 0) {
+                    VX(vx_event_record(m.join_event[j - 1], strm));
+                    VX(vx_stream_wait_event(stream, m.join_event[j - 1]));
+                }
+            }
+        }
+        c.stream = stream;
+        c.sub_b0 = 0;
+    }
     c.finish_timing();
 }
 

@@ -96,6 +96,7 @@ struct depthany_workspace {
     device_buffer arena;
     // named sub-buffers (device pointers into arena)
     std::map<std::string, void*> buf;
+    std::map<std::string, size_t> bytes; // size of each sub-buffer (all but "pos" are image-major: bytes / B per image)
     void* graph_exec = nullptr;
 };
 
