@@ -482,9 +482,39 @@ static float* transpose_new(const float* w, int64_t N, int64_t K) { /* [N][K] ->
 }
 
 /* src/visp/nn.cpp:6-12: mul_mat(weight, x) + bias; weight ne=[K,N] == torch [N][K] */
+/* What-if switch for the fp8 decision (tests/test_fp8_decision.py; not part of the reference): with mode 1 every linear
+ * rounds its INPUT rows to OCP e4m3 (per-row amax mapped to 448) before the product, as an fp8 MFMA path would. */
+static int g_linear_act_quant = 0;
+void vo_set_linear_act_quant(int mode) { g_linear_act_quant = mode; }
+float vo_round_e4m3(float v) { /* nearest e4m3fn value: 3 mantissa bits, normals from 2^-6, subnormal step 2^-9, max 448 */
+    float a = fabsf(v);
+    if (!(a > 0.0f)) return 0.0f;
+    if (a > 448.0f) a = 448.0f;
+    int e;
+    frexpf(a, &e); /* a = f * 2^e, f in [0.5, 1) -> floor(log2 a) = e - 1 */
+    int ex = e - 1;
+    if (ex < -6) ex = -6;
+    float step = ldexpf(1.0f, ex - 3);
+    float r = nearbyintf(a / step) * step;
+    if (r > 448.0f) r = 448.0f;
+    return v < 0.0f ? -r : r;
+}
 void vo_linear(const float* x, int64_t M, int64_t K, const float* w, const float* b, int64_t N, float* y) {
     float* wt = transpose_new(w, N, K);
-    gemm_nn(x, K, wt, N, y, N, M, K, N, b);
+    if (g_linear_act_quant) {
+        float* xq = (float*)malloc((size_t)M * K * sizeof(float));
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; ++m) {
+            float amax = 0.0f;
+            for (int64_t k = 0; k < K; ++k) amax = fmaxf(amax, fabsf(x[m * K + k]));
+            float sc = amax > 0.0f ? 448.0f / amax : 1.0f, inv = 1.0f / sc;
+            for (int64_t k = 0; k < K; ++k) xq[m * K + k] = vo_round_e4m3(x[m * K + k] * sc) * inv;
+        }
+        gemm_nn(xq, K, wt, N, y, N, M, K, N, b);
+        free(xq);
+    } else {
+        gemm_nn(x, K, wt, N, y, N, M, K, N, b);
+    }
     free(wt);
 }
 

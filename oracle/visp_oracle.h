@@ -105,6 +105,9 @@ void vo_depthany_image_extent(int w, int h, int image_size, int image_multiple, 
 int vo_transfer_tensor(const vo_tensor* src, int whcn_to_cwhn, void* dst, int64_t out_ne[4]);
 
 /* ---- primitives (src/visp/nn.cpp; semantics in SURVEY Appendix A) ---------------------- */
+/* fp8 what-if (tests/test_fp8_decision.py): 1 = linear inputs rounded to e4m3 per row; not reference behaviour */
+void vo_set_linear_act_quant(int mode);
+float vo_round_e4m3(float v);
 void vo_linear(const float* x, int64_t M, int64_t K, const float* w /*[N][K]*/, const float* b,
                int64_t N, float* y);
 void vo_layer_norm(const float* x, int64_t M, int64_t C, const float* w, const float* b, float eps,
