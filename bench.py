@@ -260,17 +260,17 @@ def main():
                 res["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM / 1e9,
                                    "unit": "GB/s", "frac": round(ach * 1e9 / PEAK_HBM, 4), "traffic": None,
                                    "avg_launch_ms": round(per_launch_ms, 4), "launches_per_step": dom["launches"]}
-            # HBM traffic per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
-            # separately on tools/bench_kernels.py, same shapes; corrected per MI355X_MICROARCH.md): profiles/r01_pmc/
+            # HBM traffic and MFMA-busy % per launch of that kernel from the PMC passes (rocprofv3 --pmc, one counter set per
+            # pass, on tools/bench_block.py --pmc = the same launch shapes; units and corrections in tools/pmc_summary.py)
             pmc = ROOT / "profiles" / ("r02_pmc" if (ROOT / "profiles" / "r02_pmc" / "traffic.json").exists() else "r01_pmc") / "traffic.json"
             if pmc.exists():
                 k = json.loads(pmc.read_text())["kernels"].get(dom["name"])
                 if k:
                     res["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_source"] = f"profiles/{pmc.parent.name}/traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
+                    res["roofline"]["traffic_source"] = f"profiles/{pmc.parent.name}/traffic.json (FETCH_SIZE{' x2' if k.get('fetch_doubled', True) else ''} + WRITE_SIZE)"
                     if "mfma_busy_pct" in k:
                         res["roofline"]["mfma_busy_pct"] = k["mfma_busy_pct"]
-                        res["roofline"]["mfma_busy_source"] = f"profiles/{pmc.parent.name}/ (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"
+                        res["roofline"]["mfma_busy_source"] = f"profiles/{pmc.parent.name}/ (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs))"
             res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, imgs, o, args.cpu_images, args.cpu_threads)

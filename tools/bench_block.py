@@ -49,6 +49,14 @@ def block_case(B, mlp=True, tap=False, qkv=True, fn="vx_dino_block_f16", no_dma=
     return ms
 
 
+if __name__ == "__main__" and "--pmc" in sys.argv:
+    # target of the rocprofv3 --pmc passes (profiles/r02_pmc/): the north-star launch shapes once each, nothing else
+    from bench_kernels import attn_case
+    block_case(32)
+    block_case(32, mlp=False)
+    attn_case(32, 6, 1370)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--stamps" not in sys.argv:
     for rnd in range(2):
         for fn2 in ("vx_dino_block2_f16",):

@@ -1,37 +1,55 @@
 #!/usr/bin/env python3
-"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs (two separate passes, tools/bench_kernels.py
---quick) into per-kernel HBM traffic per launch. Units and corrections per MI355X_MICROARCH.md section HBM:
-both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced streaming reads
-(TCC_EA0_RDREQ tallied at 64 B for 128-B requests), so it is doubled; WRITE_SIZE is exact for 16-B/lane stores."""
+"""Turns the rocprofv3 --pmc passes of tools/profile_round.sh (one counter set per pass, kernel trace only, target
+tools/bench_block.py --pmc: the north-star launch shapes B = 32, T = 1370, D = 384) into per-kernel figures per launch:
+
+  * HBM traffic = FETCH_SIZE + WRITE_SIZE. Both counters are in KiB (MI355X_MICROARCH.md, HBM section). On gfx950
+    FETCH_SIZE tallies a 128-byte read request as 64 bytes, so it is DOUBLED for kernels whose reads are wide coalesced
+    streams (attention: K/V/Q tiles by 16 B per lane, 1 KiB per wave instruction). The block kernel reads its token rows
+    as 32-byte segments of 32 different rows per wave instruction (a lane owns a token column); its requests are not
+    128-byte ones and the raw counter already equals the algorithmic bytes: the QKV-only instance reads x once
+    (32 x 1370 x 384 x 4 = 67.3 MB) and FETCH_SIZE reports 67.5 MB. WRITE_SIZE is exact.
+  * MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs). SQ_VALU_MFMA_BUSY_CYCLES counts 32
+    per v_mfma_f32_32x32x16_f16 summed over the chip (block kernel: 151.7 M = 32 x 4.74 M MFMAs = 155.1 GFLOP / 32768);
+    GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+
+    python tools/pmc_summary.py gpurun_out/prof_r02 profiles/r02_pmc/traffic.json"""
 import csv
 import json
 import sys
 from collections import defaultdict
 from pathlib import Path
 
-GROUPS = {"attention_kernel": "attention", "ELi1ELi5ELb0": "gemm_qkv", "1, 5, false": "gemm_qkv", "1, 1, false": "gemm_fc1",
-          "1, 3, false": "gemm_resid(fc2+out avg)"}
+GROUPS = {"dino_block_kernel<true, true": "block", "dino_block_kernel<false, true": "block_qkv0", "attention_kernel": "attention"}
+FETCH_X2 = {"attention": True, "block": False, "block_qkv0": False}
 
 
-def per_kernel(path, counter):
-    acc = defaultdict(list)
+def collect(path):
+    acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
         for key, grp in GROUPS.items():
             if key in r["Kernel_Name"]:
-                acc[grp].append(float(r["Counter_Value"]) * 1024.0)
+                acc[grp][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                acc[grp]["_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
                 break
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    return {g: {k: sum(v) / len(v) for k, v in d.items()} for g, d in acc.items()}
 
 
 if __name__ == "__main__":
-    fetch_csv, write_csv, out = sys.argv[1:4]
-    f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    src, out = Path(sys.argv[1]), Path(sys.argv[2])
+    fetch, write = collect(src / "fetch_size_pass.csv"), collect(src / "write_size_pass.csv")
+    sq, grbm = collect(src / "sq_valu_mfma_busy_cycles_pass.csv"), collect(src / "grbm_gui_active_pass.csv")
     res = {}
-    for k in sorted(set(f) | set(w)):
-        fb, wb = 2.0 * f.get(k, 0.0), w.get(k, 0.0)
-        res[k] = {"fetch_bytes_corrected_x2": round(fb), "write_bytes": round(wb), "hbm_bytes_per_launch": round(fb + wb)}
-    Path(out).write_text(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/bench_kernels.py --quick "
-                                               "(B=32, T=1370, D=384); FETCH_SIZE doubled per MI355X_MICROARCH.md", "kernels": res}, indent=1))
+    for g in sorted(fetch):
+        raw = fetch[g]["FETCH_SIZE"] * 1024.0
+        fb = raw * (2.0 if FETCH_X2[g] else 1.0)
+        wb = write[g]["WRITE_SIZE"] * 1024.0
+        cyc = grbm[g]["GRBM_GUI_ACTIVE"] / 8.0
+        res[g] = {"fetch_bytes_raw": round(raw), "fetch_doubled": FETCH_X2[g], "fetch_bytes": round(fb), "write_bytes": round(wb),
+                  "hbm_bytes_per_launch": round(fb + wb), "launch_us_under_pmc": round(grbm[g]["_us"], 1),
+                  "shader_clock_ghz": round(cyc / grbm[g]["_us"] / 1e3, 2),
+                  "mfma_busy_pct": round(100.0 * sq[g]["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 1),
+                  "sq": {k: round(v) for k, v in sq[g].items() if not k.startswith("_")}}
+    out.parent.mkdir(parents=True, exist_ok=True)
+    out.write_text(json.dumps({"source": "rocprofv3 --pmc passes of tools/profile_round.sh on tools/bench_block.py --pmc (B=32, T=1370, D=384); "
+                                         "see tools/pmc_summary.py for units and corrections", "kernels": res}, indent=1))
     print(json.dumps(res, indent=1))
