@@ -537,3 +537,85 @@ def sam_compute(model: "Model", embed: np.ndarray, image_w: int, image_h: int, p
     iou, masks = np.empty(4, np.float32), np.empty((4, 4 * res, 4 * res), np.float32)
     _check(_sam_lib().vo_sam_compute(model._h, _fp(e), res, dim, image_w, image_h, p, len(prompt), out.ctypes.data, _fp(iou), _fp(masks)))
     return (out, iou, masks) if return_all else out
+
+
+# ---- SWIN transformer encoder, the BiRefNet backbone (reference src/visp/arch/swin.cpp) ------------------------------
+
+class SwinParams(C.Structure):
+    _fields_ = [("embed_dim", C.c_int), ("window_size", C.c_int), ("depths", C.c_int * 4), ("n_heads", C.c_int * 4)]
+
+
+def swin_params(embed_dim=96, window_size=7, depths=(2, 2, 6, 2), n_heads=(3, 6, 12, 24)) -> SwinParams:
+    """Defaults = swin_t_params (swin.cpp:266-275)."""
+    return SwinParams(embed_dim, window_size, (C.c_int * 4)(*depths), (C.c_int * 4)(*n_heads))
+
+
+def _swin_lib():
+    L = lib()
+    if not getattr(L, "_swin_ready", False):
+        fp = C.POINTER(C.c_float)
+        L.vo_swin_rel_pos_index.argtypes = [C.c_int, C.POINTER(C.c_int32)]
+        L.vo_swin_attention_mask.argtypes = [C.c_int, C.c_int, C.c_int, fp]
+        L.vo_swin_block.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.vo_swin_patch_merging.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.POINTER(fp), C.POINTER(C.c_int)]
+        L.vo_swin_encode.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(SwinParams), fp, C.c_int, C.c_int, fp * 4, (C.c_int * 3) * 4,
+                                     C.POINTER(Capture), C.c_int]
+        L.vo_free.argtypes = [C.c_void_p]
+        L._swin_ready = True
+    return L
+
+
+def swin_rel_pos_index(window: int) -> np.ndarray:
+    out = np.empty(window ** 4, np.int32)
+    _swin_lib().vo_swin_rel_pos_index(window, out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
+def swin_attention_mask(w: int, h: int, window: int) -> np.ndarray:
+    """[n_windows, ws^2, ws^2] of 0 / -inf (swin.cpp:165-213)."""
+    nw = ((w + window - 1) // window) * ((h + window - 1) // window)
+    out = np.empty((nw, window * window, window * window), np.float32)
+    _swin_lib().vo_swin_attention_mask(w, h, window, _fp(out))
+    return out
+
+
+def swin_block(model: "Model", prefix: str, x: np.ndarray, w: int, h: int, heads: int, window: int, shift: int) -> np.ndarray:
+    """x: tokens [h*w, C] (row = y*w + x) -> same shape."""
+    x = _f32(x).copy()
+    assert x.shape[0] == w * h
+    mask = swin_attention_mask(w, h, window) if shift > 0 else None
+    _check(_swin_lib().vo_swin_block(model._h, prefix.encode(), _fp(x), w, h, x.shape[1], heads, window, shift, _fp(mask)))
+    return x
+
+
+def swin_patch_merging(model: "Model", prefix: str, x: np.ndarray, w: int, h: int) -> np.ndarray:
+    x = _f32(x)
+    fp = C.POINTER(C.c_float)
+    out, co = fp(), C.c_int()
+    _check(_swin_lib().vo_swin_patch_merging(model._h, prefix.encode(), _fp(x), w, h, x.shape[1], C.byref(out), C.byref(co)))
+    n = (w // 2) * (h // 2)
+    res = np.ctypeslib.as_array(out, shape=(n * co.value,)).reshape(n, co.value).copy()
+    _swin_lib().vo_free(out)
+    return res
+
+
+def swin_encode(model: "Model", params: SwinParams, image: np.ndarray, prefix: str = "bb", captures: dict[str, int] | None = None):
+    """image: normalised rgb f32 [H, W, 3] -> list of four normed stage outputs [h_i, w_i, C_i] (swin.cpp:237-262)."""
+    img = _f32(image)
+    H, W = img.shape[:2]
+    fp = C.POINTER(C.c_float)
+    outs = (fp * 4)()
+    dims = ((C.c_int * 3) * 4)()
+    caps = captures or {}
+    bufs = {k: np.empty(n, np.float32) for k, n in caps.items()}
+    names = [k.encode() for k in caps]
+    carr = (Capture * max(1, len(caps)))(*[Capture(nm, _fp(bufs[k]), bufs[k].size, 0) for nm, k in zip(names, caps)])
+    _check(_swin_lib().vo_swin_encode(model._h, prefix.encode(), C.byref(params), _fp(img), W, H, outs, dims, carr, len(caps)))
+    res = []
+    for i in range(4):
+        w, h, c = dims[i][0], dims[i][1], dims[i][2]
+        res.append(np.ctypeslib.as_array(outs[i], shape=(h * w * c,)).reshape(h, w, c).copy())
+        _swin_lib().vo_free(outs[i])
+    if captures is None:
+        return res
+    return res, {k: bufs[k][: carr[i].written].copy() for i, k in enumerate(caps)}

@@ -1993,3 +1993,260 @@ int vo_sam_compute(const vo_model* m, const float* embed, int res, int dim, int 
     free(masks);
     return ok;
 }
+
+/* ==== SWIN transformer encoder (backbone of BiRefNet) =========================================
+ * Restates reference src/visp/arch/swin.cpp. GGUF names as scripts/convert.py:358-419 writes them (timm / BiRefNet names under
+ * a prefix, normally "bb"): patch_embed.proj (stored NHWC) + patch_embed.norm, layers.L.blocks.B.{norm1, attn.qkv, attn.proj,
+ * attn.relative_position_bias_table [(2ws-1)^2][heads], norm2, mlp.fc1, mlp.fc2}, layers.L.downsample.{norm, reduction},
+ * norm0..3. GELU is ggml_gelu (same knob as TinyViT: vo_tinyvit_set_gelu_modes' "other" mode). */
+
+/* swin.cpp:26-38: index into the bias table for (query i, key j) of a ws x ws window, i = y0*ws + x0 fastest */
+void vo_swin_rel_pos_index(int ws, int32_t* dst) {
+    const int n = ws, n2 = n * n, n4 = n2 * n2;
+    for (int i = 0; i < n4; ++i) {
+        const int x0 = i % n, y0 = (i / n) % n, x1 = (i / n2) % n, y1 = (i / n2 / n) % n;
+        dst[i] = (y1 - y0 + n - 1) * (2 * n - 1) + (x1 - x0 + n - 1);
+    }
+}
+
+/* swin.cpp:165-213 compute_attention_mask: out [nw_y*nw_x][ws^2][ws^2], 0 or -inf; only the windows of the last row / column
+ * mix tokens that the shift brought together from opposite image edges */
+void vo_swin_attention_mask(int w, int h, int ws, float* out) {
+    const int n = ws, n2 = n * n, shift = ws / 2;
+    const int nw_x = (w + n - 1) / n, nw_y = (h + n - 1) / n, w_pad = nw_x * n, h_pad = nw_y * n;
+    const int64_t n4 = (int64_t)n2 * n2;
+    for (int64_t i = 0; i < (int64_t)nw_x * nw_y * n4; ++i) out[i] = 0.0f;
+    for (int iw_y = 0; iw_y < nw_y; ++iw_y)
+        for (int iw_x = 0; iw_x < nw_x; ++iw_x) {
+            if (iw_y < nw_y - 1 && iw_x < nw_x - 1) continue;
+            float* o = out + ((int64_t)iw_y * nw_x + iw_x) * n4;
+            for (int y0 = 0; y0 < n; ++y0)
+                for (int x0 = 0; x0 < n; ++x0)
+                    for (int y1 = 0; y1 < n; ++y1)
+                        for (int x1 = 0; x1 < n; ++x1) {
+                            const int yy0 = iw_y * n + y0, xx0 = iw_x * n + x0, yy1 = iw_y * n + y1, xx1 = iw_x * n + x1;
+                            const int match_y = (yy0 < h_pad - shift) == (yy1 < h_pad - shift);
+                            const int match_x = (xx0 < w_pad - shift) == (xx1 < w_pad - shift);
+                            if (!match_y || !match_x) o[(int64_t)(y0 * n + x0) * n2 + (y1 * n + x1)] = -INFINITY;
+                        }
+        }
+}
+
+static float round_f16(float v) {
+    uint16_t hbits;
+    float r;
+    vo_f32_to_f16(&v, &hbits, 1);
+    vo_f16_to_f32(&hbits, &r, 1);
+    return r;
+}
+
+/* window_attention (swin.cpp:80-115) on x [n_win][N][C]: bias = table rows gathered by the relative position index and cast
+ * to f16 (:88-92), plus the shift mask of the window (mask [n_mask_windows][N][N], window wi uses wi % n_mask_windows; NULL for
+ * unshifted blocks); qkv split per token as [3][heads][hd] (split_qkv dim 2, nn.cpp:191-194); soft_max_ext(scale, mask); proj */
+static int swin_window_attention(const vo_model* m, const char* prefix, const float* x, int n_win, int ws, int C, int heads,
+                                 const float* mask, int n_mask_windows, float* y) {
+    char p[200];
+    const int N = ws * ws, hd = C / heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    int64_t tne[4];
+    const float* table = W(m, prefix, "relative_position_bias_table", tne, 1); /* torch [(2ws-1)^2][heads] */
+    if (!table) return 0;
+    if (tne[0] != heads || tne[1] != (2 * ws - 1) * (2 * ws - 1))
+        VO_FAIL("%s.relative_position_bias_table: ne [%lld,%lld], expected [%d,%d]", prefix, (long long)tne[0], (long long)tne[1], heads, (2 * ws - 1) * (2 * ws - 1));
+    int32_t* idx = (int32_t*)malloc((size_t)N * N * sizeof(int32_t));
+    vo_swin_rel_pos_index(ws, idx);
+    float* bias = (float*)malloc((size_t)heads * N * N * 4); /* [heads][N(query)][N(key)] */
+    for (int i = 0; i < N; ++i)      /* get_rows result [heads, n*n] with row r = i (query) * N + j (key)? The index tensor is */
+        for (int j = 0; j < N; ++j)  /* laid out with (x0,y0) fastest = KEY fastest in [n, n, heads] after reshape/permute: */
+            for (int h = 0; h < heads; ++h) /* element (key j, query i) reads idx[i * N + j] with (x0,y0) = key */
+                bias[((int64_t)h * N + i) * N + j] = round_f16(table[(int64_t)idx[i * N + j] * heads + h]);
+    free(idx);
+    const int64_t M = (int64_t)n_win * N;
+    float* qkv = NULL;
+    int n3;
+    snprintf(p, sizeof p, "%s.qkv", prefix);
+    if (!tv_linear(m, p, x, M, C, &n3, &qkv)) { free(bias); return 0; }
+    if (n3 != 3 * C) { free(qkv); free(bias); VO_FAIL("%s.qkv: %d outputs, expected %d", prefix, n3, 3 * C); }
+    float* att = (float*)malloc((size_t)M * C * 4);
+#pragma omp parallel for schedule(static)
+    for (int wi = 0; wi < n_win; ++wi) {
+        float* s = (float*)malloc((size_t)N * 4);
+        const float* mk = mask ? mask + (int64_t)(wi % n_mask_windows) * N * N : NULL;
+        for (int h = 0; h < heads; ++h)
+            for (int i = 0; i < N; ++i) {
+                const float* q = qkv + ((int64_t)wi * N + i) * n3 + h * hd;
+                float mx = -INFINITY;
+                for (int j = 0; j < N; ++j) {
+                    const float* k = qkv + ((int64_t)wi * N + j) * n3 + C + h * hd;
+                    float d = 0.0f;
+                    for (int c = 0; c < hd; ++c) d = __builtin_fmaf(q[c], k[c], d);
+                    float b = bias[((int64_t)h * N + i) * N + j];
+                    if (mk) b = mk[(int64_t)i * N + j] + b; /* f16 add in the reference: 0 + b or -inf + b, both exact */
+                    d = d * scale + b;
+                    s[j] = d;
+                    if (d > mx) mx = d;
+                }
+                double sum = 0.0;
+                for (int j = 0; j < N; ++j) { float e = expf(s[j] - mx); s[j] = e; sum += (double)e; }
+                const float inv = (float)(1.0 / sum);
+                float* o = att + ((int64_t)wi * N + i) * C + h * hd;
+                for (int c = 0; c < hd; ++c) o[c] = 0.0f;
+                for (int j = 0; j < N; ++j) {
+                    const float pj = s[j] * inv;
+                    const float* v = qkv + ((int64_t)wi * N + j) * n3 + 2 * C + h * hd;
+                    for (int c = 0; c < hd; ++c) o[c] = __builtin_fmaf(pj, v[c], o[c]);
+                }
+            }
+        free(s);
+    }
+    free(qkv); free(bias);
+    float* pr = NULL;
+    int np;
+    snprintf(p, sizeof p, "%s.proj", prefix);
+    int ok = tv_linear(m, p, att, M, C, &np, &pr);
+    free(att);
+    if (!ok) return 0;
+    memcpy(y, pr, (size_t)M * C * 4);
+    free(pr);
+    return 1;
+}
+
+/* block (swin.cpp:117-163) on tokens x [h*w][C] (row = y*w + x), in place. shift > 0 needs the mask of (w, h). */
+int vo_swin_block(const vo_model* m, const char* prefix, float* x, int w, int h, int C, int heads, int ws, int shift, const float* mask) {
+    char p[200];
+    const int64_t T = (int64_t)w * h;
+    if (shift > 0 && !mask) VO_FAIL("%s: shifted block without attention mask", prefix);
+    float* ln = (float*)malloc((size_t)T * C * 4);
+    snprintf(p, sizeof p, "%s.norm1", prefix);
+    if (!tv_layer_norm(m, p, x, T, C, 1e-5f, ln)) { free(ln); return 0; }
+    const int pad_r = (ws - w % ws) % ws, pad_b = (ws - h % ws) % ws, wp = w + pad_r, hp = h + pad_b;
+    const int nwx = wp / ws, nwy = hp / ws, N = ws * ws;
+    const int64_t n_win = (int64_t)nwx * nwy;
+    /* pad (zeros right/bottom), roll by -shift, window_partition: window token (wy,wx,iy,ix) holds padded pixel
+     * ((wy*ws+iy + shift) mod hp, (wx*ws+ix + shift) mod wp) */
+    float* win = (float*)calloc((size_t)n_win * N * C, 4);
+    for (int py = 0; py < hp; ++py)
+        for (int px = 0; px < wp; ++px) {
+            const int sy = (py + shift) % hp, sx = (px + shift) % wp;
+            if (sy >= h || sx >= w) continue;
+            memcpy(win + ((((int64_t)(py / ws) * nwx + px / ws) * ws + py % ws) * ws + px % ws) * C, ln + ((int64_t)sy * w + sx) * C, (size_t)C * 4);
+        }
+    free(ln);
+    float* aw = (float*)malloc((size_t)n_win * N * C * 4);
+    snprintf(p, sizeof p, "%s.attn", prefix);
+    int ok = swin_window_attention(m, p, win, (int)n_win, ws, C, heads, shift > 0 ? mask : NULL, (int)n_win, aw);
+    free(win);
+    if (!ok) { free(aw); return 0; }
+    /* window_reverse, roll back by +shift, crop, + shortcut */
+    for (int py = 0; py < hp; ++py)
+        for (int px = 0; px < wp; ++px) {
+            const int sy = (py + shift) % hp, sx = (px + shift) % wp;
+            if (sy >= h || sx >= w) continue;
+            const float* a = aw + ((((int64_t)(py / ws) * nwx + px / ws) * ws + py % ws) * ws + px % ws) * C;
+            float* o = x + ((int64_t)sy * w + sx) * C;
+            for (int c = 0; c < C; ++c) o[c] = a[c] + o[c];
+        }
+    free(aw);
+    /* x + mlp(norm2(x)) (swin.cpp:10-15, 157-160) */
+    ln = (float*)malloc((size_t)T * C * 4);
+    snprintf(p, sizeof p, "%s.norm2", prefix);
+    if (!tv_layer_norm(m, p, x, T, C, 1e-5f, ln)) { free(ln); return 0; }
+    float *h1 = NULL, *h2 = NULL;
+    int nh, no;
+    snprintf(p, sizeof p, "%s.mlp.fc1", prefix);
+    ok = tv_linear(m, p, ln, T, C, &nh, &h1);
+    free(ln);
+    if (!ok) return 0;
+    gelu_inplace(h1, T * nh);
+    snprintf(p, sizeof p, "%s.mlp.fc2", prefix);
+    ok = tv_linear(m, p, h1, T, nh, &no, &h2);
+    free(h1);
+    if (!ok) return 0;
+    if (no != C) { free(h2); VO_FAIL("%s.mlp.fc2: %d outputs, expected %d", prefix, no, C); }
+    for (int64_t i = 0; i < T * C; ++i) x[i] = x[i] + h2[i];
+    free(h2);
+    return 1;
+}
+
+/* patch_merging (swin.cpp:140-161): channels of the 2x2 neighbourhood concatenated as (even y, even x), (odd y, even x),
+ * (even y, odd x), (odd y, odd x), LayerNorm(4C), reduction linear (no bias) -> out [(h/2)*(w/2)][2C] (malloc'd) */
+int vo_swin_patch_merging(const vo_model* m, const char* prefix, const float* x, int w, int h, int C, float** out, int* cout) {
+    char p[200];
+    if (w % 2 || h % 2) VO_FAIL("%s: patch merging expects even spatial dimensions, got %dx%d", prefix, w, h);
+    const int ow = w / 2, oh = h / 2;
+    const int64_t T = (int64_t)ow * oh;
+    float* cat = (float*)malloc((size_t)T * 4 * C * 4);
+    for (int y = 0; y < oh; ++y)
+        for (int xx = 0; xx < ow; ++xx) {
+            float* d = cat + ((int64_t)y * ow + xx) * 4 * C;
+            memcpy(d, x + ((int64_t)(2 * y) * w + 2 * xx) * C, (size_t)C * 4);
+            memcpy(d + C, x + ((int64_t)(2 * y + 1) * w + 2 * xx) * C, (size_t)C * 4);
+            memcpy(d + 2 * C, x + ((int64_t)(2 * y) * w + 2 * xx + 1) * C, (size_t)C * 4);
+            memcpy(d + 3 * C, x + ((int64_t)(2 * y + 1) * w + 2 * xx + 1) * C, (size_t)C * 4);
+        }
+    float* ln = (float*)malloc((size_t)T * 4 * C * 4);
+    snprintf(p, sizeof p, "%s.norm", prefix);
+    int ok = tv_layer_norm(m, p, cat, T, 4 * C, 1e-5f, ln);
+    free(cat);
+    if (!ok) { free(ln); return 0; }
+    snprintf(p, sizeof p, "%s.reduction", prefix);
+    ok = tv_linear(m, p, ln, T, 4 * C, cout, out);
+    free(ln);
+    return ok;
+}
+
+/* swin_encode (swin.cpp:237-262, 300-319): image = normalised rgb_f32 [H][W][3] (H, W multiples of 4; even token maps where a
+ * stage is merged). outs[i] (malloc'd here, caller frees) = norm_i(stage i output) as NHWC [h_i][w_i][C_i]; dims[i] = {w_i, h_i, C_i} */
+int vo_swin_encode(const vo_model* m, const char* prefix, const vo_swin_params* P, const float* image, int W_img, int H_img,
+                   float* outs[4], int dims[4][3], vo_capture* captures, int n_captures) {
+    char p[200], cname[64];
+    for (int i = 0; i < 4; ++i) outs[i] = NULL;
+    if (W_img % 4 || H_img % 4) VO_FAIL("swin: image extent %dx%d is not a multiple of the patch size 4", W_img, H_img);
+    int oh, ow, C;
+    float* x = NULL;
+    snprintf(p, sizeof p, "%s.patch_embed.proj", prefix);
+    if (!conv_m(m, p, image, 1, H_img, W_img, 3, 4, 0, &oh, &ow, &C, &x)) return 0;
+    int w = ow, h = oh;
+    snprintf(p, sizeof p, "%s.patch_embed.norm", prefix);
+    if (W(m, p, "weight", NULL, 0)) { /* nn.cpp:173-178 */
+        float* t = (float*)malloc((size_t)w * h * C * 4);
+        if (!tv_layer_norm(m, p, x, (int64_t)w * h, C, 1e-5f, t)) { free(t); free(x); return 0; }
+        free(x);
+        x = t;
+    }
+    capture(captures, n_captures, "patch_embed", x, (int64_t)w * h * C);
+    if (C != P->embed_dim) { free(x); VO_FAIL("swin: patch embed has %d channels, expected %d", C, P->embed_dim); }
+    int ok = 1;
+    for (int l = 0; l < 4 && ok; ++l) {
+        const int ws = P->window_size, heads = P->n_heads[l];
+        float* mask = NULL;
+        if (P->depths[l] > 1) {
+            const int nwx = (w + ws - 1) / ws, nwy = (h + ws - 1) / ws;
+            mask = (float*)malloc((size_t)nwx * nwy * ws * ws * ws * ws * 4);
+            vo_swin_attention_mask(w, h, ws, mask);
+        }
+        for (int b = 0; b < P->depths[l] && ok; ++b) {
+            snprintf(p, sizeof p, "%s.layers.%d.blocks.%d", prefix, l, b);
+            ok = vo_swin_block(m, p, x, w, h, C, heads, ws, b % 2 == 0 ? 0 : ws / 2, mask);
+            snprintf(cname, sizeof cname, "block_%d_%d", l, b);
+            if (ok) capture(captures, n_captures, cname, x, (int64_t)w * h * C);
+        }
+        free(mask);
+        if (!ok) break;
+        snprintf(p, sizeof p, "%s.norm%d", prefix, l);
+        outs[l] = (float*)malloc((size_t)w * h * C * 4);
+        ok = tv_layer_norm(m, p, x, (int64_t)w * h, C, 1e-5f, outs[l]);
+        dims[l][0] = w; dims[l][1] = h; dims[l][2] = C;
+        if (ok && l < 3) {
+            float* xd = NULL;
+            int co;
+            snprintf(p, sizeof p, "%s.layers.%d.downsample", prefix, l);
+            ok = vo_swin_patch_merging(m, p, x, w, h, C, &xd, &co);
+            if (ok) { free(x); x = xd; w = (w + 1) / 2; h = (h + 1) / 2; C = co; }
+        }
+    }
+    free(x);
+    if (!ok) for (int i = 0; i < 4; ++i) { free(outs[i]); outs[i] = NULL; }
+    return ok;
+}
+void vo_free(void* p) { free(p); }

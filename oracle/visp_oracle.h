@@ -199,6 +199,19 @@ void vo_sam_process_mask(const float* mask, int mask_size, int image_size, int t
 int vo_sam_compute(const vo_model*, const float* embed, int res, int dim, int image_w, int image_h, const int* prompt, int n_prompt,
                    uint8_t* out_mask, float* iou_out, float* masks_out);
 
+/* ---- SWIN transformer encoder, the BiRefNet backbone (reference src/visp/arch/swin.cpp) ---- */
+typedef struct { int embed_dim, window_size, depths[4], n_heads[4]; } vo_swin_params; /* swin_t: 96, 7, {2,2,6,2}, {3,6,12,24} (swin.cpp:266-275) */
+void vo_swin_rel_pos_index(int window, int32_t* dst /*[ws^4]*/);                      /* swin.cpp:26-38 */
+void vo_swin_attention_mask(int w, int h, int window, float* out /*[nw_y*nw_x][ws^2][ws^2]*/); /* swin.cpp:165-213 */
+/* block (swin.cpp:117-163) on tokens x [h*w][C] in place; mask = vo_swin_attention_mask(w, h) when shift > 0 */
+int vo_swin_block(const vo_model*, const char* prefix, float* x, int w, int h, int C, int heads, int window, int shift, const float* mask);
+/* patch_merging (swin.cpp:140-161): *out malloc'd [(h/2)*(w/2)][*cout], free with vo_free */
+int vo_swin_patch_merging(const vo_model*, const char* prefix, const float* x, int w, int h, int C, float** out, int* cout);
+/* swin_encode (swin.cpp:237-262): normalised rgb_f32 image [H][W][3] -> four normed stage outputs (NHWC, malloc'd: vo_free) */
+int vo_swin_encode(const vo_model*, const char* prefix, const vo_swin_params*, const float* image, int W, int H, float* outs[4],
+                   int dims[4][3], vo_capture* captures, int n_captures);
+void vo_free(void* p);
+
 /* dino building blocks, exposed for module-level parity tests */
 int vo_dino_layer(const vo_model*, const char* prefix, int n_heads, int gelu_mode, float* x /*[N][C] in/out*/,
                   int64_t N, int64_t C);

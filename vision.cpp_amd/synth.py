@@ -518,3 +518,96 @@ def write_mobile_sam_gguf(path: str | Path, cfg: TinyVitConfig = TINYVIT_5M, see
         w.add_tensor(name, t)
     w.write()
     return Path(path)
+
+
+# ---- SWIN transformer encoder, the BiRefNet backbone (reference src/visp/arch/swin.cpp, scripts/convert.py:358-419) ----
+
+@dataclass(frozen=True)
+class SwinConfig:
+    """swin_t_params (swin.cpp:266-275) by default; small instances for the parity tests keep head_dim = 32."""
+    embed_dim: int = 96
+    window_size: int = 7
+    depths: tuple = (2, 2, 6, 2)
+    n_heads: tuple = (3, 6, 12, 24)
+    mlp_ratio: int = 4
+    image_size: int = 1024
+    name: str = "swin_t"
+
+
+SWIN_T = SwinConfig()
+SWIN_MINI = SwinConfig(embed_dim=32, depths=(2, 2, 2, 2), n_heads=(1, 2, 4, 8), image_size=224, name="swin_mini")
+
+
+def swin_state_dict(cfg: SwinConfig = SWIN_T, seed: int = 0, prefix: str = "bb.") -> dict[str, np.ndarray]:
+    """float32 tensors under the names of a BiRefNet checkpoint's backbone (timm-style Swin), torch shapes. The
+    relative_position_index buffers are left out: the converter drops them (convert.py:391-392)."""
+    rng = np.random.default_rng(seed)
+    sd: dict[str, np.ndarray] = {}
+
+    def normal(shape, std):
+        return (rng.standard_normal(shape) * std).astype(np.float32)
+
+    def lin(name, out_f, in_f, gain=1.0, bias=True):
+        sd[f"{name}.weight"] = normal((out_f, in_f), gain / np.sqrt(in_f))
+        if bias:
+            sd[f"{name}.bias"] = normal((out_f,), 0.02)
+
+    def norm(name, c):
+        sd[f"{name}.weight"] = (1.0 + rng.standard_normal(c) * 0.05).astype(np.float32)
+        sd[f"{name}.bias"] = normal((c,), 0.02)
+
+    C = cfg.embed_dim
+    sd[f"{prefix}patch_embed.proj.weight"] = normal((C, 3, 4, 4), 1.0 / np.sqrt(48))
+    sd[f"{prefix}patch_embed.proj.bias"] = normal((C,), 0.02)
+    norm(f"{prefix}patch_embed.norm", C)
+    ws = cfg.window_size
+    for l in range(4):
+        c = C << l
+        for b in range(cfg.depths[l]):
+            p = f"{prefix}layers.{l}.blocks.{b}"
+            norm(f"{p}.norm1", c)
+            lin(f"{p}.attn.qkv", 3 * c, c, gain=1.5)
+            sd[f"{p}.attn.relative_position_bias_table"] = normal(((2 * ws - 1) ** 2, cfg.n_heads[l]), 0.5)
+            lin(f"{p}.attn.proj", c, c)
+            norm(f"{p}.norm2", c)
+            lin(f"{p}.mlp.fc1", cfg.mlp_ratio * c, c, gain=1.4)
+            lin(f"{p}.mlp.fc2", c, cfg.mlp_ratio * c, gain=1.4)
+        if l < 3:
+            norm(f"{prefix}layers.{l}.downsample.norm", 4 * c)
+            lin(f"{prefix}layers.{l}.downsample.reduction", 2 * c, 4 * c, bias=False)
+    for l in range(4):
+        norm(f"{prefix}norm{l}", C << l)
+    return sd
+
+
+def swin_gguf_tensors(sd: dict[str, np.ndarray]):
+    """convert_birefnet's rules for the backbone tensors (convert.py:413-419): the patch_embed kernel is always stored NHWC
+    (never listed in conv2d_weights), everything is written f16."""
+    out: dict[str, np.ndarray] = {}
+    for name, t in sd.items():
+        if t.ndim == 4 and "patch_embed" in name:
+            t = np.ascontiguousarray(t.transpose(0, 2, 3, 1))
+        out[name] = t.astype(np.float16)
+    return out, []
+
+
+def write_swin_gguf(path: str | Path, cfg: SwinConfig = SWIN_T, seed: int = 0, sd: dict[str, np.ndarray] | None = None) -> Path:
+    """A 'birefnet' GGUF holding the backbone only (metadata of convert.py:358-380)."""
+    sd = sd if sd is not None else swin_state_dict(cfg, seed)
+    tensors, _ = swin_gguf_tensors(sd)
+    w = GGUFWriter(path, "birefnet")
+    w.add_string("birefnet.tensor_data_layout", "whcn")
+    w.add_string("swin.config", "tiny" if cfg.embed_dim == 96 else ("large" if cfg.embed_dim == 192 else cfg.name))
+    w.add_int32("swin.embed_dim", cfg.embed_dim)
+    if cfg.embed_dim not in (96, 192):  # test instances: the layer table travels in the file (not a reference key)
+        w.add_int32("swin.window_size", cfg.window_size)
+        w.add_array_i32("swin.depths", cfg.depths)
+        w.add_array_i32("swin.n_heads", cfg.n_heads)
+    w.add_int32("birefnet.image_size", cfg.image_size)
+    w.add_int32("birefnet.image_multiple", 128)
+    w.add_uint32("general.quantization_version", 2)
+    w.add_uint32("general.file_type", 1)
+    for name, t in tensors.items():
+        w.add_tensor(name, t)
+    w.write()
+    return Path(path)
