@@ -196,6 +196,25 @@ VISP_API int32_t visp_sam_read_capture(visp_model* m, char const* name, float* h
 VISP_API int32_t visp_sam_enable_timing(visp_model* m, int32_t enable);
 VISP_API int32_t visp_sam_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
 
+/* ---- SWIN encoder, the backbone of BiRefNet (reference src/visp/arch/swin.cpp, swin_encode) ---------
+ * The BiRefNet decoder is not built in this backend yet, so visp_model_load / visp_model_compute keep refusing family 1; the
+ * encoder of a birefnet GGUF (tensors bb.*, KV swin.embed_dim) is reachable on its own. The handle is destroyed with
+ * visp_model_destroy(m, VISP_BIREFNET). */
+VISP_API int32_t visp_swin_load(char const* filepath, visp_device const* dev, visp_model** out);
+/* dims[3 i .. 3 i + 2] = {w_i, h_i, C_i} of output i for an image of extent (w, h) (swin.cpp:229-262) */
+VISP_API int32_t visp_swin_output_dims(visp_model* m, int32_t w, int32_t h, int32_t dims[12]);
+/* rgb_u8 [batch, h, w, 3] (device) -> outs[i] f32 [batch, h_i, w_i, C_i] (device; NHWC = the reference's CWHN result tensors):
+ * birefnet_process_input's normalisation (birefnet.cpp:259-270) + swin_encode. w, h multiples of 32. stream = hipStream_t or
+ * NULL (NULL: the device's stream, synchronised before returning). */
+VISP_API int32_t visp_swin_encode_batch_device(visp_model* m, void const* rgb_u8, int32_t batch, int32_t w, int32_t h, void* const outs[4],
+                                               void* stream);
+VISP_API int32_t visp_swin_encode_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w, int32_t h, float* const outs[4]);
+/* test hooks as for the other families: "patch_embed", "block_<layer>_<i>" (f16 -> f32), per-kernel-group timing */
+VISP_API int32_t visp_swin_enable_captures(visp_model* m, int32_t enable);
+VISP_API int32_t visp_swin_read_capture(visp_model* m, char const* name, float* host_out, int64_t capacity, int64_t* n_written, int64_t shape[4]);
+VISP_API int32_t visp_swin_enable_timing(visp_model* m, int32_t enable);
+VISP_API int32_t visp_swin_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
+
 #ifdef __cplusplus
 }
 #endif

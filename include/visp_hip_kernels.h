@@ -192,6 +192,22 @@ VX_API int vx_layernorm_f16(const void* x, const float* w, const float* b, void*
 VX_API size_t vx_window_attention_bias_bytes(int N, int heads);
 VX_API int vx_window_attention_pack_bias(const float* bias_host, int N, int heads, void* packed_host);
 VX_API int vx_window_attention_f16(const void* qkv, const void* bias_packed, void* out, int n_windows, int N, int heads, void* stream);
+/* ---- SWIN encoder (BiRefNet backbone, swin.cpp), kernels_swin.hip + the masked form of the window attention --------------
+ * shifted windows (swin.cpp:165-213): bias_packed holds FOUR images (vx_swin_attention_pack_bias: bias, + last-column mask,
+ * + last-row mask, + corner mask); window (wy, wx) of an nwy x nwx image picks its class. nwx = nwy = 0: one image. */
+VX_API int vx_swin_attention_pack_bias(const float* table /*[(2ws-1)^2][heads]*/, int ws, int heads, void* packed_host /*4 x bias_bytes(ws*ws, heads)*/);
+VX_API int vx_window_attention_masked_f16(const void* qkv, const void* bias_packed, void* out, int n_windows, int N, int heads, int nwx, int nwy,
+                                          void* stream);
+/* LayerNorm of f16 rows [.., C] (C % 8 == 0, <= 2048). ws > 0: norm1 + pad + roll(-shift) + window_partition of swin::block
+ * (swin.cpp:124-139): x is [B, H, W, C], output rows are window tokens (zeros where the padded map has no pixel). ws = 0: rows in
+ * place; out_f32 writes f32 (the per-stage output norms, swin.cpp:255-258). */
+VX_API int vx_swin_layernorm_f16(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int H, int W, int ws,
+                                 int shift, int out_f32, void* stream);
+/* patch_merging up to the reduction linear (swin.cpp:140-158): 2x2 gather in the reference's concat order + LayerNorm(4C);
+ * x [B, H, W, C] -> y [B * H/2 * W/2, 4C] */
+VX_API int vx_swin_merge_layernorm_f16(const void* x, const float* w, const float* b, void* y, int B, int H, int W, int C, float eps, void* stream);
+/* window_reverse + roll(+shift) + crop + shortcut (swin.cpp:141-156): y [B,H,W,C] = x + a[window row] */
+VX_API int vx_swin_window_reverse_add_f16(const void* a, const void* x, void* y, int B, int H, int W, int C, int ws, int shift, void* stream);
 /* window_reverse + residual: y[b,py,px,:] = x[b,py,px,:] + a[window row of (py,px),:] (mobile-sam.cpp:48-64, 146-149) */
 VX_API int vx_window_reverse_add_f16(const void* a, const void* x, void* y, int B, int res, int ws, int C, void* stream);
 /* y f16 = a + b[i mod b_period]; a f16 or f32 (SAM decoder: queries + query_pe, keys + key_pe, embedding + no_mask_embed) */

@@ -16,6 +16,7 @@
 #include "depthany.h"
 #include "esrgan.h"
 #include "tinyvit.h"
+#include "swin.h"
 #include "visp_util.h"
 
 using namespace visp;
@@ -63,6 +64,10 @@ esrgan_model& as_esrgan(visp_model* m) {
 sam_model& as_sam(visp_model* m) {
     if (family_of(m) != VISP_SAM) throw except("model handle is not a sam model (family %d)", family_of(m));
     return *static_cast<sam_model*>(reinterpret_cast<model_base*>(m));
+}
+swin_model& as_swin(visp_model* m) { // the encoder half of the birefnet family (visp_swin_load)
+    if (family_of(m) != VISP_BIREFNET) throw except("model handle is not a swin encoder (family %d)", family_of(m));
+    return *static_cast<swin_model*>(reinterpret_cast<model_base*>(m));
 }
 visp_model* handle_of(model_base* m) { return reinterpret_cast<visp_model*>(m); }
 
@@ -195,6 +200,7 @@ void visp_model_destroy(visp_model* model, int32_t arch) {
     if (base->family == VISP_DEPTH_ANYTHING) delete static_cast<depthany_model*>(base);
     else if (base->family == VISP_ESRGAN) delete static_cast<esrgan_model*>(base);
     else if (base->family == VISP_SAM) delete static_cast<sam_model*>(base);
+    else if (base->family == VISP_BIREFNET) delete static_cast<swin_model*>(base); // visp_swin_load
 }
 
 int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* inputs, int32_t n_inputs, int32_t* args, int32_t n_args,
@@ -573,6 +579,63 @@ int32_t visp_sam_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32
         sam_model& sm = as_sam(m);
         int32_t count = 0;
         for (timing_entry const& t : sm.last_timing) {
+            if (count >= cap) break;
+            snprintf(out[count].name, sizeof out[count].name, "%s", t.name.c_str());
+            out[count].ms = t.ms;
+            out[count].launches = t.launches;
+            out[count].flops = t.flops;
+            out[count].bytes = t.bytes;
+            ++count;
+        }
+        *n = count;
+    });
+}
+
+// ---- SWIN encoder (BiRefNet backbone) ----------------------------------------------------------------------------------
+
+int32_t visp_swin_load(char const* filepath, visp_device const* dev, visp_model** out) {
+    return handle_errors([&]() {
+        if (!filepath || !dev || !out) throw except("visp_swin_load: null argument");
+        *out = handle_of(swin_load_model(filepath, *reinterpret_cast<backend_device const*>(dev)));
+    });
+}
+
+int32_t visp_swin_output_dims(visp_model* m, int32_t w, int32_t h, int32_t dims[12]) {
+    return handle_errors([&]() {
+        int d[4][3];
+        swin_output_dims(as_swin(m), w, h, d);
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 3; ++j) dims[i * 3 + j] = d[i][j];
+    });
+}
+
+int32_t visp_swin_encode_batch_device(visp_model* m, void const* rgb_u8, int32_t batch, int32_t w, int32_t h, void* const outs[4], void* stream) {
+    return handle_errors([&]() { swin_encode_batch_device(as_swin(m), rgb_u8, batch, w, h, outs, stream); });
+}
+
+int32_t visp_swin_encode_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w, int32_t h, float* const outs[4]) {
+    return handle_errors([&]() { swin_encode_batch_host(as_swin(m), rgb_u8, batch, w, h, outs); });
+}
+
+int32_t visp_swin_enable_captures(visp_model* m, int32_t enable) {
+    return handle_errors([&]() { as_swin(m).captures = enable != 0; });
+}
+
+int32_t visp_swin_read_capture(visp_model* m, char const* name, float* host_out, int64_t capacity, int64_t* n_written, int64_t shape[4]) {
+    return handle_errors([&]() {
+        swin_model& sm = as_swin(m);
+        read_capture(*sm.backend, sm.capture_bufs, name, host_out, capacity, n_written, shape);
+    });
+}
+
+int32_t visp_swin_enable_timing(visp_model* m, int32_t enable) {
+    return handle_errors([&]() { as_swin(m).timing = enable != 0; });
+}
+
+int32_t visp_swin_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n) {
+    return handle_errors([&]() {
+        int32_t count = 0;
+        for (timing_entry const& t : as_swin(m).last_timing) {
             if (count >= cap) break;
             snprintf(out[count].name, sizeof out[count].name, "%s", t.name.c_str());
             out[count].ms = t.ms;

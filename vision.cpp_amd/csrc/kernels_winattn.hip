@@ -32,7 +32,7 @@ __device__ __forceinline__ float wa_other_half(float v) { // value of the lane t
 
 template <int QB>
 __global__ __launch_bounds__(QB * 64) void window_attention_kernel(const f16* __restrict__ qkv, const f16* __restrict__ bias, f16* __restrict__ out,
-                                                                   int N, int heads, float scale) {
+                                                                   int N, int heads, float scale, int nwx, int nwy, long cls_stride) {
     constexpr int NP = QB * 32;                      // padded tokens
     constexpr int ROW = WA_HD * 2;                   // bytes per K / V row in LDS
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * ROW];
@@ -66,6 +66,13 @@ __global__ __launch_bounds__(QB * 64) void window_attention_kernel(const f16* __
         qf[0] = *reinterpret_cast<const f16x8*>(qrow + 8 * h);
         qf[1] = *reinterpret_cast<const f16x8*>(qrow + 16 + 8 * h);
     }
+    // SWIN shifted windows (swin.cpp:165-213): the windows of the last row / column of an image add a -inf mask between tokens
+    // that the cyclic shift brought together; the host packs bias + mask for the four window classes (interior, last column,
+    // last row, corner) as four consecutive images (vx_swin_attention_pack_bias). nwx = 0: one image, no classes.
+    if (nwx > 0) {
+        const int wi = win % (nwx * nwy), wy = wi / nwx, wx = wi - wy * nwx;
+        bias += ((wy == nwy - 1 ? 2 : 0) + (wx == nwx - 1 ? 1 : 0)) * cls_stride;
+    }
     const f16* bp = bias + ((long)(head * QB + wave) * QB * 64 + lane) * 16;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -81,7 +88,9 @@ __global__ __launch_bounds__(QB * 64) void window_attention_kernel(const f16* __
     f32x16 o;
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
+    // finite floor instead of -inf: with the SWIN shift masks a whole 32-key block can be masked for a query, and
+    // exp2(-inf - (-inf)) would be NaN; with the floor such a block contributes exact zeros
+    float m_run = -1e30f, l_run = 0.0f;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(QB * 64) void window_attention_kernel(const f16* __
             mloc = fmaxf(mloc, s[e]);
         }
         mloc = fmaxf(mloc, wa_other_half(mloc));
-        const float m_new = fmaxf(m_run, mloc * WA_LOG2E); // every key block holds at least one real key: finite
+        const float m_new = fmaxf(m_run, mloc * WA_LOG2E);
         if (__any(m_new > m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
@@ -179,7 +188,39 @@ int vx_window_attention_pack_bias(const float* bias, int N, int heads, void* pac
 }
 
 int vx_window_attention_f16(const void* qkv, const void* bias_packed, void* out, int n_windows, int N, int heads, void* stream) {
+    return vx_window_attention_masked_f16(qkv, bias_packed, out, n_windows, N, heads, 0, 0, stream);
+}
+
+// SWIN: relative_position_bias_table [(2 ws - 1)^2][heads] f32 -> four packed images (bias, bias + last-column mask, bias +
+// last-row mask, bias + corner mask) of vx_window_attention_bias_bytes(ws*ws, heads) bytes each. The bias is rounded to f16
+// first, as the reference casts it (swin.cpp:88-92); index = compute_relative_position_index (swin.cpp:26-38).
+int vx_swin_attention_pack_bias(const float* table, int ws, int heads, void* packed_host) {
+    VX_REQUIRE(table && packed_host && ws > 0 && ws <= 16 && heads > 0, "vx_swin_attention_pack_bias: bad operands (window %d)", ws);
+    const int N = ws * ws, shift = ws / 2;
+    const size_t img = vx_window_attention_bias_bytes(N, heads);
+    float* b = new float[(size_t)heads * N * N];
+    for (int cls = 0; cls < 4; ++cls) {
+        for (int i = 0; i < N; ++i)       // query (y1, x1) = slow index of the reference's table, key (y0, x0) = fast index
+            for (int j = 0; j < N; ++j) {
+                const int y1 = i / ws, x1 = i % ws, y0 = j / ws, x0 = j % ws;
+                const int idx = (y1 - y0 + ws - 1) * (2 * ws - 1) + (x1 - x0 + ws - 1);
+                // inside the last window row / column, positions >= ws - shift come from the other side of the image
+                const bool cut_y = (cls & 2) && ((y0 < ws - shift) != (y1 < ws - shift));
+                const bool cut_x = (cls & 1) && ((x0 < ws - shift) != (x1 < ws - shift));
+                for (int h = 0; h < heads; ++h)
+                    b[((size_t)h * N + i) * N + j] = (cut_y || cut_x) ? -INFINITY : (float)(__fp16)table[(size_t)idx * heads + h];
+            }
+        if (!vx_window_attention_pack_bias(b, N, heads, static_cast<unsigned char*>(packed_host) + cls * img)) { delete[] b; return 0; }
+    }
+    delete[] b;
+    return 1;
+}
+
+int vx_window_attention_masked_f16(const void* qkv, const void* bias_packed, void* out, int n_windows, int N, int heads, int nwx, int nwy,
+                                   void* stream) {
     VX_REQUIRE(qkv && bias_packed && out && n_windows > 0 && heads > 0, "vx_window_attention_f16: bad operands");
+    VX_REQUIRE((nwx == 0 && nwy == 0) || (nwx > 0 && nwy > 0 && n_windows % (nwx * nwy) == 0), "vx_window_attention_masked_f16: %d windows are not whole images of %dx%d", n_windows, nwx, nwy);
+    const long cls_stride = (long)(vx_window_attention_bias_bytes(N, heads) / 2);
     const int QB = query_blocks(N);
     VX_REQUIRE(N > 0 && QB > 0, "vx_window_attention_f16: %d tokens per window (at most 256)", N);
     const f16* q = reinterpret_cast<const f16*>(qkv);
@@ -189,11 +230,11 @@ int vx_window_attention_f16(const void* qkv, const void* bias_packed, void* out,
     const float scale = 1.0f / sqrtf((float)WA_HD);
     hipStream_t s = as_stream(stream);
     switch (QB) {
-        case 1: hipLaunchKernelGGL(window_attention_kernel<1>, grid, dim3(64), 0, s, q, b, o, N, heads, scale); break;
-        case 2: hipLaunchKernelGGL(window_attention_kernel<2>, grid, dim3(128), 0, s, q, b, o, N, heads, scale); break;
-        case 4: hipLaunchKernelGGL(window_attention_kernel<4>, grid, dim3(256), 0, s, q, b, o, N, heads, scale); break;
-        case 7: hipLaunchKernelGGL(window_attention_kernel<7>, grid, dim3(448), 0, s, q, b, o, N, heads, scale); break;
-        default: hipLaunchKernelGGL(window_attention_kernel<8>, grid, dim3(512), 0, s, q, b, o, N, heads, scale); break;
+        case 1: hipLaunchKernelGGL(window_attention_kernel<1>, grid, dim3(64), 0, s, q, b, o, N, heads, scale, nwx, nwy, cls_stride); break;
+        case 2: hipLaunchKernelGGL(window_attention_kernel<2>, grid, dim3(128), 0, s, q, b, o, N, heads, scale, nwx, nwy, cls_stride); break;
+        case 4: hipLaunchKernelGGL(window_attention_kernel<4>, grid, dim3(256), 0, s, q, b, o, N, heads, scale, nwx, nwy, cls_stride); break;
+        case 7: hipLaunchKernelGGL(window_attention_kernel<7>, grid, dim3(448), 0, s, q, b, o, N, heads, scale, nwx, nwy, cls_stride); break;
+        default: hipLaunchKernelGGL(window_attention_kernel<8>, grid, dim3(512), 0, s, q, b, o, N, heads, scale, nwx, nwy, cls_stride); break;
     }
     VX_LAUNCH_CHECK();
     return 1;

@@ -121,7 +121,7 @@ class Model:
         return res
 
     def _family_fn(self, name: str):
-        prefix = {Arch.esrgan: "visp_esrgan_", Arch.sam: "visp_sam_"}.get(self.arch, "visp_depthany_")
+        prefix = {Arch.esrgan: "visp_esrgan_", Arch.sam: "visp_sam_", Arch.birefnet: "visp_swin_"}.get(self.arch, "visp_depthany_")
         return getattr(self._api, prefix + name)
 
     # ---- batched extension
@@ -364,3 +364,34 @@ class DeviceBuffer:
         if getattr(self, "ptr", None):
             self._api.vx_free(self.ptr)
             self.ptr = None
+
+
+class SwinEncoder(Model):
+    """The SWIN encoder of a birefnet GGUF (reference swin_encode, src/visp/arch/swin.cpp:237-262, behind birefnet::encode): the
+    BiRefNet decoder is not built in this backend, so the family's Model.load / compute stay refused and the encoder has its
+    own handle (visp_swin_*). Outputs are the four normed stage maps, f32 [B, h_i, w_i, C_i]."""
+
+    @classmethod
+    def load(cls, path, device: Device):
+        api = get_lib()
+        handle = c_void_p()
+        check(api.visp_swin_load(lib.path_to_char_p(path), device._handle, byref(handle)))
+        return cls(api, handle, Arch.birefnet, device)
+
+    def output_dims(self, w: int, h: int):
+        d = (c_int32 * 12)()
+        check(self._api.visp_swin_output_dims(self._handle, w, h, d))
+        return [(d[3 * i], d[3 * i + 1], d[3 * i + 2]) for i in range(4)]  # (w_i, h_i, C_i)
+
+    def encode_batch(self, images: np.ndarray):
+        """images: uint8 [B, h, w, 3] on the host -> list of four f32 arrays [B, h_i, w_i, C_i]."""
+        imgs = np.ascontiguousarray(images, dtype=np.uint8)
+        b, h, w, c = imgs.shape
+        assert c == 3
+        outs = [np.empty((b, hh, ww, cc), np.float32) for ww, hh, cc in self.output_dims(w, h)]
+        ptrs = (c_void_p * 4)(*[o.ctypes.data for o in outs])
+        check(self._api.visp_swin_encode_batch_host(self._handle, imgs.ctypes.data, b, w, h, ptrs))
+        return outs
+
+    def encode_batch_device(self, rgb_dev: int, batch: int, w: int, h: int, outs_dev, stream: int | None = None):
+        check(self._api.visp_swin_encode_batch_device(self._handle, rgb_dev, batch, w, h, (c_void_p * 4)(*outs_dev), stream))
