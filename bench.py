@@ -46,9 +46,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["depthany", "esrgan", "sam"], default="depthany",
+    ap.add_argument("--workload", choices=["depthany", "esrgan", "sam", "swin"], default="depthany",
                     help="depthany = the headline metric (BASELINE.json configs[1]); esrgan = configs[2], the next SURVEY section 8 row")
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 for depthany, 16 for esrgan, 128 for sam)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 for depthany, 16 for esrgan, 128 for sam, 8 for swin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--min-seconds", type=float, default=10.0, help="soak: after the K timed steps keep stepping for this long and report that rate too (0 = skip)")
@@ -88,8 +88,8 @@ def main():
         torch.cuda.synchronize()
 
     api = L.get_lib()
-    if args.workload in ("esrgan", "sam"):
-        (run_esrgan if args.workload == "esrgan" else run_sam)(args, torch, dist, rank, world, device_index, barrier, api)
+    if args.workload in ("esrgan", "sam", "swin"):
+        {"esrgan": run_esrgan, "sam": run_sam, "swin": run_swin}[args.workload](args, torch, dist, rank, world, device_index, barrier, api)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -573,6 +573,119 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
         res["cpu_baseline"] = {"value": round(n / dt, 4), "unit": "images/s", "cores": args.cpu_threads, "kind": "port",
                                "sample": f"{n} image(s) 1024x1024, batch-1 sequential, OpenMP {args.cpu_threads} threads, oracle/libvisp_oracle.so",
                                "mean_abs_diff_gpu_vs_cpu": round(float(e.mean()), 5), "max_abs_diff_gpu_vs_cpu": round(float(e.max()), 4)}
+    print(json.dumps(res), flush=True)
+
+
+def run_swin(args, torch, dist, rank, world, device_index, barrier, api):
+    """A step = birefnet_process_input's normalisation + swin_encode (swin.cpp:237-262: SWIN-T, 1024x1024 -> four normed stage
+    maps) for a batch of synthetic rgb_u8 images resident in HBM: the encoder half of BASELINE.json configs[3] (BiRefNet-lite,
+    batch 64 over 8 GPUs = 8 images per GPU and step; the decoder is not built yet). Ranks take whole images, no collective."""
+    B, S = args.batch or 8, 1024
+    cfg = synth.SWIN_T
+    tmp = Path(tempfile.gettempdir()) / f"visp_bench_swin_t_f16_{os.environ.get('MASTER_PORT', '0')}.gguf"
+    if rank == 0:
+        synth.write_swin_gguf(tmp, cfg, seed=4)
+    barrier()
+    dev = vision.Device.init(index=device_index)
+    model = vision.SwinEncoder.load(tmp, dev)  # 55 MB of weights: every rank reads the file
+    imgs = synth.images(min(B, 2), S, S, seed=77 + 100 * rank)
+    imgs = np.concatenate([imgs] * ((B + len(imgs) - 1) // len(imgs)))[:B]
+    src = torch.from_numpy(imgs).cuda()
+    dims = model.output_dims(S, S)
+    outs = [torch.empty((B, h, w, c), dtype=torch.float32, device="cuda") for (w, h, c) in dims]
+    ptrs = [o.data_ptr() for o in outs]
+    stream = torch.cuda.Stream().cuda_stream
+
+    def step():
+        model.encode_batch_device(src.data_ptr(), B, S, S, ptrs, stream)
+
+    groups = []
+    if rank == 0:
+        step()
+        torch.cuda.synchronize()
+        model.enable_timing(True)
+        step()
+        torch.cuda.synchronize()
+        groups = sorted(model.read_timing(), key=lambda g: -g["ms"])
+        model.enable_timing(False)
+        if args.profile_groups:
+            tot = sum(g["ms"] for g in groups)
+            print(f"{'group':16s} {'ms':>8s} {'%':>6s} {'launch':>6s} {'TFLOP/s':>9s} {'GB/s':>9s}", file=sys.stderr)
+            for g in groups:
+                print(f"{g['name']:16s} {g['ms']:8.3f} {100 * g['ms'] / tot:6.1f} {g['launches']:6d} "
+                      f"{g['flops'] / g['ms'] / 1e9:9.1f} {g['bytes'] / g['ms'] / 1e6:9.1f}", file=sys.stderr)
+            print(f"{'total':16s} {tot:8.3f}", file=sys.stderr)
+    for _ in range(args.warmup):
+        step()
+    ev = StepEvents(api, stream, args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev.mark()
+        step()
+    ev.mark()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    step_ms = ev.step_ms()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    o3 = outs[3].cpu().numpy()
+    assert np.isfinite(o3).all() and o3.std() > 0.1, "invalid output"
+    if rank != 0:
+        return
+    value = world * B * args.steps / elapsed
+    gflop = sum(g["flops"] for g in groups) / B / 1e9 if groups else None
+    res = {
+        "metric": "images/sec, SWIN-T encoder of BiRefNet-lite 1024x1024 f16",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "step_ms_device": {"mean": round(float(np.mean(step_ms)), 3), "std": round(float(np.std(step_ms)), 3), "min": round(float(np.min(step_ms)), 3),
+                           "note": "rank 0, HIP events at the step boundaries of the same timed region"},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"SWIN-T encoder (the backbone of BiRefNet-lite, BASELINE.json configs[3]) 1024x1024 f16, batch={B} per MI355X; "
+                               "encoder only: the BiRefNet decoder is not built in this backend",
+                   "images_per_gpu_per_step": B, "global_batch": world * B, "weights": "random-init synthetic GGUF (seed 4)",
+                   "parallelism": f"dp{world} (image shards, no data-path collective)"},
+        "model_gflop_per_image": round(gflop, 2) if gflop else None,
+        "model_tflops": round(value * gflop / 1e3, 2) if gflop else None,
+    }
+    if groups:
+        tot = sum(g["ms"] for g in groups)
+        dom = groups[0]
+        hbm_bound = dom["flops"] / max(dom["bytes"], 1) < PEAK_MFMA_F16 / PEAK_HBM
+        if hbm_bound:
+            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            res["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                               "frac": round(ach * 1e9 / PEAK_HBM, 4), "traffic": None}
+        else:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
+                               "frac": round(ach * 1e12 / PEAK_MFMA_F16, 4), "traffic": None}
+        res["roofline"]["avg_launch_ms"] = round(dom["ms"] / max(dom["launches"], 1), 4)
+        res["roofline"]["launches_per_step"] = dom["launches"]
+        res["roofline"]["share_of_step"] = round(dom["ms"] / tot, 3)
+        res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+
+        tensors, conv2d = synth.swin_gguf_tensors(synth.swin_state_dict(cfg, 4))
+        om = oracle.Model(tensors, conv2d)
+        P = oracle.swin_params(cfg.embed_dim, cfg.window_size, cfg.depths, cfg.n_heads)
+        oracle.set_num_threads(args.cpu_threads)
+        mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+        n = 2
+        t0 = time.perf_counter()
+        errs = []
+        for i in range(n):
+            want = oracle.swin_encode(om, P, ((imgs[i].astype(np.float32) / 255.0 - mean) / std).astype(np.float32))
+            errs.append(max(float(np.abs(outs[k][i].cpu().numpy() - want[k]).max() / np.abs(want[k]).max()) for k in range(4)))
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(n / dt, 4), "unit": "images/s", "cores": args.cpu_threads, "kind": "port",
+                               "sample": f"{n} images 1024x1024, OpenMP {args.cpu_threads} threads, oracle/libvisp_oracle.so (vo_swin_encode)",
+                               "max_rel_err_gpu_vs_cpu": round(max(errs), 5)}
     print(json.dumps(res), flush=True)
 
 

@@ -8,39 +8,48 @@
 //  * swin_merge_ln_kernel    patch_merging's 2x2 gather + LayerNorm(4C) (swin.cpp:140-161), input of the reduction GEMM.
 //  * swin_window_reverse_add window_reverse + roll(+shift) + crop + shortcut add.
 //
-// One wave per row, a lane holds up to NCH chunks of 8 channels (16-byte loads), statistics by wave reduction, two-pass
-// (mean, then centred variance) in registers as ggml_norm does (nn.cpp:14-19).
+// 16, 32 or 64 lanes per row (narrow rows share a wave), a lane holds up to NCH chunks of 8 channels (16-byte loads), statistics by
+// sub-wave reduction, two-pass (mean, then centred variance) in registers as ggml_norm does (nn.cpp:14-19).
 #include "vx_common.h"
 
 namespace {
 
 inline unsigned blocks_for(long items, int per_block = 256) { return (unsigned)((items + per_block - 1) / per_block); }
 
-// LayerNorm of one row held as v[NCH][8] (chunk c of lane l covers channels 8 (l + 64 c) .. +7; chunks beyond C hold zeros)
-template <int NCH>
+// sum over the LPR lanes that share a row (LPR = 16, 32 or 64 consecutive lanes)
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// LayerNorm of one row held by LPR lanes as v[NCH][8] (chunk c of row-lane l covers channels 8 (l + LPR c) .. +7; chunks beyond C
+// hold zeros). Narrow rows share a wave: 64 / LPR rows per wave, so that C = 96 keeps 12 of 16 lanes busy instead of 12 of 64.
+template <int LPR, int NCH>
 __device__ __forceinline__ void ln_row_store(float (&v)[NCH][8], int C, const float* __restrict__ w, const float* __restrict__ b, float eps, void* yrow,
-                                             int out_f32, int lane) {
+                                             int out_f32, int lane, bool store) {
     float s = 0.0f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += v[c][j];
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = row_sum<LPR>(s) / (float)C;
     float q = 0.0f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const bool live = (lane + 64 * c) * 8 < C;
+        const bool live = (lane + LPR * c) * 8 < C;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             v[c][j] = live ? v[c][j] - mean : 0.0f;
             q += v[c][j] * v[c][j];
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    const float rstd = 1.0f / sqrtf(row_sum<LPR>(q) / (float)C + eps);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int ch = (lane + 64 * c) * 8;
-        if (ch >= C) continue;
+        const int ch = (lane + LPR * c) * 8;
+        if (ch >= C || !store) continue;
         const float4 w0 = *reinterpret_cast<const float4*>(w + ch), w1 = *reinterpret_cast<const float4*>(w + ch + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(b + ch), b1 = *reinterpret_cast<const float4*>(b + ch + 4);
         const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
@@ -60,12 +69,14 @@ __device__ __forceinline__ void ln_row_store(float (&v)[NCH][8], int C, const fl
     }
 }
 
-template <int NCH>
+template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void swin_ln_rows_kernel(const f16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, void* y,
                                                            long rows_out, int C, float eps, int H, int W, int ws, int shift, int out_f32) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows_out) return;
+    constexpr int RPB = 256 / LPR; // rows per block
+    const int lane = threadIdx.x % LPR;
+    long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live_row = row < rows_out; // dead rows of the last wave still take part in the shuffles
+    if (!live_row) row = rows_out - 1;
     long src = row;
     if (ws > 0) { // window token -> source pixel of the padded, rolled map (swin.cpp:128-139)
         const int N = ws * ws, nwx = (W + ws - 1) / ws, nwy = (H + ws - 1) / ws, wp = nwx * ws, hp = nwy * ws;
@@ -79,33 +90,38 @@ __global__ __launch_bounds__(256) void swin_ln_rows_kernel(const f16* __restrict
         src = (sy < H && sx < W) ? (img * H + sy) * W + sx : -1;
     }
     void* yrow = out_f32 ? static_cast<void*>(static_cast<float*>(y) + row * C) : static_cast<void*>(static_cast<f16*>(y) + row * C);
-    if (src < 0) { // padding: zeros, not a normalised zero row (the reference pads AFTER norm1)
+    const bool pad_row = src < 0;
+    if (pad_row) { // padding: zeros, not a normalised zero row (the reference pads AFTER norm1)
+        if (live_row) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int ch = (lane + 64 * c) * 8;
-            if (ch < C) *reinterpret_cast<uint4*>(static_cast<f16*>(yrow) + ch) = make_uint4(0, 0, 0, 0);
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = (lane + LPR * c) * 8;
+                if (ch < C) *reinterpret_cast<uint4*>(static_cast<f16*>(yrow) + ch) = make_uint4(0, 0, 0, 0);
+            }
         }
-        return;
+        src = 0; // keep the lanes in the shuffles below; nothing is stored
     }
     float v[NCH][8];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int ch = (lane + 64 * c) * 8;
+        const int ch = (lane + LPR * c) * 8;
         f16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
         if (ch < C) t = *reinterpret_cast<const f16x8*>(x + src * C + ch);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[c][j] = (float)t[j];
     }
-    ln_row_store<NCH>(v, C, w, b, eps, yrow, out_f32, lane);
+    ln_row_store<LPR, NCH>(v, C, w, b, eps, yrow, out_f32, lane, live_row && !pad_row);
 }
 
 // output row (img, oy, ox) = LayerNorm over [x(2oy,2ox) | x(2oy+1,2ox) | x(2oy,2ox+1) | x(2oy+1,2ox+1)], 4C channels
-template <int NCH>
+template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void swin_merge_ln_kernel(const f16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                             f16* __restrict__ y, long rows_out, int C, float eps, int H, int W) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows_out) return;
+    constexpr int RPB = 256 / LPR;
+    const int lane = threadIdx.x % LPR;
+    long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live_row = row < rows_out;
+    if (!live_row) row = rows_out - 1;
     const int ow = W / 2, oh = H / 2;
     const long img = row / ((long)ow * oh);
     const int t = (int)(row - img * ow * oh), oy = t / ow, ox = t - oy * ow;
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(256) void swin_merge_ln_kernel(const f16* __restric
     float v[NCH][8];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int ch = (lane + 64 * c) * 8;
+        const int ch = (lane + LPR * c) * 8;
         f16x8 tv = {0, 0, 0, 0, 0, 0, 0, 0};
         if (ch < C4) {
             const int part = ch / C, cc = ch - part * C; // C % 8 == 0: a chunk never straddles two parts
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(256) void swin_merge_ln_kernel(const f16* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[c][j] = (float)tv[j];
     }
-    ln_row_store<NCH>(v, C4, w, b, eps, y + row * C4, 0, lane);
+    ln_row_store<LPR, NCH>(v, C4, w, b, eps, y + row * C4, 0, lane, live_row);
 }
 
 // y[img, sy, sx, :] = x[img, sy, sx, :] + a[window row of the padded position that the roll mapped to (sy, sx), :]
@@ -163,10 +179,13 @@ int vx_swin_layernorm_f16(const void* x, const float* w, const float* b, void* y
     const f16* xp = reinterpret_cast<const f16*>(x);
     const long rows = (long)rows_out;
     hipStream_t s = as_stream(stream);
-    const dim3 grid(blocks_for(rows, 4));
-    if (C <= 512) hipLaunchKernelGGL(swin_ln_rows_kernel<1>, grid, dim3(256), 0, s, xp, w, b, y, rows, C, eps, H, W, ws, shift, out_f32);
-    else if (C <= 1024) hipLaunchKernelGGL(swin_ln_rows_kernel<2>, grid, dim3(256), 0, s, xp, w, b, y, rows, C, eps, H, W, ws, shift, out_f32);
-    else hipLaunchKernelGGL(swin_ln_rows_kernel<4>, grid, dim3(256), 0, s, xp, w, b, y, rows, C, eps, H, W, ws, shift, out_f32);
+#define LN_LAUNCH(LPR, NCH) hipLaunchKernelGGL((swin_ln_rows_kernel<LPR, NCH>), dim3(blocks_for(rows, 256 / LPR)), dim3(256), 0, s, xp, w, b, y, rows, C, eps, H, W, ws, shift, out_f32)
+    if (C <= 128) LN_LAUNCH(16, 1);
+    else if (C <= 256) LN_LAUNCH(32, 1);
+    else if (C <= 512) LN_LAUNCH(64, 1);
+    else if (C <= 1024) LN_LAUNCH(64, 2);
+    else LN_LAUNCH(64, 4);
+#undef LN_LAUNCH
     VX_LAUNCH_CHECK();
     return 1;
 }
@@ -178,11 +197,14 @@ int vx_swin_merge_layernorm_f16(const void* x, const float* w, const float* b, v
     const f16* xp = reinterpret_cast<const f16*>(x);
     f16* yp = reinterpret_cast<f16*>(y);
     hipStream_t s = as_stream(stream);
-    const dim3 grid(blocks_for(rows, 4));
-    if (4 * C <= 512) hipLaunchKernelGGL(swin_merge_ln_kernel<1>, grid, dim3(256), 0, s, xp, w, b, yp, rows, C, eps, H, W);
-    else if (4 * C <= 1024) hipLaunchKernelGGL(swin_merge_ln_kernel<2>, grid, dim3(256), 0, s, xp, w, b, yp, rows, C, eps, H, W);
-    else if (4 * C <= 2048) hipLaunchKernelGGL(swin_merge_ln_kernel<4>, grid, dim3(256), 0, s, xp, w, b, yp, rows, C, eps, H, W);
-    else hipLaunchKernelGGL(swin_merge_ln_kernel<8>, grid, dim3(256), 0, s, xp, w, b, yp, rows, C, eps, H, W);
+#define MG_LAUNCH(LPR, NCH) hipLaunchKernelGGL((swin_merge_ln_kernel<LPR, NCH>), dim3(blocks_for(rows, 256 / LPR)), dim3(256), 0, s, xp, w, b, yp, rows, C, eps, H, W)
+    if (4 * C <= 128) MG_LAUNCH(16, 1);
+    else if (4 * C <= 256) MG_LAUNCH(32, 1);
+    else if (4 * C <= 512) MG_LAUNCH(64, 1);
+    else if (4 * C <= 1024) MG_LAUNCH(64, 2);
+    else if (4 * C <= 2048) MG_LAUNCH(64, 4);
+    else MG_LAUNCH(64, 8);
+#undef MG_LAUNCH
     VX_LAUNCH_CHECK();
     return 1;
 }
