@@ -113,6 +113,9 @@ typedef struct {
      * mobile-sam.cpp:25-46); out and res1/res2 are addressed at the PIXEL row of each window row, padded rows are dropped:
      * window_reverse + residual add fused (mobile-sam.cpp:48-64, 146-149) */
     int post_gelu, win_ws, win_res;
+    /* SWIN (swin.cpp:141-156): win_res_h > 0 makes the map win_res (width) x win_res_h (height); win_shift > 0 undoes the cyclic
+     * shift as well (window row -> padded position -> + shift modulo the padded extent -> pixel, dropped if outside the map) */
+    int win_res_h, win_shift;
     void* debug_stamps; /* diagnostics only: u64 [blocks][8] s_memtime stamps per phase, NULL in product */
 } vx_gemm_args;
 

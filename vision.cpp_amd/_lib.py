@@ -65,7 +65,7 @@ class GemmArgs(ctypes.Structure):  # == vx_gemm_args
         ("q_scale", c_float),
         ("ps_s", c_int), ("ps_Cout", c_int), ("ps_H", c_int), ("ps_W", c_int),
         ("res1", c_void_p), ("res2", c_void_p), ("n_valid", c_int), ("stages", c_int), ("head_bias", c_float), ("head_scale", c_float),
-        ("post_gelu", c_int), ("win_ws", c_int), ("win_res", c_int), ("debug_stamps", c_void_p),
+        ("post_gelu", c_int), ("win_ws", c_int), ("win_res", c_int), ("win_res_h", c_int), ("win_shift", c_int), ("debug_stamps", c_void_p),
     ]
 
 

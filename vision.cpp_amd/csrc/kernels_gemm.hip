@@ -97,14 +97,17 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
             const int m = m0 + tid;
             int pix = -1;
             if (m < p.M) {
-                const int ws = p.win_ws, res = p.win_res, nw = (res + ws - 1) / ws, N = ws * ws;
+                const int ws = p.win_ws, rw = p.win_res, rh = p.win_res_h > 0 ? p.win_res_h : p.win_res, N = ws * ws;
+                const int nwx = (rw + ws - 1) / ws, nwy = (rh + ws - 1) / ws;
                 const int in = m % N;
                 int wq = m / N;
-                const int wx = wq % nw;
-                wq /= nw;
-                const int wy = wq % nw, bb = wq / nw;
-                const int py = wy * ws + in / ws, px = wx * ws + in % ws;
-                if (py < res && px < res) pix = (bb * res + py) * res + px;
+                const int wx = wq % nwx;
+                wq /= nwx;
+                const int wy = wq % nwy, bb = wq / nwy;
+                int py = wy * ws + in / ws + p.win_shift, px = wx * ws + in % ws + p.win_shift; // roll(+shift) of the padded map
+                if (py >= nwy * ws) py -= nwy * ws;
+                if (px >= nwx * ws) px -= nwx * ws;
+                if (py < rh && px < rw) pix = (bb * rh + py) * rw + px;
             }
             s_pix[tid] = pix;
         }
@@ -523,8 +526,9 @@ extern "C" int vx_gemm_f16(const vx_gemm_args* args, void* stream) {
     if (a.post_gelu) VX_REQUIRE(a.epi == VX_EPI_F16_ADD && a.res1 && !a.res2, "vx_gemm_f16: post_gelu needs the F16_ADD epilogue with exactly one residual");
     if (a.win_ws > 0) {
         VX_REQUIRE(a.epi == VX_EPI_F16_ADD && a.conv_kh == 0 && a.win_res > 0, "vx_gemm_f16: window-order output needs the plain F16_ADD form");
-        const long nw = (a.win_res + a.win_ws - 1) / a.win_ws;
-        VX_REQUIRE(a.M % (nw * nw * a.win_ws * a.win_ws) == 0, "vx_gemm_f16: M=%d is not a whole number of %ld x %ld window maps", a.M, nw, nw);
+        const long nw = (a.win_res + a.win_ws - 1) / a.win_ws, nwh = ((a.win_res_h > 0 ? a.win_res_h : a.win_res) + a.win_ws - 1) / a.win_ws;
+        VX_REQUIRE(a.M % (nw * nwh * a.win_ws * a.win_ws) == 0, "vx_gemm_f16: M=%d is not a whole number of %ld x %ld window maps", a.M, nw, nwh);
+        VX_REQUIRE(a.win_shift >= 0 && a.win_shift < a.win_ws && a.win_res_h >= 0, "vx_gemm_f16: bad window shift / height");
     }
     if (a.epi == VX_EPI_HEAD_OUT) VX_REQUIRE(a.N == 32 && a.lambda, "vx_gemm_f16: head epilogue needs N == 32 and conv3 weights");
     if (a.conv_kh > 0) {

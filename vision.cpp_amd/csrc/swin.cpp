@@ -175,13 +175,16 @@ struct swin_exec {
         for (auto& mk : marks) vx_event_destroy(mk.second);
         marks.clear();
     }
-    void gemm(packed_gemm const& g, const void* A, long M, int lda, void* out, int epi, const void* res1, const char* group) {
+    // win_ws > 0: rows are window tokens of a win_w x win_h map rolled by win_shift; out / res1 are addressed at their pixels
+    void gemm(packed_gemm const& g, const void* A, long M, int lda, void* out, int epi, const void* res1, const char* group, int win_ws = 0,
+              int win_w = 0, int win_h = 0, int win_shift = 0) {
         vx_gemm_args a;
         memset(&a, 0, sizeof a);
         a.A = A; a.lda = lda;
         a.W = wa + g.w; a.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b);
         a.M = (int)M; a.N = g.N; a.K = g.K; a.n_valid = g.n_real;
         a.epi = epi; a.out = out; a.ldo = g.n_real; a.res1 = res1;
+        a.win_ws = win_ws; a.win_res = win_w; a.win_res_h = win_h; a.win_shift = win_shift;
         mark(group, 2.0 * M * g.n_real * g.k_real, (double)M * (g.k_real + g.n_real) * 2);
         VX(vx_gemm_f16(&a, stream));
     }
@@ -275,9 +278,9 @@ void swin_encode_batch_device(swin_model& m, void const* rgb_dev, int B, int w, 
             ex.gemm(b.qkv, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_qkv");
             ex.mark("window_attention", 4.0 * rows * N * C, (double)rows * C * 8);
             VX(vx_window_attention_masked_f16(t2, ex.wa + b.bias.off, t1, (int)(rows / N), N, L.n_heads, shift ? nwx : 0, shift ? nwy : 0, s));
-            ex.gemm(b.proj, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_proj");
-            ex.mark("window_reverse", 0, (double)(rows + 2 * T) * C * 2);
-            VX(vx_swin_window_reverse_add_f16(t2, x, t3, B, ch, cw, C, ws, shift, s));
+            // proj + window_reverse + roll(+shift) + crop + shortcut: window rows are scattered to their pixels by the GEMM epilogue
+            // (vx_swin_window_reverse_add_f16 is the unfused form, kept for the kernel-level parity test)
+            ex.gemm(b.proj, t1, rows, C, t3, VX_EPI_F16_ADD, x, "gemm_proj", ws, cw, ch, shift);
             ex.mark("layernorm", 0, (double)T * C * 4);
             VX(vx_swin_layernorm_f16(t3, ex.fptr(b.norm2_w), ex.fptr(b.norm2_b), t1, T, C, 1e-5f, 0, 0, 0, 0, 0, s));
             ex.gemm(b.fc1, t1, T, C, t2, VX_EPI_F16_GELU, nullptr, "gemm_fc1");
