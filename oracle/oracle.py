@@ -619,3 +619,68 @@ def swin_encode(model: "Model", params: SwinParams, image: np.ndarray, prefix: s
     if captures is None:
         return res
     return res, {k: bufs[k][: carr[i].written].copy() for i, k in enumerate(caps)}
+
+
+# ---- BiRefNet (reference src/visp/arch/birefnet.cpp); the deformable convolution is parity-unpinned (see visp_oracle.c) ----
+
+def _bf_lib():
+    L = _swin_lib()
+    if not getattr(L, "_bf_ready", False):
+        fp = C.POINTER(C.c_float)
+        L.vo_deform_conv2d_nhwc.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, fp]
+        L.vo_birefnet_encode.argtypes = [C.c_void_p, C.POINTER(SwinParams), fp, C.c_int, C.c_int, fp * 4, (C.c_int * 3) * 4]
+        L.vo_birefnet_predict.argtypes = [C.c_void_p, C.POINTER(SwinParams), fp, C.c_int, C.c_int, fp, C.POINTER(Capture), C.c_int]
+        L.vo_image_to_patches.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L._bf_ready = True
+    return L
+
+
+def deform_conv2d_nhwc(x, w, offset, mask=None, stride=1, pad=0):
+    """x [H, W, Cin], w [Cout, kh, kw, Cin], offset [OH, OW, 2*kh*kw] (dy, dx per tap), mask [OH, OW, kh*kw] -> [OH, OW, Cout]."""
+    x, w, offset = _f32(x), _f32(w), _f32(offset)
+    mask = _f32(mask) if mask is not None else None
+    H, W, Cin = x.shape
+    Cout, kh, kw, _ = w.shape
+    OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = np.empty((OH, OW, Cout), np.float32)
+    _bf_lib().vo_deform_conv2d_nhwc(_fp(x), H, W, Cin, _fp(w), Cout, kh, kw, _fp(offset), _fp(mask), stride, pad, _fp(y))
+    return y
+
+
+def birefnet_encode(model: "Model", params: SwinParams, image: np.ndarray):
+    """normalised rgb f32 [H, W, 3] -> the four concatenated encoder features [h_i, w_i, C_i] (birefnet.cpp:43-73)."""
+    img = _f32(image)
+    H, W = img.shape[:2]
+    fp = C.POINTER(C.c_float)
+    outs, dims = (fp * 4)(), ((C.c_int * 3) * 4)()
+    _check(_bf_lib().vo_birefnet_encode(model._h, C.byref(params), _fp(img), W, H, outs, dims))
+    res = []
+    for i in range(4):
+        w, h, c = dims[i][0], dims[i][1], dims[i][2]
+        res.append(np.ctypeslib.as_array(outs[i], shape=(h * w * c,)).reshape(h, w, c).copy())
+        _bf_lib().vo_free(outs[i])
+    return res
+
+
+def birefnet_predict(model: "Model", params: SwinParams, image: np.ndarray, captures: dict[str, int] | None = None):
+    """normalised rgb f32 [H, W, 3] -> sigmoid mask [H, W] (birefnet_predict, birefnet.cpp:252-260)."""
+    img = _f32(image)
+    H, W = img.shape[:2]
+    out = np.empty((H, W), np.float32)
+    caps = captures or {}
+    bufs = {k: np.empty(n, np.float32) for k, n in caps.items()}
+    names = [k.encode() for k in caps]
+    carr = (Capture * max(1, len(caps)))(*[Capture(nm, _fp(bufs[k]), bufs[k].size, 0) for nm, k in zip(names, caps)])
+    _check(_bf_lib().vo_birefnet_predict(model._h, C.byref(params), _fp(img), W, H, _fp(out), carr, len(caps)))
+    if captures is None:
+        return out
+    return out, {k: bufs[k][: carr[i].written].copy() for i, k in enumerate(caps)}
+
+
+def image_to_patches(image: np.ndarray, w: int, h: int) -> np.ndarray:
+    """[IH, IW, C] -> [h, w, gw*gh*C] (birefnet.cpp:158-167)."""
+    img = _f32(image)
+    IH, IW, Cc = img.shape
+    out = np.empty((h, w, (IW // w) * (IH // h) * Cc), np.float32)
+    _bf_lib().vo_image_to_patches(_fp(img), IW, IH, Cc, w, h, _fp(out))
+    return out

@@ -2250,3 +2250,345 @@ int vo_swin_encode(const vo_model* m, const char* prefix, const vo_swin_params* 
     return ok;
 }
 void vo_free(void* p) { free(p); }
+
+/* ==== BiRefNet: two-scale SWIN encode, squeeze block, decoder ===============================
+ * Restates reference src/visp/arch/birefnet.cpp. Tensor names as scripts/convert.py:358-419 writes them (BatchNorm fused into
+ * conv_in / conv_out / dec_att.conv1 / global_avg_pool.1 / gdt_convs_N.0 biases, the ASPP branch norms fused to bn.weight /
+ * bn.bias, decoder_block -> block, atrous_conv / regular_conv -> conv, offset_conv -> offset, modulator_conv -> modulator).
+ *
+ * PARITY UNPINNED for the deformable convolution: the reference maps it to ggml_conv_2d_deform (a fork-only ggml op, absent
+ * here) and tests it against torchvision.ops.deform_conv2d (tests/test_birefnet.py:767-795), which is not importable here
+ * either. vo_deform_conv2d_nhwc restates torchvision's published algorithm (deform_conv2d_kernel.cpp: bilinear_interpolate with
+ * zero padding, offsets stored as (dy, dx) pairs per kernel tap, modulation mask per tap). */
+
+/* torchvision bilinear_interpolate: zero outside (-1, H) x (-1, W), corners outside the map contribute zero */
+static inline void deform_sample(const float* x, int H, int W, int C, float h, float w, float scale, float* dst) {
+    if (h <= -1.0f || (float)H <= h || w <= -1.0f || (float)W <= w) { for (int c = 0; c < C; ++c) dst[c] = 0.0f; return; }
+    const int h_low = (int)floorf(h), w_low = (int)floorf(w), h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h - (float)h_low, lw = w - (float)w_low, hh = 1.0f - lh, hw = 1.0f - lw;
+    const float* v1 = (h_low >= 0 && w_low >= 0) ? x + ((int64_t)h_low * W + w_low) * C : NULL;
+    const float* v2 = (h_low >= 0 && w_high <= W - 1) ? x + ((int64_t)h_low * W + w_high) * C : NULL;
+    const float* v3 = (h_high <= H - 1 && w_low >= 0) ? x + ((int64_t)h_high * W + w_low) * C : NULL;
+    const float* v4 = (h_high <= H - 1 && w_high <= W - 1) ? x + ((int64_t)h_high * W + w_high) * C : NULL;
+    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+    for (int c = 0; c < C; ++c) {
+        float v = w1 * (v1 ? v1[c] : 0.0f) + w2 * (v2 ? v2[c] : 0.0f) + w3 * (v3 ? v3[c] : 0.0f) + w4 * (v4 ? v4[c] : 0.0f);
+        dst[c] = v * scale;
+    }
+}
+
+/* deform_conv2d (dilation 1, one offset group): x [H][W][Cin], w [Cout][kh][kw][Cin], offset [OH][OW][2*kh*kw] (dy, dx per tap,
+ * tap = ky*kw + kx), mask [OH][OW][kh*kw] or NULL, y [OH][OW][Cout] */
+void vo_deform_conv2d_nhwc(const float* x, int H, int W, int Cin, const float* w, int Cout, int kh, int kw, const float* offset,
+                           const float* mask, int stride, int pad, float* y) {
+    const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1, taps = kh * kw;
+    const int64_t K = (int64_t)taps * Cin, M = (int64_t)OH * OW;
+    float* cols = (float*)malloc((size_t)M * K * 4);
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < M; ++p) {
+        const int oy = (int)(p / OW), ox = (int)(p % OW);
+        for (int t = 0; t < taps; ++t) {
+            const int ky = t / kw, kx = t % kw;
+            const float dy = offset[(p * taps + t) * 2], dx = offset[(p * taps + t) * 2 + 1];
+            const float sc = mask ? mask[p * taps + t] : 1.0f;
+            deform_sample(x, H, W, Cin, (float)(oy * stride - pad + ky) + dy, (float)(ox * stride - pad + kx) + dx, sc, cols + p * K + (int64_t)t * Cin);
+        }
+    }
+    float* wt = transpose_new(w, Cout, K);
+    gemm_nn(cols, K, wt, Cout, y, Cout, M, K, Cout, NULL);
+    free(wt); free(cols);
+}
+
+static void relu_inplace(float* x, int64_t n) { for (int64_t i = 0; i < n; ++i) x[i] = x[i] > 0.0f ? x[i] : 0.0f; }
+static void sigmoid_inplace(float* x, int64_t n, float scale) { for (int64_t i = 0; i < n; ++i) x[i] = scale / (1.0f + expf(-x[i])); }
+
+/* concat along channels of maps with the same [H][W]: parts[i] has cs[i] channels; result malloc'd */
+static float* concat_channels(const float* const* parts, const int* cs, int n, int64_t pixels, int* ctot) {
+    int C = 0;
+    for (int i = 0; i < n; ++i) C += cs[i];
+    float* out = (float*)malloc((size_t)pixels * C * 4);
+    for (int64_t p = 0; p < pixels; ++p) {
+        float* d = out + p * C;
+        for (int i = 0; i < n; ++i) { memcpy(d, parts[i] + p * cs[i], (size_t)cs[i] * 4); d += cs[i]; }
+    }
+    *ctot = C;
+    return out;
+}
+static float* resize_ac(const float* x, int H, int W, int C, int OH, int OW) { /* bilinear, align_corners (birefnet.cpp:17-41) */
+    float* y = (float*)malloc((size_t)OH * OW * C * 4);
+    vo_interpolate_bilinear_nhwc(x, 1, H, W, C, OH, OW, 1, y);
+    return y;
+}
+
+/* deformable_conv_2d (birefnet.cpp:83-92) */
+static int bf_deformable_conv(const vo_model* m, const char* prefix, const float* x, int H, int Wd, int C, int pad, int* Cout, float** y) {
+    char p[200];
+    float *off = NULL, *mod = NULL;
+    int oh, ow, co, cm;
+    snprintf(p, sizeof p, "%s.offset", prefix);
+    if (!conv_m(m, p, x, 1, H, Wd, C, 1, pad, &oh, &ow, &co, &off)) return 0;
+    snprintf(p, sizeof p, "%s.modulator", prefix);
+    if (!conv_m(m, p, x, 1, H, Wd, C, 1, pad, &oh, &ow, &cm, &mod)) { free(off); return 0; }
+    sigmoid_inplace(mod, (int64_t)oh * ow * cm, 2.0f);
+    int64_t ne[4];
+    const float* w = W(m, prefix, "conv.weight", ne, 1); /* cwhn: [Cin, kw, kh, Cout] */
+    if (!w) { free(off); free(mod); return 0; }
+    const int kw = (int)ne[1], kh = (int)ne[2];
+    if (ne[0] != C || co != 2 * kh * kw || cm != kh * kw) { free(off); free(mod); VO_FAIL("%s: deformable conv shapes do not match (cin %lld vs %d, offsets %d, modulator %d, kernel %dx%d)", prefix, (long long)ne[0], C, co, cm, kw, kh); }
+    *Cout = (int)ne[3];
+    *y = (float*)malloc((size_t)oh * ow * *Cout * 4);
+    vo_deform_conv2d_nhwc(x, H, Wd, C, w, *Cout, kh, kw, off, mod, 1, pad, *y);
+    free(off); free(mod);
+    return 1;
+}
+
+/* aspp_module_deformable (birefnet.cpp:110-115): deformable conv, fused batch norm (mul + add), relu */
+static int bf_aspp_module(const vo_model* m, const char* prefix, const float* x, int H, int Wd, int C, int pad, int* Cout, float** y) {
+    char p[200];
+    snprintf(p, sizeof p, "%s.conv", prefix);
+    if (!bf_deformable_conv(m, p, x, H, Wd, C, pad, Cout, y)) return 0;
+    snprintf(p, sizeof p, "%s.bn", prefix);
+    const float* bw = W(m, p, "weight", NULL, 1);
+    const float* bb = W(m, p, "bias", NULL, 1);
+    if (!bw || !bb) { free(*y); return 0; }
+    for (int64_t i = 0; i < (int64_t)H * Wd; ++i)
+        for (int c = 0; c < *Cout; ++c) {
+            float v = (*y)[i * *Cout + c] * bw[c];
+            v = v + bb[c];
+            (*y)[i * *Cout + c] = v > 0.0f ? v : 0.0f;
+        }
+    return 1;
+}
+
+/* aspp_deformable (birefnet.cpp:117-142) */
+static int bf_aspp_deformable(const vo_model* m, const char* prefix, const float* x, int H, int W, int C, int* Cout, float** y) {
+    char p[200];
+    float* parts[5] = {NULL, NULL, NULL, NULL, NULL};
+    int cs[5] = {0, 0, 0, 0, 0};
+    const int ks[3] = {1, 3, 7};
+    int ok = 1;
+    snprintf(p, sizeof p, "%s.aspp1", prefix);
+    ok = bf_aspp_module(m, p, x, H, W, C, 0, &cs[0], &parts[0]);
+    for (int i = 0; i < 3 && ok; ++i) {
+        snprintf(p, sizeof p, "%s.aspp_deforms.%d", prefix, i);
+        ok = bf_aspp_module(m, p, x, H, W, C, ks[i] / 2, &cs[1 + i], &parts[1 + i]);
+    }
+    if (ok) { /* global_avg_pool (birefnet.cpp:94-108): mean over pixels, 1x1 conv (+ fused BN), relu, broadcast back */
+        float* mean = (float*)calloc((size_t)C, 4);
+        for (int c = 0; c < C; ++c) {
+            double s = 0.0;
+            for (int64_t i = 0; i < (int64_t)H * W; ++i) s += (double)x[i * C + c];
+            mean[c] = (float)(s / (double)((int64_t)H * W));
+        }
+        float* g = NULL;
+        int oh, ow;
+        snprintf(p, sizeof p, "%s.global_avg_pool.1", prefix);
+        ok = conv_m(m, p, mean, 1, 1, 1, C, 1, 0, &oh, &ow, &cs[4], &g);
+        free(mean);
+        if (ok) {
+            relu_inplace(g, cs[4]);
+            parts[4] = (float*)malloc((size_t)H * W * cs[4] * 4);
+            for (int64_t i = 0; i < (int64_t)H * W; ++i) memcpy(parts[4] + i * cs[4], g, (size_t)cs[4] * 4);
+            free(g);
+        }
+    }
+    if (ok) {
+        int ct;
+        float* cat = concat_channels((const float* const*)parts, cs, 5, (int64_t)H * W, &ct);
+        int oh, ow;
+        snprintf(p, sizeof p, "%s.conv1", prefix);
+        ok = conv_m(m, p, cat, 1, H, W, ct, 1, 0, &oh, &ow, Cout, y);
+        free(cat);
+        if (ok) relu_inplace(*y, (int64_t)H * W * *Cout);
+    }
+    for (int i = 0; i < 5; ++i) free(parts[i]);
+    return ok;
+}
+
+/* basic_decoder_block (birefnet.cpp:144-150) */
+static int bf_decoder_block(const vo_model* m, const char* prefix, const float* x, int H, int W, int C, int* Cout, float** y) {
+    char p[200];
+    float *a = NULL, *b = NULL;
+    int oh, ow, ci, ca;
+    snprintf(p, sizeof p, "%s.conv_in", prefix);
+    if (!conv_m(m, p, x, 1, H, W, C, 1, 1, &oh, &ow, &ci, &a)) return 0;
+    relu_inplace(a, (int64_t)H * W * ci);
+    snprintf(p, sizeof p, "%s.dec_att", prefix);
+    int ok = bf_aspp_deformable(m, p, a, H, W, ci, &ca, &b);
+    free(a);
+    if (!ok) return 0;
+    snprintf(p, sizeof p, "%s.conv_out", prefix);
+    ok = conv_m(m, p, b, 1, H, W, ca, 1, 1, &oh, &ow, Cout, y);
+    free(b);
+    return ok;
+}
+
+/* simple_conv (birefnet.cpp:152-156) on image_to_patches(image, w, h) (birefnet.cpp:158-167): channel = gw + grid_w (gh + grid_h c) */
+void vo_image_to_patches(const float* image, int IW, int IH, int C, int w, int h, float* patches /*[h][w][gw*gh*C]*/) {
+    const int gw = IW / w, gh = IH / h, CP = gw * gh * C;
+    for (int py = 0; py < h; ++py)
+        for (int px = 0; px < w; ++px)
+            for (int c = 0; c < C; ++c)
+                for (int iy = 0; iy < gh; ++iy)
+                    for (int ix = 0; ix < gw; ++ix)
+                        patches[((int64_t)py * w + px) * CP + ix + gw * (iy + gh * c)] = image[((int64_t)(iy * h + py) * IW + ix * w + px) * C + c];
+}
+static int bf_ipt_block(const vo_model* m, const char* prefix, const float* image, int IW, int IH, int w, int h, int* Cout, float** y) {
+    char p[200];
+    if (IW % w || IH % h) VO_FAIL("%s: grid %dx%d does not divide the image %dx%d", prefix, w, h, IW, IH);
+    const int gw = IW / w, gh = IH / h, C = gw * gh * 3;
+    float* patches = (float*)malloc((size_t)w * h * C * 4);
+    vo_image_to_patches(image, IW, IH, 3, w, h, patches);
+    float *a = NULL;
+    int oh, ow, ci;
+    snprintf(p, sizeof p, "%s.conv1", prefix);
+    int ok = conv_m(m, p, patches, 1, h, w, C, 1, 1, &oh, &ow, &ci, &a);
+    free(patches);
+    if (!ok) return 0;
+    snprintf(p, sizeof p, "%s.conv_out", prefix);
+    ok = conv_m(m, p, a, 1, h, w, ci, 1, 1, &oh, &ow, Cout, y);
+    free(a);
+    return ok;
+}
+
+/* one decoder level (birefnet.cpp:176-194 and its repeats): concat(x, ipt(image)), decoder block, gdt attention (levels 4..2) */
+static int bf_level(const vo_model* m, const char* prefix, int level, float* x, int w, int h, int C, const float* image, int IW, int IH,
+                    int gdt, int* Cout, float** y) {
+    char p[200];
+    float* ipt = NULL;
+    int ci, ct;
+    snprintf(p, sizeof p, "%s.ipt_blk%d", prefix, level + 1);
+    if (!bf_ipt_block(m, p, image, IW, IH, w, h, &ci, &ipt)) return 0;
+    const float* parts[2] = {x, ipt};
+    const int cs[2] = {C, ci};
+    float* cat = concat_channels(parts, cs, 2, (int64_t)w * h, &ct);
+    free(ipt);
+    snprintf(p, sizeof p, "%s.block%d", prefix, level);
+    int ok = bf_decoder_block(m, p, cat, h, w, ct, Cout, y);
+    free(cat);
+    if (!ok || !gdt) return ok;
+    float *g = NULL, *a = NULL;
+    int oh, ow, cg, c1;
+    snprintf(p, sizeof p, "%s.gdt_convs_%d.0", prefix, level); /* gdt_conv: conv 3x3 (+ fused BN), relu */
+    if (!conv_m(m, p, *y, 1, h, w, *Cout, 1, 1, &oh, &ow, &cg, &g)) { free(*y); return 0; }
+    relu_inplace(g, (int64_t)w * h * cg);
+    snprintf(p, sizeof p, "%s.gdt_convs_attn_%d.0", prefix, level);
+    ok = conv_m(m, p, g, 1, h, w, cg, 1, 0, &oh, &ow, &c1, &a);
+    free(g);
+    if (!ok) { free(*y); return 0; }
+    if (c1 != 1) { free(a); free(*y); VO_FAIL("%s: gdt attention has %d channels, expected 1", p, c1); }
+    sigmoid_inplace(a, (int64_t)w * h, 1.0f);
+    for (int64_t i = 0; i < (int64_t)w * h; ++i)
+        for (int c = 0; c < *Cout; ++c) (*y)[i * *Cout + c] = (*y)[i * *Cout + c] * a[i];
+    free(a);
+    return 1;
+}
+
+/* birefnet::encode (birefnet.cpp:43-73): SWIN on the image and on its half-size copy, concatenated per stage; the last stage also
+ * gets the three finer stages scaled down to its size. feats[i] malloc'd NHWC, dims[i] = {w, h, C}. */
+int vo_birefnet_encode(const vo_model* m, const vo_swin_params* P, const float* image, int W_img, int H_img, float* feats[4], int dims[4][3]) {
+    float *xs[4], *lo[4];
+    int d[4][3], dl[4][3];
+    for (int i = 0; i < 4; ++i) feats[i] = NULL;
+    if (W_img % 2 || H_img % 2) VO_FAIL("birefnet: image extent %dx%d must be even", W_img, H_img);
+    if (!vo_swin_encode(m, "bb", P, image, W_img, H_img, xs, d, NULL, 0)) return 0;
+    float* low = resize_ac(image, H_img, W_img, 3, H_img / 2, W_img / 2);
+    int ok = vo_swin_encode(m, "bb", P, low, W_img / 2, H_img / 2, lo, dl, NULL, 0);
+    free(low);
+    if (!ok) { for (int i = 0; i < 4; ++i) free(xs[i]); return 0; }
+    for (int i = 0; i < 4; ++i) {
+        float* up = resize_ac(lo[i], dl[i][1], dl[i][0], dl[i][2], d[i][1], d[i][0]);
+        free(lo[i]);
+        const float* parts[2] = {xs[i], up};
+        const int cs[2] = {d[i][2], dl[i][2]};
+        int ct;
+        feats[i] = concat_channels(parts, cs, 2, (int64_t)d[i][0] * d[i][1], &ct);
+        free(up); free(xs[i]);
+        dims[i][0] = d[i][0]; dims[i][1] = d[i][1]; dims[i][2] = ct;
+    }
+    float* parts[4];
+    int cs[4], ct;
+    for (int i = 0; i < 3; ++i) { /* downscale_by_whcn(xs[i], 8 >> i): target = own size / f */
+        const int f = 8 >> i;
+        parts[i] = resize_ac(feats[i], dims[i][1], dims[i][0], dims[i][2], dims[i][1] / f, dims[i][0] / f);
+        cs[i] = dims[i][2];
+        if (dims[i][0] / f != dims[3][0] || dims[i][1] / f != dims[3][1]) {
+            for (int k = 0; k <= i; ++k) free(parts[k]);
+            for (int k = 0; k < 4; ++k) { free(feats[k]); feats[k] = NULL; }
+            VO_FAIL("birefnet: stage %d scaled by %d is %dx%d, stage 3 is %dx%d", i, f, dims[i][0] / f, dims[i][1] / f, dims[3][0], dims[3][1]);
+        }
+    }
+    parts[3] = feats[3];
+    cs[3] = dims[3][2];
+    float* x4 = concat_channels((const float* const*)parts, cs, 4, (int64_t)dims[3][0] * dims[3][1], &ct);
+    for (int i = 0; i < 3; ++i) free(parts[i]);
+    free(feats[3]);
+    feats[3] = x4;
+    dims[3][2] = ct;
+    return 1;
+}
+
+/* birefnet_predict (birefnet.cpp:252-260, decode :170-250): normalised rgb_f32 image [H][W][3] -> sigmoid mask [H][W] */
+int vo_birefnet_predict(const vo_model* m, const vo_swin_params* P, const float* image, int W_img, int H_img, float* out,
+                        vo_capture* captures, int n_captures) {
+    float* f[4];
+    int d[4][3];
+    char cname[32];
+    if (!vo_birefnet_encode(m, P, image, W_img, H_img, f, d)) return 0;
+    for (int i = 0; i < 4; ++i) { snprintf(cname, sizeof cname, "feature_%d", i); capture(captures, n_captures, cname, f[i], (int64_t)d[i][0] * d[i][1] * d[i][2]); }
+    int ok, co;
+    { /* squeeze block */
+        float* y = NULL;
+        ok = bf_decoder_block(m, "squeeze_module.0", f[3], d[3][1], d[3][0], d[3][2], &co, &y);
+        if (ok) { free(f[3]); f[3] = y; d[3][2] = co; capture(captures, n_captures, "squeeze", y, (int64_t)d[3][0] * d[3][1] * co); }
+    }
+    float* p = NULL; /* running decoder map at level size */
+    int pc = 0;
+    for (int level = 4; level >= 1 && ok; --level) {
+        const int fi = level - 1, w = d[fi][0], h = d[fi][1];
+        float* xin;
+        int cin;
+        if (level == 4) { xin = f[3]; cin = d[3][2]; f[3] = NULL; }
+        else { /* lateral 1x1 conv of the encoder feature + upscaled previous level (birefnet.cpp:196-198) */
+            char lp[64];
+            float* lat = NULL;
+            int oh, ow, cl;
+            snprintf(lp, sizeof lp, "decoder.lateral_block%d.conv", level + 1);
+            ok = conv_m(m, lp, f[fi], 1, h, w, d[fi][2], 1, 0, &oh, &ow, &cl, &lat);
+            if (!ok) break;
+            float* up = resize_ac(p, d[fi + 1][1], d[fi + 1][0], pc, h, w);
+            free(p); p = NULL;
+            if (cl != pc) { free(up); free(lat); ok = 0; snprintf(g_err, sizeof g_err, "birefnet: lateral_block%d has %d channels, decoder carries %d", level + 1, cl, pc); break; }
+            for (int64_t i = 0; i < (int64_t)w * h * cl; ++i) up[i] = up[i] + lat[i];
+            free(lat);
+            xin = up; cin = cl;
+        }
+        float* y = NULL;
+        ok = bf_level(m, "decoder", level, xin, w, h, cin, image, W_img, H_img, level > 1, &co, &y);
+        free(xin);
+        if (ok) { p = y; pc = co; snprintf(cname, sizeof cname, "p%d", level); capture(captures, n_captures, cname, p, (int64_t)w * h * pc); }
+    }
+    for (int i = 0; i < 4; ++i) free(f[i]);
+    if (ok) { /* _p1 upscaled to the image, concat ipt_blk1(image), conv_out1.0, sigmoid (birefnet.cpp:238-247) */
+        float* up = resize_ac(p, d[0][1], d[0][0], pc, H_img, W_img);
+        free(p); p = NULL;
+        float *a = NULL, *b = NULL;
+        int oh, ow, ci, cb, c1, ct;
+        ok = conv_m(m, "decoder.ipt_blk1.conv1", image, 1, H_img, W_img, 3, 1, 1, &oh, &ow, &ci, &a);
+        if (ok) { ok = conv_m(m, "decoder.ipt_blk1.conv_out", a, 1, H_img, W_img, ci, 1, 1, &oh, &ow, &cb, &b); free(a); }
+        if (ok) {
+            const float* parts[2] = {up, b};
+            const int cs[2] = {pc, cb};
+            float* cat = concat_channels(parts, cs, 2, (int64_t)W_img * H_img, &ct);
+            free(b);
+            float* o = NULL;
+            ok = conv_m(m, "decoder.conv_out1.0", cat, 1, H_img, W_img, ct, 1, 0, &oh, &ow, &c1, &o);
+            free(cat);
+            if (ok && c1 != 1) { free(o); ok = 0; snprintf(g_err, sizeof g_err, "birefnet: conv_out1 has %d channels, expected 1", c1); }
+            if (ok) { sigmoid_inplace(o, (int64_t)W_img * H_img, 1.0f); memcpy(out, o, (size_t)W_img * H_img * 4); free(o); }
+        }
+        free(up);
+    }
+    free(p);
+    return ok;
+}

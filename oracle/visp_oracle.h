@@ -212,6 +212,18 @@ int vo_swin_encode(const vo_model*, const char* prefix, const vo_swin_params*, c
                    int dims[4][3], vo_capture* captures, int n_captures);
 void vo_free(void* p);
 
+/* ---- BiRefNet (reference src/visp/arch/birefnet.cpp): two-scale SWIN encode, squeeze block, decoder -------------------------
+ * The deformable convolution is PARITY UNPINNED (no torchvision / ggml here): torchvision's published algorithm restated. */
+void vo_deform_conv2d_nhwc(const float* x, int H, int W, int Cin, const float* w /*[Cout][kh][kw][Cin]*/, int Cout, int kh, int kw,
+                           const float* offset /*[OH][OW][2 kh kw]: (dy, dx) per tap*/, const float* mask /*[OH][OW][kh kw] or NULL*/, int stride,
+                           int pad, float* y /*[OH][OW][Cout]*/);
+/* image_to_patches (birefnet.cpp:158-167): [IH][IW][C] -> [h][w][gw*gh*C], channel = gx + gw (gy + gh c) */
+void vo_image_to_patches(const float* image, int IW, int IH, int C, int w, int h, float* patches);
+/* birefnet::encode (birefnet.cpp:43-73): feats[i] malloc'd NHWC (vo_free), dims[i] = {w, h, C} */
+int vo_birefnet_encode(const vo_model*, const vo_swin_params*, const float* image, int W, int H, float* feats[4], int dims[4][3]);
+/* birefnet_predict (birefnet.cpp:252-260): normalised rgb_f32 [H][W][3] -> sigmoid mask [H][W]; captures: feature_0..3, squeeze, p4..p1 */
+int vo_birefnet_predict(const vo_model*, const vo_swin_params*, const float* image, int W, int H, float* out, vo_capture* captures, int n_captures);
+
 /* dino building blocks, exposed for module-level parity tests */
 int vo_dino_layer(const vo_model*, const char* prefix, int n_heads, int gelu_mode, float* x /*[N][C] in/out*/,
                   int64_t N, int64_t C);

@@ -1,0 +1,133 @@
+"""CPU suite: the oracle's BiRefNet restatement (oracle/visp_oracle.c vo_birefnet_*, reference src/visp/arch/birefnet.cpp).
+
+PARITY UNPINNED for the deformable convolution: the reference implements it with ggml_conv_2d_deform (a fork-only ggml op that is
+not in /root/reference) and tests it against torchvision.ops.deform_conv2d (tests/test_birefnet.py:767-795); neither is available
+here, and the reference holds no literal vector for it. What these tests can do: check the C restatement against an independent
+numpy restatement of torchvision's published algorithm, against the regular convolution where the two must coincide, and pin
+everything around it (image_to_patches against the einops pattern the reference's test uses, the two-scale encode against its
+definition in terms of already-pinned operators)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from visioncpp_amd import synth
+
+
+def _deform_numpy(x, w, offset, mask, stride, pad):
+    """torchvision deform_conv2d (dilation 1, one offset group), written independently of the C code: for every output pixel
+    and kernel tap, bilinear-sample the zero-extended input at (y*s - p + ky + dy, x*s - p + kx + dx); a sample outside
+    (-1, H) x (-1, W) is zero; corners outside the map count as zero."""
+    H, W, Cin = x.shape
+    Cout, kh, kw, _ = w.shape
+    OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = np.zeros((OH, OW, Cout), np.float64)
+
+    def at(yy, xx):
+        return x[yy, xx].astype(np.float64) if 0 <= yy < H and 0 <= xx < W else np.zeros(Cin)
+
+    for oy in range(OH):
+        for ox in range(OW):
+            for ky in range(kh):
+                for kx in range(kw):
+                    t = ky * kw + kx
+                    py = oy * stride - pad + ky + float(offset[oy, ox, 2 * t])
+                    px = ox * stride - pad + kx + float(offset[oy, ox, 2 * t + 1])
+                    if py <= -1 or py >= H or px <= -1 or px >= W:
+                        continue
+                    y0, x0 = int(np.floor(py)), int(np.floor(px))
+                    ly, lx = py - y0, px - x0
+                    v = (1 - ly) * (1 - lx) * at(y0, x0) + (1 - ly) * lx * at(y0, x0 + 1) + ly * (1 - lx) * at(y0 + 1, x0) + ly * lx * at(y0 + 1, x0 + 1)
+                    if mask is not None:
+                        v = v * float(mask[oy, ox, t])
+                    out[oy, ox] += w[:, ky, kx, :].astype(np.float64) @ v
+    return out.astype(np.float32)
+
+
+@pytest.mark.parametrize("k,pad,stride", [(1, 0, 1), (3, 1, 1), (7, 3, 1), (3, 0, 2)])
+def test_deform_conv_against_numpy_restatement(k, pad, stride):
+    rng = np.random.default_rng(k)
+    H, W, Cin, Cout = 9, 11, 5, 4
+    x = rng.standard_normal((H, W, Cin)).astype(np.float32)
+    w = rng.standard_normal((Cout, k, k, Cin)).astype(np.float32)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    offset = (rng.standard_normal((OH, OW, 2 * k * k)) * 1.5).astype(np.float32)
+    offset[0, 0, :2] = [-20.0, 3.0]      # far outside: contributes nothing
+    offset[1, 1, :2] = [-0.5, -0.5]      # straddles the border
+    mask = (rng.random((OH, OW, k * k)) * 2).astype(np.float32)
+    got = oracle.deform_conv2d_nhwc(x, w, offset, mask, stride, pad)
+    want = _deform_numpy(x, w, offset, mask, stride, pad)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(oracle.deform_conv2d_nhwc(x, w, offset, None, stride, pad), _deform_numpy(x, w, offset, None, stride, pad), rtol=1e-4, atol=1e-4)
+
+
+def test_deform_conv_with_zero_offsets_is_the_regular_convolution():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((12, 10, 8)).astype(np.float32)
+    w = rng.standard_normal((6, 3, 3, 8)).astype(np.float32)
+    zero = np.zeros((12, 10, 18), np.float32)
+    got = oracle.deform_conv2d_nhwc(x, w, zero, np.ones((12, 10, 9), np.float32), 1, 1)
+    want = oracle.conv2d_nhwc(x[None], w, None, 1, 1)[0]
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    # an integer offset is a shifted read: every tap moved one pixel right = the convolution of the image shifted left
+    off = zero.copy()
+    off[..., 1::2] = 1.0
+    shifted = np.zeros_like(x)
+    shifted[:, :-1] = x[:, 1:]
+    # (away from the left border, where the shifted image has a padding zero and the deformable read still sees column 0)
+    np.testing.assert_allclose(oracle.deform_conv2d_nhwc(x, w, off, None, 1, 1)[:, 1:], oracle.conv2d_nhwc(shifted[None], w, None, 1, 1)[0][:, 1:], rtol=1e-5, atol=1e-5)
+
+
+def test_image_to_patches_matches_the_reference_pattern():
+    """tests/test_birefnet.py:1072-1090: 'b c (hg h) (wg w) -> b (c hg wg) h w' on arange(3*8*8) with a 2 x 2 grid."""
+    x = np.arange(3 * 8 * 8, dtype=np.float32).reshape(3, 8, 8)                      # c, H, W
+    want = x.reshape(3, 2, 4, 2, 4).transpose(0, 1, 3, 2, 4).reshape(12, 4, 4)       # (c hg wg), h, w
+    got = oracle.image_to_patches(x.transpose(1, 2, 0), 4, 4)                        # NHWC in, [h, w, 12] out
+    np.testing.assert_array_equal(got.transpose(2, 0, 1), want)
+
+
+@pytest.fixture(scope="module")
+def mini():
+    cfg = synth.SWIN_MINI
+    tensors, conv_idx = synth.birefnet_gguf_tensors(synth.birefnet_state_dict(cfg, 1))
+    return oracle.Model(tensors, conv_idx), oracle.swin_params(cfg.embed_dim, cfg.window_size, cfg.depths, cfg.n_heads)
+
+
+def test_two_scale_encode_is_composed_of_pinned_operators(mini):
+    """birefnet::encode (birefnet.cpp:43-73) in terms of swin_encode (pinned, tests/test_oracle_swin.py) and the align-corners
+    bilinear resize (pinned, tests/test_oracle_golden.py): full + upscaled half-resolution features per stage; the last stage
+    also carries stages 0..2 scaled down by 8, 4, 2."""
+    model, P = mini
+    rng = np.random.default_rng(3)
+    img = rng.standard_normal((128, 192, 3)).astype(np.float32)      # H = 128, W = 192
+    feats = oracle.birefnet_encode(model, P, img)
+    full = oracle.swin_encode(model, P, img)
+    low = oracle.swin_encode(model, P, oracle.interpolate_nhwc(img[None], (64, 96), "bilinear", True)[0])
+    cat = []
+    for i in range(4):
+        h, w = full[i].shape[:2]
+        up = oracle.interpolate_nhwc(low[i][None], (h, w), "bilinear", True)[0]
+        cat.append(np.concatenate([full[i], up], -1))
+    h3, w3 = cat[3].shape[:2]
+    last = np.concatenate([oracle.interpolate_nhwc(cat[i][None], (h3, w3), "bilinear", True)[0] for i in range(3)] + [cat[3]], -1)
+    assert [f.shape for f in feats] == [(32, 48, 64), (16, 24, 128), (8, 12, 256), (4, 6, 960)]
+    for i in range(3):
+        np.testing.assert_allclose(feats[i], cat[i], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(feats[3], last, rtol=1e-5, atol=1e-5)
+
+
+def test_predict_shapes_ranges_and_errors(mini):
+    model, P = mini
+    rng = np.random.default_rng(5)
+    img = rng.standard_normal((128, 128, 3)).astype(np.float32)
+    out, caps = oracle.birefnet_predict(model, P, img, captures={"p4": 4 * 4 * 256, "p1": 32 * 32 * 32, "squeeze": 4 * 4 * 512})
+    assert out.shape == (128, 128) and out.min() > 0 and out.max() < 1 and out.std() > 1e-3
+    assert all(np.isfinite(v).all() and np.abs(v).max() > 1e-3 for v in caps.values())
+    np.testing.assert_array_equal(oracle.birefnet_predict(model, P, img), out)
+    with pytest.raises(RuntimeError, match="multiple of the patch size|must be even"):
+        oracle.birefnet_predict(model, P, np.zeros((62, 64, 3), np.float32))
+    cfg = synth.SWIN_MINI
+    sd = synth.birefnet_state_dict(cfg, 1)
+    del sd["decoder.block3.dec_att.aspp_deforms.2.conv.modulator.weight"]
+    t, c = synth.birefnet_gguf_tensors(sd)
+    with pytest.raises(RuntimeError, match="tensor not found"):
+        oracle.birefnet_predict(oracle.Model(t, c), P, img)

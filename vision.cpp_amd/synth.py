@@ -611,3 +611,97 @@ def write_swin_gguf(path: str | Path, cfg: SwinConfig = SWIN_T, seed: int = 0, s
         w.add_tensor(name, t)
     w.write()
     return Path(path)
+
+
+# ---- BiRefNet: SWIN backbone + squeeze block + decoder (reference src/visp/arch/birefnet.cpp, tests/test_birefnet.py:1025-1260) ----
+
+def birefnet_state_dict(cfg: SwinConfig = SWIN_T, seed: int = 0) -> dict[str, np.ndarray]:
+    """float32 tensors under the names convert_birefnet writes (convert.py:381-419: decoder_block -> block, atrous_conv /
+    regular_conv -> conv, offset_conv -> offset, modulator_conv -> modulator), with every BatchNorm already fused the way the
+    converter fuses it: conv + bn -> conv weight / bias (conv_in, conv_out, dec_att.conv1, global_avg_pool.1, gdt_convs_N.0),
+    the ASPP branch norms -> bn.weight / bn.bias (mul + add). Channel table of the reference's Decoder for backbone width C0:
+    lateral channels [16, 8, 4, 2] C0, squeeze 30 C0 -> 16 C0, decoder-block inter channels 64, ASPP planes 256."""
+    sd = swin_state_dict(cfg, seed)
+    rng = np.random.default_rng(seed + 7919)
+    C0 = cfg.embed_dim
+    assert C0 % 4 == 0
+
+    def normal(shape, std):
+        return (rng.standard_normal(shape) * std).astype(np.float32)
+
+    def conv(name, out_c, in_c, k, bias=True, gain=1.0):
+        sd[f"{name}.weight"] = normal((out_c, in_c, k, k), gain / np.sqrt(in_c * k * k))
+        if bias:
+            sd[f"{name}.bias"] = normal((out_c,), 0.05)
+
+    def deform(name, in_c, out_c, k):  # DeformableConv2d: offsets about half a pixel, modulation around 1
+        conv(f"{name}.conv.offset", 2 * k * k, in_c, k, gain=0.6)
+        conv(f"{name}.conv.modulator", k * k, in_c, k, gain=1.0)
+        conv(f"{name}.conv.conv", out_c, in_c, k, bias=False, gain=1.2)
+        sd[f"{name}.bn.weight"] = (1.0 + rng.standard_normal(out_c) * 0.1).astype(np.float32)
+        sd[f"{name}.bn.bias"] = normal((out_c,), 0.1)
+
+    def dec_block(name, in_c, out_c, inter=64, planes=256):
+        conv(f"{name}.conv_in", inter, in_c, 3, gain=1.3)
+        deform(f"{name}.dec_att.aspp1", inter, planes, 1)
+        for i, k in enumerate((1, 3, 7)):
+            deform(f"{name}.dec_att.aspp_deforms.{i}", inter, planes, k)
+        conv(f"{name}.dec_att.global_avg_pool.1", planes, inter, 1, gain=1.3)
+        conv(f"{name}.dec_att.conv1", inter, 5 * planes, 1, gain=1.3)
+        conv(f"{name}.conv_out", out_c, inter, 3, gain=1.3)
+
+    ch = [16 * C0, 8 * C0, 4 * C0, 2 * C0]
+    dec_block("squeeze_module.0", 30 * C0, ch[0])
+    d = "decoder."
+    ipt_out = {5: ch[0] // 8, 4: ch[0] // 8, 3: ch[1] // 8, 2: ch[2] // 8, 1: ch[3] // 8}
+    for lvl, grid in ((5, 32), (4, 16), (3, 8), (2, 4), (1, 1)):
+        conv(f"{d}ipt_blk{lvl}.conv1", 64, 3 * grid * grid, 3)
+        conv(f"{d}ipt_blk{lvl}.conv_out", ipt_out[lvl], 64, 3)
+    dec_block(f"{d}block4", ch[0] + ipt_out[5], ch[1])
+    dec_block(f"{d}block3", ch[1] + ipt_out[4], ch[2])
+    dec_block(f"{d}block2", ch[2] + ipt_out[3], ch[3])
+    dec_block(f"{d}block1", ch[3] + ipt_out[2], ch[3] // 2)
+    conv(f"{d}conv_out1.0", 1, ch[3] // 2 + ipt_out[1], 1)
+    for lvl, c in ((4, ch[1]), (3, ch[2]), (2, ch[3])):
+        conv(f"{d}lateral_block{lvl}.conv", c, c, 1)
+        conv(f"{d}gdt_convs_{lvl}.0", 16, c, 3, gain=1.3)
+        conv(f"{d}gdt_convs_attn_{lvl}.0", 1, 16, 1)
+    return sd
+
+
+def birefnet_gguf_tensors(sd: dict[str, np.ndarray]):
+    """convert_birefnet's storage rules (convert.py:413-419): the SWIN patch_embed kernel NHWC, every other conv kernel stays
+    OIHW and its tensor index is listed in conv2d_weights (--layout nchw, the converter's default); everything f16."""
+    out: dict[str, np.ndarray] = {}
+    conv2d: list[int] = []
+    for name, t in sd.items():
+        if t.ndim == 4:
+            if "patch_embed" in name:
+                t = np.ascontiguousarray(t.transpose(0, 2, 3, 1))
+            else:
+                conv2d.append(len(out))
+        out[name] = t.astype(np.float16)
+    return out, conv2d
+
+
+def write_birefnet_gguf(path: str | Path, cfg: SwinConfig = SWIN_T, seed: int = 0, sd: dict[str, np.ndarray] | None = None) -> Path:
+    sd = sd if sd is not None else birefnet_state_dict(cfg, seed)
+    tensors, conv2d = birefnet_gguf_tensors(sd)
+    w = GGUFWriter(path, "birefnet")
+    w.add_string("birefnet.tensor_data_layout", "whcn")
+    w.add_string("swin.config", "tiny" if cfg.embed_dim == 96 else ("large" if cfg.embed_dim == 192 else cfg.name))
+    w.add_int32("swin.embed_dim", cfg.embed_dim)
+    if cfg.embed_dim not in (96, 192):
+        w.add_int32("swin.window_size", cfg.window_size)
+        w.add_array_i32("swin.depths", cfg.depths)
+        w.add_array_i32("swin.n_heads", cfg.n_heads)
+    w.add_int32("birefnet.image_size", cfg.image_size)
+    w.add_int32("birefnet.image_multiple", 128)
+    w.add_uint32("general.quantization_version", 2)
+    w.add_uint32("general.file_type", 1)
+    if conv2d:
+        w.add_array_i32("birefnet.conv2d_weights", conv2d)
+    for name, t in tensors.items():
+        w.add_tensor(name, t)
+    w.write()
+    return Path(path)
