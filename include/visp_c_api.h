@@ -196,10 +196,16 @@ VISP_API int32_t visp_sam_read_capture(visp_model* m, char const* name, float* h
 VISP_API int32_t visp_sam_enable_timing(visp_model* m, int32_t enable);
 VISP_API int32_t visp_sam_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
 
+/* ---- BiRefNet (family 1; reference src/visp/arch/birefnet.cpp, vision.cpp:98-132): visp_model_load + visp_model_compute run
+ * birefnet_compute (any 8-bit colour image -> alpha_u8 mask at its extent). Batched extension: rgb_u8 [batch, h, w, 3] at the
+ * model extent (visp_birefnet_image_extent; multiples of 64) -> sigmoid mask f32 [batch, h, w]. */
+VISP_API int32_t visp_birefnet_image_extent(visp_model* m, int32_t w, int32_t h, int32_t* out_w, int32_t* out_h);
+VISP_API int32_t visp_birefnet_compute_batch_device(visp_model* m, void const* rgb_u8, int32_t batch, int32_t w, int32_t h, void* mask_f32, void* stream);
+VISP_API int32_t visp_birefnet_compute_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w, int32_t h, float* mask);
+
 /* ---- SWIN encoder, the backbone of BiRefNet (reference src/visp/arch/swin.cpp, swin_encode) ---------
- * The BiRefNet decoder is not built in this backend yet, so visp_model_load / visp_model_compute keep refusing family 1; the
- * encoder of a birefnet GGUF (tensors bb.*, KV swin.embed_dim) is reachable on its own. The handle is destroyed with
- * visp_model_destroy(m, VISP_BIREFNET). */
+ * The encoder of a birefnet GGUF (tensors bb.*, KV swin.embed_dim) on its own: visp_swin_load reads only the backbone; the
+ * visp_swin_* calls also accept a full birefnet model handle. Destroyed with visp_model_destroy(m, VISP_BIREFNET). */
 VISP_API int32_t visp_swin_load(char const* filepath, visp_device const* dev, visp_model** out);
 /* dims[3 i .. 3 i + 2] = {w_i, h_i, C_i} of output i for an image of extent (w, h) (swin.cpp:229-262) */
 VISP_API int32_t visp_swin_output_dims(visp_model* m, int32_t w, int32_t h, int32_t dims[12]);

@@ -206,6 +206,8 @@ VX_API int vx_window_attention_masked_f16(const void* qkv, const void* bias_pack
  * place; out_f32 writes f32 (the per-stage output norms, swin.cpp:255-258). */
 VX_API int vx_swin_layernorm_f16(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int H, int W, int ws,
                                  int shift, int out_f32, void* stream);
+VX_API int vx_swin_layernorm_strided_f16(const void* x, const float* w, const float* b, void* y, int64_t rows, int C, float eps, int ldy, int out_f32,
+                                         void* stream); /* plain rows, output row stride ldy elements (0 = C) */
 /* patch_merging up to the reduction linear (swin.cpp:140-158): 2x2 gather in the reference's concat order + LayerNorm(4C);
  * x [B, H, W, C] -> y [B * H/2 * W/2, 4C] */
 VX_API int vx_swin_merge_layernorm_f16(const void* x, const float* w, const float* b, void* y, int B, int H, int W, int C, float eps, void* stream);
@@ -213,6 +215,21 @@ VX_API int vx_swin_merge_layernorm_f16(const void* x, const float* w, const floa
 VX_API int vx_swin_window_reverse_add_f16(const void* a, const void* x, void* y, int B, int H, int W, int C, int ws, int shift, void* stream);
 /* window_reverse + residual: y[b,py,px,:] = x[b,py,px,:] + a[window row of (py,px),:] (mobile-sam.cpp:48-64, 146-149) */
 VX_API int vx_window_reverse_add_f16(const void* a, const void* x, void* y, int B, int res, int ws, int C, void* stream);
+/* ---- BiRefNet glue (two-scale encode + decoder, birefnet.cpp), kernels_birefnet.hip ---------------------------------------
+ * normalised (birefnet_process_input) and downscaled by 2 (bilinear, align_corners): rgb u8 [B,H,W,3] -> f16 [B,H/2,W/2][8] value + residue */
+VX_API int vx_bf_preprocess_half(const uint8_t* rgb, void* out8, int B, int H, int W, void* stream);
+/* image_to_patches of the normalised image (birefnet.cpp:158-167): -> f16 [B, h, w, (IW/w)*(IH/h)*3], channel = gx + gw (gy + gh c) */
+VX_API int vx_bf_patches(const uint8_t* rgb, void* out, int B, int IH, int IW, int h, int w, void* stream);
+/* bilinear align-corners resize of f16 NHWC maps; lds / ldd = row strides in elements (channel slices of wider buffers); C % 8 == 0 */
+VX_API int vx_bf_resize_f16(const void* src, int lds, void* dst, int ldd, int B, int h, int w, int C, int oh, int ow, void* stream);
+/* sampling half of deformable_conv_2d (birefnet.cpp:83-92 = torchvision deform_conv2d, stride 1, pad k/2): x f16 [B,h,w,C]; offmod
+ * [B*h*w, ldom] = per pixel 2 k^2 offsets (dy, dx per tap) then k^2 modulator logits; cols [B*h*w, k*k*C] = 2 sigmoid(mod) * sample */
+VX_API int vx_bf_deform_cols_f16(const void* x, const void* offmod, int ldom, void* cols, int B, int h, int w, int C, int k, void* stream);
+/* per-image pixel mean [B, n, C] (row stride ld) -> [B, C]; broadcast of [B, C] rows to every pixel of a slice; y *= sigmoid(a); final mask */
+VX_API int vx_bf_mean_f16(const void* x, int ld, void* y, int B, int64_t n, int C, void* stream);
+VX_API int vx_bf_broadcast_f16(const void* g, int ldg, void* dst, int ldd, int B, int64_t n, int C, void* stream);
+VX_API int vx_bf_mul_sigmoid_f16(void* y, int ldy, const void* a, int lda, int64_t rows, int C, void* stream);
+VX_API int vx_bf_sigmoid_out_f32(const void* a, int lda, float* out, int64_t n, void* stream);
 /* y f16 = a + b[i mod b_period]; a f16 or f32 (SAM decoder: queries + query_pe, keys + key_pe, embedding + no_mask_embed) */
 VX_API int vx_add_rows_f16(const void* a, int a_is_f32, const void* b, int64_t b_period, void* y, int64_t n, void* stream);
 /* attention with few queries or few keys (SAM mask decoder, mobile-sam.cpp:306-320): q [Nq][heads*hd], k, v [Nk][heads*hd]

@@ -101,6 +101,7 @@ C_API_SYMBOLS = [
     "visp_sam_encode", "visp_sam_read_embedding", "visp_sam_encode_batch_device", "visp_sam_encode_batch_host",
     "visp_sam_weights_arena", "visp_sam_weights_ready", "visp_sam_enable_timing", "visp_sam_read_timing",
     "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks", "visp_image_scale", "visp_gguf_validate",
+    "visp_birefnet_image_extent", "visp_birefnet_compute_batch_device", "visp_birefnet_compute_batch_host",
     "visp_swin_load", "visp_swin_output_dims", "visp_swin_encode_batch_device", "visp_swin_encode_batch_host", "visp_swin_enable_captures",
     "visp_swin_read_capture", "visp_swin_enable_timing", "visp_swin_read_timing",
 ]
@@ -114,7 +115,8 @@ KERNEL_SYMBOLS = [
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
     "vx_dconv3x3_f16", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
     "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_mbconv_dw_pw_supported", "vx_mbconv_pack_w3", "vx_mbconv_dw_pw_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
-    "vx_swin_attention_pack_bias", "vx_window_attention_masked_f16", "vx_swin_layernorm_f16", "vx_swin_merge_layernorm_f16", "vx_swin_window_reverse_add_f16",
+    "vx_bf_preprocess_half", "vx_bf_patches", "vx_bf_resize_f16", "vx_bf_deform_cols_f16", "vx_bf_mean_f16", "vx_bf_broadcast_f16", "vx_bf_mul_sigmoid_f16", "vx_bf_sigmoid_out_f32",
+    "vx_swin_attention_pack_bias", "vx_window_attention_masked_f16", "vx_swin_layernorm_f16", "vx_swin_layernorm_strided_f16", "vx_swin_merge_layernorm_f16", "vx_swin_window_reverse_add_f16",
     "vx_dino_block_supported", "vx_dino_block_mlp_bytes", "vx_dino_block_qkv_bytes", "vx_dino_block_pack_mlp", "vx_dino_block_pack_qkv", "vx_dino_block_f16", "vx_dino_block2_f16",
 ]
 
@@ -200,6 +202,9 @@ def init() -> ctypes.CDLL:
     lib.visp_sam_enable_timing.argtypes = [c_void_p, c_int32]
     lib.visp_sam_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
     lib.visp_gguf_validate.argtypes = [c_char_p, POINTER(c_int32)]
+    lib.visp_birefnet_image_extent.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]
+    lib.visp_birefnet_compute_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.visp_birefnet_compute_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
     lib.visp_swin_load.argtypes = [c_char_p, c_void_p, POINTER(c_void_p)]
     lib.visp_swin_output_dims.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_int32)]
     lib.visp_swin_encode_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p), c_void_p]
@@ -251,9 +256,18 @@ def init() -> ctypes.CDLL:
     lib.vx_dwconv3x3_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_int, c_void_p]
     lib.vx_window_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.vx_bf_preprocess_half.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.vx_bf_patches.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.vx_bf_resize_f16.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.vx_bf_deform_cols_f16.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.vx_bf_mean_f16.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]
+    lib.vx_bf_broadcast_f16.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]
+    lib.vx_bf_mul_sigmoid_f16.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]
+    lib.vx_bf_sigmoid_out_f32.argtypes = [c_void_p, c_int, c_void_p, c_int64, c_void_p]
     lib.vx_swin_attention_pack_bias.argtypes = [c_void_p, c_int, c_int, c_void_p]
     lib.vx_window_attention_masked_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_swin_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.vx_swin_layernorm_strided_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_void_p]
     lib.vx_swin_merge_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]
     lib.vx_swin_window_reverse_add_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_add_rows_f16.argtypes = [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]

@@ -17,6 +17,7 @@
 #include "esrgan.h"
 #include "tinyvit.h"
 #include "swin.h"
+#include "birefnet.h"
 #include "visp_util.h"
 
 using namespace visp;
@@ -69,6 +70,11 @@ swin_model& as_swin(visp_model* m) { // the encoder half of the birefnet family 
     if (family_of(m) != VISP_BIREFNET) throw except("model handle is not a swin encoder (family %d)", family_of(m));
     return *static_cast<swin_model*>(reinterpret_cast<model_base*>(m));
 }
+birefnet_model& as_birefnet(visp_model* m) {
+    swin_model& s = as_swin(m);
+    if (!s.full) throw except("model handle is a swin encoder (visp_swin_load), not a birefnet model");
+    return static_cast<birefnet_model&>(s);
+}
 visp_model* handle_of(model_base* m) { return reinterpret_cast<visp_model*>(m); }
 
 int32_t detect_family(model_file const& file) { // reference vision.cpp:7-21
@@ -83,8 +89,8 @@ int32_t detect_family(model_file const& file) { // reference vision.cpp:7-21
 
 void require_built(int32_t family) {
     if (family < 0 || family >= VISP_FAMILY_COUNT) throw except("Unsupported model family");
-    if (family != VISP_DEPTH_ANYTHING && family != VISP_ESRGAN && family != VISP_SAM)
-        throw except("Model family %d is not built in this backend (MI355X backend implements depth_anything, esrgan and the sam image encoder)", family);
+    if (family != VISP_DEPTH_ANYTHING && family != VISP_ESRGAN && family != VISP_SAM && family != VISP_BIREFNET)
+        throw except("Model family %d is not built in this backend (MI355X backend implements depth_anything, esrgan, sam and birefnet)", family);
 }
 
 void read_capture(backend_device const& dev, std::map<std::string, capture_entry> const& bufs, char const* name, float* host_out,
@@ -184,6 +190,10 @@ int32_t visp_model_load_ex(char const* filepath, visp_device const* dev, int32_t
         require_built(family);
         if (family == VISP_ESRGAN) *out = handle_of(esrgan_load_model(filepath, *dev, flags));
         else if (family == VISP_SAM) *out = handle_of(sam_load_model(filepath, *dev, flags));
+        else if (family == VISP_BIREFNET) {
+            if (flags & VISP_LOAD_NO_UPLOAD) throw except("birefnet: load without upload is not supported (every rank reads the file)");
+            *out = handle_of(birefnet_load_model(filepath, *dev));
+        }
         else *out = handle_of(depthany_load_model(filepath, *dev, flags));
     });
 }
@@ -200,7 +210,7 @@ void visp_model_destroy(visp_model* model, int32_t arch) {
     if (base->family == VISP_DEPTH_ANYTHING) delete static_cast<depthany_model*>(base);
     else if (base->family == VISP_ESRGAN) delete static_cast<esrgan_model*>(base);
     else if (base->family == VISP_SAM) delete static_cast<sam_model*>(base);
-    else if (base->family == VISP_BIREFNET) delete static_cast<swin_model*>(base); // visp_swin_load
+    else if (base->family == VISP_BIREFNET) delete static_cast<swin_model*>(base); // swin encoder or full birefnet model (virtual destructor)
 }
 
 int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* inputs, int32_t n_inputs, int32_t* args, int32_t n_args,
@@ -219,6 +229,10 @@ int32_t visp_model_compute(visp_model* model, int32_t family, visp_image_view* i
             sam_model& sm = as_sam(model);
             sam_encode(sm, in);
             return_image(sam_compute(sm, args, n_args), out_image, out_data);
+            return;
+        }
+        if (family == VISP_BIREFNET) { // model_funcs<birefnet>::compute (reference c-api.cpp:59-62)
+            return_image(birefnet_compute(as_birefnet(model), in), out_image, out_data);
             return;
         }
         if (family == VISP_ESRGAN) { // model_funcs<esrgan>::compute (reference c-api.cpp:103-106)
@@ -597,6 +611,22 @@ int32_t visp_swin_load(char const* filepath, visp_device const* dev, visp_model*
     return handle_errors([&]() {
         if (!filepath || !dev || !out) throw except("visp_swin_load: null argument");
         *out = handle_of(swin_load_model(filepath, *reinterpret_cast<backend_device const*>(dev)));
+    });
+}
+
+int32_t visp_birefnet_compute_batch_device(visp_model* m, void const* rgb_u8, int32_t batch, int32_t w, int32_t h, void* mask_f32, void* stream) {
+    return handle_errors([&]() { birefnet_compute_batch_device(as_birefnet(m), rgb_u8, batch, w, h, mask_f32, stream); });
+}
+
+int32_t visp_birefnet_compute_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w, int32_t h, float* mask) {
+    return handle_errors([&]() { birefnet_compute_batch_host(as_birefnet(m), rgb_u8, batch, w, h, mask); });
+}
+
+int32_t visp_birefnet_image_extent(visp_model* m, int32_t w, int32_t h, int32_t* out_w, int32_t* out_h) {
+    return handle_errors([&]() {
+        i32x2 e = birefnet_image_extent({{w, h}}, as_birefnet(m).bparams);
+        *out_w = e[0];
+        *out_h = e[1];
     });
 }
 

@@ -71,7 +71,7 @@ __device__ __forceinline__ void ln_row_store(float (&v)[NCH][8], int C, const fl
 
 template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void swin_ln_rows_kernel(const f16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, void* y,
-                                                           long rows_out, int C, float eps, int H, int W, int ws, int shift, int out_f32) {
+                                                           long rows_out, int C, float eps, int H, int W, int ws, int shift, int out_f32, int ldy) {
     constexpr int RPB = 256 / LPR; // rows per block
     const int lane = threadIdx.x % LPR;
     long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void swin_ln_rows_kernel(const f16* __restrict
         if (sx >= wp) sx -= wp;
         src = (sy < H && sx < W) ? (img * H + sy) * W + sx : -1;
     }
-    void* yrow = out_f32 ? static_cast<void*>(static_cast<float*>(y) + row * C) : static_cast<void*>(static_cast<f16*>(y) + row * C);
+    void* yrow = out_f32 ? static_cast<void*>(static_cast<float*>(y) + row * ldy) : static_cast<void*>(static_cast<f16*>(y) + row * ldy);
     const bool pad_row = src < 0;
     if (pad_row) { // padding: zeros, not a normalised zero row (the reference pads AFTER norm1)
         if (live_row) {
@@ -168,8 +168,22 @@ __global__ __launch_bounds__(256) void swin_window_reverse_add_kernel(const f16*
 
 extern "C" {
 
+static int swin_layernorm_impl(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int H, int W, int ws, int shift,
+                               int out_f32, int ldy, void* stream);
+
 int vx_swin_layernorm_f16(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int H, int W, int ws, int shift,
                           int out_f32, void* stream) {
+    return swin_layernorm_impl(x, w, b, y, rows_out, C, eps, H, W, ws, shift, out_f32, C, stream);
+}
+
+// plain rows with an output row stride (ldy elements, 0 = C): a stage output written straight into a wider concatenation buffer
+int vx_swin_layernorm_strided_f16(const void* x, const float* w, const float* b, void* y, int64_t rows, int C, float eps, int ldy, int out_f32, void* stream) {
+    VX_REQUIRE(ldy == 0 || (ldy >= C && ldy % 8 == 0), "vx_swin_layernorm_strided_f16: row stride %d for %d channels", ldy, C);
+    return swin_layernorm_impl(x, w, b, y, rows, C, eps, 0, 0, 0, 0, out_f32, ldy ? ldy : C, stream);
+}
+
+static int swin_layernorm_impl(const void* x, const float* w, const float* b, void* y, int64_t rows_out, int C, float eps, int H, int W, int ws, int shift,
+                               int out_f32, int ldy, void* stream) {
     VX_REQUIRE(x && w && b && y && rows_out > 0 && C > 0 && C % 8 == 0 && C <= 2048, "vx_swin_layernorm_f16: bad operands (C = %d: a multiple of 8, at most 2048)", C);
     VX_REQUIRE(ws == 0 || (H > 0 && W > 0 && shift >= 0 && shift < ws && !out_f32), "vx_swin_layernorm_f16: bad window arguments");
     if (ws > 0) {
@@ -179,7 +193,7 @@ int vx_swin_layernorm_f16(const void* x, const float* w, const float* b, void* y
     const f16* xp = reinterpret_cast<const f16*>(x);
     const long rows = (long)rows_out;
     hipStream_t s = as_stream(stream);
-#define LN_LAUNCH(LPR, NCH) hipLaunchKernelGGL((swin_ln_rows_kernel<LPR, NCH>), dim3(blocks_for(rows, 256 / LPR)), dim3(256), 0, s, xp, w, b, y, rows, C, eps, H, W, ws, shift, out_f32)
+#define LN_LAUNCH(LPR, NCH) hipLaunchKernelGGL((swin_ln_rows_kernel<LPR, NCH>), dim3(blocks_for(rows, 256 / LPR)), dim3(256), 0, s, xp, w, b, y, rows, C, eps, H, W, ws, shift, out_f32, ldy)
     if (C <= 128) LN_LAUNCH(16, 1);
     else if (C <= 256) LN_LAUNCH(32, 1);
     else if (C <= 512) LN_LAUNCH(64, 1);

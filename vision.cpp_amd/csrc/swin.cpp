@@ -47,6 +47,12 @@ swin_model* swin_load_model(char const* filepath, backend_device const& dev, cha
     if (file.arch() != "birefnet")
         throw except("Architecture expected to be 'birefnet', but was '%.*s' (%s)", (int)file.arch().size(), file.arch().data(), filepath); // birefnet.cpp:313-315
     auto model = std::make_unique<swin_model>();
+    swin_load_into(*model, file, dev, prefix);
+    return model.release();
+}
+
+void swin_load_into(swin_model& mdl, model_file const& file, backend_device const& dev, char const* prefix) {
+    swin_model* const model = &mdl;
     model->backend = &dev;
     model->params = swin_detect_params(file);
     swin_params const& P = model->params;
@@ -123,7 +129,6 @@ swin_model* swin_load_model(char const* filepath, backend_device const& dev, cha
     VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
     VX(vx_memcpy_h2d(model->weight_arena.ptr, ab.data.data(), ab.data.size(), dev.stream));
     VX(vx_stream_sync(dev.stream));
-    return model.release();
 }
 
 void swin_output_dims(swin_model const& m, int w, int h, int dims[4][3]) {
@@ -134,47 +139,51 @@ void swin_output_dims(swin_model const& m, int w, int h, int dims[4][3]) {
     }
 }
 
+void timing_marks::mark(const char* name, double flops, double bytes, void* stream) {
+    void* ev = nullptr;
+    VX(vx_event_create(&ev));
+    VX(vx_event_record(ev, stream));
+    marks.push_back({name, ev});
+    acc.push_back({name, 0, 1, flops, bytes});
+}
+
+void timing_marks::finish(void* stream, std::vector<timing_entry>& out, bool append) {
+    void* ev = nullptr;
+    VX(vx_event_create(&ev));
+    VX(vx_event_record(ev, stream));
+    marks.push_back({"end", ev});
+    std::map<std::string, timing_entry> by;
+    std::vector<std::string> order;
+    if (append)
+        for (timing_entry const& t : out) { order.push_back(t.name); by[t.name] = t; }
+    for (size_t i = 0; i + 1 < marks.size(); ++i) {
+        float ms = 0;
+        VX(vx_event_elapsed_ms(marks[i].second, marks[i + 1].second, &ms));
+        auto it = by.find(marks[i].first);
+        if (it == by.end()) { order.push_back(marks[i].first); it = by.emplace(marks[i].first, timing_entry{marks[i].first, 0, 0, 0, 0}).first; }
+        it->second.ms += ms;
+        it->second.launches += acc[i].launches;
+        it->second.flops += acc[i].flops;
+        it->second.bytes += acc[i].bytes;
+    }
+    out.clear();
+    for (auto& n : order) out.push_back(by[n]);
+    for (auto& mk : marks) vx_event_destroy(mk.second);
+    marks.clear();
+    acc.clear();
+}
+
 namespace {
 
 struct swin_exec {
     swin_model& m;
     void* stream;
     const uint8_t* wa;
-    std::vector<std::pair<std::string, void*>> marks;
-    std::vector<timing_entry> acc;
+    timing_marks tm;
 
     const float* fptr(packed_vec const& v) const { return reinterpret_cast<const float*>(wa + v.off); }
-    void mark(const char* name, double flops, double bytes) {
-        if (!m.timing) return;
-        void* ev = nullptr;
-        VX(vx_event_create(&ev));
-        VX(vx_event_record(ev, stream));
-        marks.push_back({name, ev});
-        acc.push_back({name, 0, 1, flops, bytes});
-    }
-    void finish_timing() {
-        if (!m.timing) return;
-        void* ev = nullptr;
-        VX(vx_event_create(&ev));
-        VX(vx_event_record(ev, stream));
-        marks.push_back({"end", ev});
-        std::map<std::string, timing_entry> by;
-        std::vector<std::string> order;
-        for (size_t i = 0; i + 1 < marks.size(); ++i) {
-            float ms = 0;
-            VX(vx_event_elapsed_ms(marks[i].second, marks[i + 1].second, &ms));
-            auto it = by.find(marks[i].first);
-            if (it == by.end()) { order.push_back(marks[i].first); it = by.emplace(marks[i].first, timing_entry{marks[i].first, 0, 0, 0, 0}).first; }
-            it->second.ms += ms;
-            it->second.launches += acc[i].launches;
-            it->second.flops += acc[i].flops;
-            it->second.bytes += acc[i].bytes;
-        }
-        m.last_timing.clear();
-        for (auto& n : order) m.last_timing.push_back(by[n]);
-        for (auto& mk : marks) vx_event_destroy(mk.second);
-        marks.clear();
-    }
+    void mark(const char* name, double flops, double bytes) { if (m.timing) tm.mark(name, flops, bytes, stream); }
+    void finish_timing() { if (m.timing) tm.finish(stream, m.last_timing); }
     // win_ws > 0: rows are window tokens of a win_w x win_h map rolled by win_shift; out / res1 are addressed at their pixels
     void gemm(packed_gemm const& g, const void* A, long M, int lda, void* out, int epi, const void* res1, const char* group, int win_ws = 0,
               int win_w = 0, int win_h = 0, int win_shift = 0) {
@@ -205,8 +214,17 @@ struct swin_exec {
 
 void swin_encode_batch_device(swin_model& m, void const* rgb_dev, int B, int w, int h, void* const outs[4], void* stream) {
     if (B < 1 || !rgb_dev || !outs) throw except("swin: empty batch or null pointer");
-    for (int i = 0; i < 4; ++i)
+    swin_out so[4];
+    for (int i = 0; i < 4; ++i) {
         if (!outs[i]) throw except("swin: output %d is null", i);
+        so[i].ptr = outs[i];
+    }
+    swin_encode_pixels(m, nullptr, B, w, h, so, stream, rgb_dev);
+}
+
+// in8 == nullptr: pre-process rgb_dev (birefnet_process_input's normalisation, birefnet.cpp:259-270) into the workspace first
+void swin_encode_pixels(swin_model& m, void const* in8_arg, int B, int w, int h, swin_out const outs[4], void* stream, void const* rgb_dev) {
+    if (B < 1 || (!in8_arg && !rgb_dev)) throw except("swin: empty batch or null pointer");
     // patch 4, then three patch mergings that require even maps (swin.cpp:143)
     if (w < 32 || h < 32 || w % 32 || h % 32) throw except("swin: image extent %dx%d must be a positive multiple of 32", w, h);
     VX(vx_set_device(m.backend->index));
@@ -241,11 +259,13 @@ void swin_encode_batch_device(swin_model& m, void const* rgb_dev, int B, int w, 
     }
     uint8_t* base = static_cast<uint8_t*>(m.ws.ptr);
     void *x = base, *t1 = base + big, *t2 = base + 2 * big, *t3 = base + 3 * big;
-    void* in8 = base + 4 * big;
+    const void* in8 = in8_arg ? in8_arg : base + 4 * big;
 
-    swin_exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
-    ex.mark("preprocess", 0, (double)B * w * h * 19);
-    VX(vx_tv_preprocess(static_cast<const uint8_t*>(rgb_dev), in8, (int64_t)B * w * h, s)); // birefnet_process_input: same mean / std (birefnet.cpp:259-270)
+    swin_exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}};
+    if (!in8_arg) {
+        ex.mark("preprocess", 0, (double)B * w * h * 19);
+        VX(vx_tv_preprocess(static_cast<const uint8_t*>(rgb_dev), base + 4 * big, (int64_t)B * w * h, s)); // same mean / std as sam (birefnet.cpp:259-270)
+    }
     { // patch_embed (nn.cpp:166-180): 4x4 stride-4 conv as implicit GEMM on the 8-channel pixels, then LayerNorm
         packed_gemm const& g = Wt.patch_embed;
         vx_gemm_args a;
@@ -288,7 +308,7 @@ void swin_encode_batch_device(swin_model& m, void const* rgb_dev, int B, int w, 
             ex.capture("block_" + std::to_string(l) + "_" + std::to_string(bi), x, B, ch, cw, C);
         }
         ex.mark("layernorm", 0, (double)T * C * 6);
-        VX(vx_swin_layernorm_f16(x, ex.fptr(Wt.out_norm_w[l]), ex.fptr(Wt.out_norm_b[l]), outs[l], T, C, 1e-5f, 0, 0, 0, 0, 1, s)); // swin.cpp:255-258
+        VX(vx_swin_layernorm_strided_f16(x, ex.fptr(Wt.out_norm_w[l]), ex.fptr(Wt.out_norm_b[l]), outs[l].ptr, T, C, 1e-5f, outs[l].ld, outs[l].f32 ? 1 : 0, s)); // swin.cpp:255-258
         if (l < 3) { // patch_merging (swin.cpp:140-161)
             ex.mark("merge_layernorm", 0, (double)T * C * 4);
             VX(vx_swin_merge_layernorm_f16(x, ex.fptr(Wt.merge_norm_w[l]), ex.fptr(Wt.merge_norm_b[l]), t1, B, ch, cw, C, 1e-5f, s));

@@ -10,6 +10,14 @@
 
 namespace visp {
 
+// per-kernel-group timing of one pass (HIP events between launches), shared by the swin and birefnet executors
+struct timing_marks {
+    std::vector<std::pair<std::string, void*>> marks;
+    std::vector<timing_entry> acc;
+    void mark(const char* name, double flops, double bytes, void* stream);
+    void finish(void* stream, std::vector<timing_entry>& out, bool append = false);
+};
+
 struct swin_layer_t { int depth, n_heads, n_features; };
 struct swin_params { // vision.h swin_params; swin_t_params / swin_l_params of swin.cpp:264-291
     int embed_dim = 96, window_size = 7;
@@ -34,6 +42,7 @@ struct swin_weights {
 
 struct swin_model : model_base { // the encoder half of vision.h birefnet_model
     swin_model() : model_base(family_birefnet) {}
+    bool full = false; // true: this object is a birefnet_model (birefnet.h) -- encoder + decoder
     backend_device const* backend = nullptr;
     swin_params params;
     swin_weights weights;
@@ -42,10 +51,17 @@ struct swin_model : model_base { // the encoder half of vision.h birefnet_model
     bool timing = false, captures = false;
     std::vector<timing_entry> last_timing;
     std::map<std::string, capture_entry> capture_bufs;
-    ~swin_model();
+    virtual ~swin_model();
 };
 
 swin_model* swin_load_model(char const* filepath, backend_device const& dev, char const* prefix = "bb");
+void swin_load_into(swin_model& model, model_file const& file, backend_device const& dev, char const* prefix); // weights of an open file
+
+// one output of the encoder: row stride ld (elements; 0 = C), f32 or f16 -- lets a caller write a stage straight into a wider
+// concatenation buffer (birefnet::encode_concat)
+struct swin_out { void* ptr = nullptr; int ld = 0; bool f32 = true; };
+// the encoder on already pre-processed pixels: in8 = f16 [B, h, w, 8] (value + residue, vx_tv_preprocess layout)
+void swin_encode_pixels(swin_model& m, void const* in8, int B, int w, int h, swin_out const outs[4], void* stream, void const* rgb_dev = nullptr);
 // dims[i] = {w_i, h_i, C_i} of the four outputs for an image of extent (w, h)
 void swin_output_dims(swin_model const& m, int w, int h, int dims[4][3]);
 // rgb_u8 [B, h, w, 3] in device memory -> outs[i] f32 [B, h_i, w_i, C_i] (NHWC = the reference's CWHN tensors); w, h multiples of

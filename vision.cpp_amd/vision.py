@@ -193,6 +193,24 @@ class Model:
                 for i in range(n.value)]
 
 
+    # ---- BiRefNet (family 1): batched extension
+    def birefnet_image_extent(self, w: int, h: int):
+        ow, oh = c_int32(), c_int32()
+        check(self._api.visp_birefnet_image_extent(self._handle, w, h, byref(ow), byref(oh)))
+        return ow.value, oh.value
+
+    def segment_batch(self, images: np.ndarray) -> np.ndarray:
+        """images: uint8 [B, h, w, 3] at the model extent -> sigmoid masks f32 [B, h, w] (birefnet_predict per image)."""
+        imgs = np.ascontiguousarray(images, dtype=np.uint8)
+        b, h, w, c = imgs.shape
+        assert c == 3
+        out = np.empty((b, h, w), np.float32)
+        check(self._api.visp_birefnet_compute_batch_host(self._handle, imgs.ctypes.data, b, w, h, out.ctypes.data))
+        return out
+
+    def segment_batch_device(self, rgb_dev: int, batch: int, w: int, h: int, mask_dev: int, stream: int | None = None):
+        check(self._api.visp_birefnet_compute_batch_device(self._handle, rgb_dev, batch, w, h, mask_dev, stream))
+
     # ---- ESRGAN (family 4): batched extension
     @property
     def esrgan_info(self) -> lib.EsrganInfo:
