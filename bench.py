@@ -46,9 +46,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["depthany", "esrgan", "sam", "swin"], default="depthany",
+    ap.add_argument("--workload", choices=["depthany", "esrgan", "sam", "swin", "birefnet"], default="depthany",
                     help="depthany = the headline metric (BASELINE.json configs[1]); esrgan = configs[2], the next SURVEY section 8 row")
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 for depthany, 16 for esrgan, 128 for sam, 8 for swin)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 for depthany, 16 for esrgan, 128 for sam, 8 for swin and birefnet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--min-seconds", type=float, default=10.0, help="soak: after the K timed steps keep stepping for this long and report that rate too (0 = skip)")
@@ -88,8 +88,8 @@ def main():
         torch.cuda.synchronize()
 
     api = L.get_lib()
-    if args.workload in ("esrgan", "sam", "swin"):
-        {"esrgan": run_esrgan, "sam": run_sam, "swin": run_swin}[args.workload](args, torch, dist, rank, world, device_index, barrier, api)
+    if args.workload in ("esrgan", "sam", "swin", "birefnet"):
+        {"esrgan": run_esrgan, "sam": run_sam, "swin": run_swin, "birefnet": run_birefnet}[args.workload](args, torch, dist, rank, world, device_index, barrier, api)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -686,6 +686,115 @@ def run_swin(args, torch, dist, rank, world, device_index, barrier, api):
         res["cpu_baseline"] = {"value": round(n / dt, 4), "unit": "images/s", "cores": args.cpu_threads, "kind": "port",
                                "sample": f"{n} images 1024x1024, OpenMP {args.cpu_threads} threads, oracle/libvisp_oracle.so (vo_swin_encode)",
                                "max_rel_err_gpu_vs_cpu": round(max(errs), 5)}
+    print(json.dumps(res), flush=True)
+
+
+def run_birefnet(args, torch, dist, rank, world, device_index, barrier, api):
+    """A step = birefnet_process_input's normalisation + birefnet_predict (birefnet.cpp:252-260: two-scale SWIN-T encode, squeeze
+    block, deformable-conv decoder -> sigmoid mask) for a batch of synthetic rgb_u8 images resident in HBM: BASELINE.json
+    configs[3] (BiRefNet-lite, 1024x1024, batch 64 over 8 GPUs = 8 images per GPU and step). Ranks take whole images, no collective."""
+    import dataclasses
+
+    B, S = args.batch or 8, 1024
+    cfg = dataclasses.replace(synth.SWIN_T, image_size=S)
+    tmp = Path(tempfile.gettempdir()) / f"visp_bench_birefnet_lite_f16_{os.environ.get('MASTER_PORT', '0')}.gguf"
+    if rank == 0:
+        synth.write_birefnet_gguf(tmp, cfg, seed=4)
+    barrier()
+    dev = vision.Device.init(index=device_index)
+    model = vision.Model.load(tmp, dev, vision.Arch.birefnet)  # 100 MB of weights: every rank reads the file
+    imgs = synth.images(min(B, 2), S, S, seed=77 + 100 * rank)
+    imgs = np.concatenate([imgs] * ((B + len(imgs) - 1) // len(imgs)))[:B]
+    src = torch.from_numpy(imgs).cuda()
+    out = torch.empty((B, S, S), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream().cuda_stream
+
+    def step():
+        model.segment_batch_device(src.data_ptr(), B, S, S, out.data_ptr(), stream)
+
+    groups = []
+    if rank == 0:
+        step()
+        torch.cuda.synchronize()
+        model.enable_timing(True)
+        step()
+        torch.cuda.synchronize()
+        groups = sorted(model.read_timing(), key=lambda g: -g["ms"])
+        model.enable_timing(False)
+        if args.profile_groups:
+            tot = sum(g["ms"] for g in groups)
+            print(f"{'group':16s} {'ms':>8s} {'%':>6s} {'launch':>6s} {'TFLOP/s':>9s} {'GB/s':>9s}", file=sys.stderr)
+            for g in groups:
+                print(f"{g['name']:16s} {g['ms']:8.3f} {100 * g['ms'] / tot:6.1f} {g['launches']:6d} "
+                      f"{g['flops'] / g['ms'] / 1e9:9.1f} {g['bytes'] / g['ms'] / 1e6:9.1f}", file=sys.stderr)
+            print(f"{'total':16s} {tot:8.3f}", file=sys.stderr)
+    for _ in range(args.warmup):
+        step()
+    ev = StepEvents(api, stream, args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev.mark()
+        step()
+    ev.mark()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    step_ms = ev.step_ms()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all() and o.min() >= 0 and o.max() <= 1 and o.std() > 1e-3, "invalid output"
+    if rank != 0:
+        return
+    value = world * B * args.steps / elapsed
+    gflop = sum(g["flops"] for g in groups) / B / 1e9 if groups else None
+    res = {
+        "metric": "images/sec, BiRefNet-lite (SWIN-T) 1024x1024 f16",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "step_ms_device": {"mean": round(float(np.mean(step_ms)), 3), "std": round(float(np.std(step_ms)), 3), "min": round(float(np.min(step_ms)), 3),
+                           "note": "rank 0, HIP events at the step boundaries of the same timed region"},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"BiRefNet-lite f16 (SWIN-T shifted-window attention, deformable-conv decoder) 1024x1024, batch={B} per MI355X "
+                               "(BASELINE.json configs[3]: batch 64 over 8 GPUs)",
+                   "images_per_gpu_per_step": B, "global_batch": world * B, "weights": "random-init synthetic GGUF (seed 4)",
+                   "parallelism": f"dp{world} (image shards, no data-path collective)"},
+        "model_gflop_per_image": round(gflop, 2) if gflop else None,
+        "model_tflops": round(value * gflop / 1e3, 2) if gflop else None,
+    }
+    if groups:
+        tot = sum(g["ms"] for g in groups)
+        dom = groups[0]
+        hbm_bound = dom["flops"] / max(dom["bytes"], 1) < PEAK_MFMA_F16 / PEAK_HBM
+        if hbm_bound:
+            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            res["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                               "frac": round(ach * 1e9 / PEAK_HBM, 4), "traffic": None}
+        else:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
+                               "frac": round(ach * 1e12 / PEAK_MFMA_F16, 4), "traffic": None}
+        res["roofline"]["avg_launch_ms"] = round(dom["ms"] / max(dom["launches"], 1), 4)
+        res["roofline"]["launches_per_step"] = dom["launches"]
+        res["roofline"]["share_of_step"] = round(dom["ms"] / tot, 3)
+        res["kernel_groups_ms"] = {g["name"]: round(g["ms"], 3) for g in groups}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+
+        tensors, conv2d = synth.birefnet_gguf_tensors(synth.birefnet_state_dict(cfg, 4))
+        om = oracle.Model(tensors, conv2d)
+        P = oracle.swin_params(cfg.embed_dim, cfg.window_size, cfg.depths, cfg.n_heads)
+        oracle.set_num_threads(args.cpu_threads)
+        mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+        t0 = time.perf_counter()
+        want = oracle.birefnet_predict(om, P, ((imgs[0].astype(np.float32) / 255.0 - mean) / std).astype(np.float32))
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(1 / dt, 4), "unit": "images/s", "cores": args.cpu_threads, "kind": "port",
+                               "sample": f"1 image 1024x1024, OpenMP {args.cpu_threads} threads, oracle/libvisp_oracle.so (vo_birefnet_predict)",
+                               "mask_mae_gpu_vs_cpu": round(float(np.abs(o[0] - want).mean()), 6), "mask_max_abs_diff_gpu_vs_cpu": round(float(np.abs(o[0] - want).max()), 5)}
     print(json.dumps(res), flush=True)
 
 

@@ -226,7 +226,7 @@ VX_API int vx_bf_resize_f16(const void* src, int lds, void* dst, int ldd, int B,
  * [B*h*w, ldom] = per pixel 2 k^2 offsets (dy, dx per tap) then k^2 modulator logits; cols [B*h*w, k*k*C] = 2 sigmoid(mod) * sample */
 VX_API int vx_bf_deform_cols_f16(const void* x, const void* offmod, int ldom, void* cols, int B, int h, int w, int C, int k, void* stream);
 /* per-image pixel mean [B, n, C] (row stride ld) -> [B, C]; broadcast of [B, C] rows to every pixel of a slice; y *= sigmoid(a); final mask */
-VX_API int vx_bf_mean_f16(const void* x, int ld, void* y, int B, int64_t n, int C, void* stream);
+VX_API int vx_bf_mean_f16(const void* x, int ld, void* y, float* acc_scratch /*f32 [B*C]*/, int B, int64_t n, int C, void* stream);
 VX_API int vx_bf_broadcast_f16(const void* g, int ldg, void* dst, int ldd, int B, int64_t n, int C, void* stream);
 VX_API int vx_bf_mul_sigmoid_f16(void* y, int ldy, const void* a, int lda, int64_t rows, int C, void* stream);
 VX_API int vx_bf_sigmoid_out_f32(const void* a, int lda, float* out, int64_t n, void* stream);

@@ -98,10 +98,10 @@ def test_deformable_conv_as_composed_on_the_device(k):
 
 def test_mean_broadcast_mul_sigmoid():
     rng = np.random.default_rng(0)
-    B, n, Cc = 3, 150, 72
+    B, n, Cc = 3, 5000, 72
     x = rng.standard_normal((B, n, Cc)).astype(np.float16)
     y = empty(B * Cc * 2)
-    L.vx_check(api().vx_bf_mean_f16(dev(x).ptr, Cc, y.ptr, B, n, Cc, None))
+    L.vx_check(api().vx_bf_mean_f16(dev(x).ptr, Cc, y.ptr, empty(B * Cc * 4).ptr, B, n, Cc, None))
     sync()
     assert np.abs(y.to_numpy(np.float16, (B, Cc)).astype(np.float32) - x.astype(np.float32).mean(1)).max() < 2e-3
     g = rng.standard_normal((B, Cc)).astype(np.float16)
@@ -153,6 +153,25 @@ def test_birefnet_every_level(mini):
     model.enable_captures(False)
     again = model.segment_batch(imgs[::-1].copy())
     np.testing.assert_array_equal(again[::-1], masks)  # images are independent units; repeated launches are bit-identical
+
+
+def test_birefnet_lite_configuration(device, tmp_path):
+    """BiRefNet-lite's shape (swin_t backbone: features 192 / 384 / 768 / 2880 channels, decoder table of
+    tests/test_birefnet.py:1130-1175) on one 256 x 256 image."""
+    cfg = dataclasses.replace(synth.SWIN_T, image_size=256)
+    sd = synth.birefnet_state_dict(cfg, 9)
+    model = vision.Model.load(synth.write_birefnet_gguf(tmp_path / "lite.gguf", cfg, sd=sd), device)
+    tensors, conv_idx = synth.birefnet_gguf_tensors(sd)
+    om = oracle.Model(tensors, conv_idx)
+    P = oracle.swin_params(cfg.embed_dim, cfg.window_size, cfg.depths, cfg.n_heads)
+    img = synth.images(1, 256, 256, seed=13)
+    model.enable_captures(True)
+    mask = model.segment_batch(img)[0]
+    want, caps = oracle.birefnet_predict(om, P, _pre(img[0]), captures={"feature_3": 8 * 8 * 2880, "squeeze": 8 * 8 * 1536, "p1": 64 * 64 * 96})
+    for name, tol in (("feature_3", 2e-2), ("squeeze", 3e-2), ("p1", 4e-2)):
+        got = model.read_capture(name)[0].reshape(-1)
+        assert rel_err(got, caps[name]) < tol, (name, rel_err(got, caps[name]))
+    assert np.abs(mask - want).max() < 3e-2 and np.abs(mask - want).mean() < 3e-3, np.abs(mask - want).max()
 
 
 def test_reference_c_api_compute(mini):

@@ -260,7 +260,7 @@ def init() -> ctypes.CDLL:
     lib.vx_bf_patches.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_bf_resize_f16.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_bf_deform_cols_f16.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
-    lib.vx_bf_mean_f16.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]
+    lib.vx_bf_mean_f16.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]
     lib.vx_bf_broadcast_f16.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]
     lib.vx_bf_mul_sigmoid_f16.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]
     lib.vx_bf_sigmoid_out_f32.argtypes = [c_void_p, c_int, c_void_p, c_int64, c_void_p]

@@ -186,13 +186,14 @@ void decoder_block(bf_exec& ex, bf_block_weights const& bw, const void* x, int B
     { // global_avg_pool (birefnet.cpp:94-108, 128-133)
         void* mean = ex.take((size_t)std::max(B, 8) * bw.inter * 2 + 4096);
         void* g = ex.take((size_t)std::max(B, 8) * bw.planes * 2 + 4096);
+        void* acc = ex.take((size_t)B * bw.inter * 4);
         if (!ex.dry) {
-            ex.mark("dec_glue", 0, (double)M * bw.inter * 2);
-            VX(vx_bf_mean_f16(a, bw.inter, mean, B, (int64_t)h * w, bw.inter, ex.stream));
+            ex.mark("dec_mean", 0, (double)M * bw.inter * 2);
+            VX(vx_bf_mean_f16(a, bw.inter, mean, static_cast<float*>(acc), B, (int64_t)h * w, bw.inter, ex.stream));
         }
         ex.gemm(bw.gap, mean, B, bw.inter, g, bw.planes, VX_EPI_F16_RELU, nullptr, "dec_conv1x1");
         if (!ex.dry) {
-            ex.mark("dec_glue", 0, (double)M * bw.planes * 2);
+            ex.mark("dec_broadcast", 0, (double)M * bw.planes * 2);
             VX(vx_bf_broadcast_f16(g, bw.planes, bf_exec::off16(cat, (size_t)4 * bw.planes), ldc, B, (int64_t)h * w, bw.planes, ex.stream));
         }
     }
@@ -350,7 +351,7 @@ void birefnet_compute_batch_device(birefnet_model& m, void const* rgb_dev, int B
                 void* patches = ex.take((size_t)M * cp * 2);
                 void* t = ex.take((size_t)M * c1 * 2);
                 if (!dry) {
-                    ex.mark("dec_glue", 0, (double)B * w * h * 3 + (double)M * cp * 2);
+                    ex.mark("dec_patches", 0, (double)B * w * h * 3 + (double)M * cp * 2);
                     VX(vx_bf_patches(rgb, patches, B, h, w, lh, lw, s));
                 }
                 ex.conv(D.ipt[i].conv1, patches, B, lh, lw, cp, 3, 1, t, c1, VX_EPI_F16, "ipt_conv3x3");
@@ -367,7 +368,7 @@ void birefnet_compute_batch_device(birefnet_model& m, void const* rgb_dev, int B
                 ex.conv(D.gdt[i], y, B, lh, lw, bw.cout, 3, 1, g, cg, VX_EPI_F16_RELU, "dec_conv3x3");
                 ex.gemm(D.gdt_attn[i], g, M, cg, a, 8, VX_EPI_F16, nullptr, "dec_conv1x1");
                 if (!dry) {
-                    ex.mark("dec_glue", 0, (double)M * bw.cout * 4);
+                    ex.mark("dec_gdt_mul", 0, (double)M * bw.cout * 4);
                     VX(vx_bf_mul_sigmoid_f16(y, bw.cout, a, 8, M, bw.cout, s));
                 }
                 ex.cur = mark1;
@@ -393,7 +394,7 @@ void birefnet_compute_batch_device(birefnet_model& m, void const* rgb_dev, int B
             ex.conv(D.ipt[4].conv_out, t, B, h, w, c1, 3, 1, bf_exec::off16(X, (size_t)cc), ct, VX_EPI_F16, "ipt_conv3x3");
             ex.gemm(D.conv_out1, X, M, ct, a, 8, VX_EPI_F16, nullptr, "dec_conv1x1");
             if (!dry) {
-                ex.mark("dec_glue", 0, (double)M * 6);
+                ex.mark("mask_out", 0, (double)M * 6);
                 VX(vx_bf_sigmoid_out_f32(a, 8, static_cast<float*>(mask_dev), M, s));
             }
         }

@@ -51,17 +51,28 @@ __global__ __launch_bounds__(256) void bf_preprocess_half_kernel(const unsigned 
     *reinterpret_cast<f16x8*>(out + i * 8) = o;
 }
 
-// patches [B, h, w, gw*gh*3]: channel gx + gw (gy + gh c) of pixel (py, px) = normalised image (gy h + py, gx w + px, c)
+// patches [B, h, w, gw*gh*3]: channel gx + gw (gy + gh c) of pixel (py, px) = normalised image (gy h + py, gx w + px, c).
+// A thread writes 8 consecutive channels (16 bytes); gw*gh*3 is a multiple of 8 for the grids in use (4 .. 32), else scalar tail.
 __global__ __launch_bounds__(256) void bf_patches_kernel(const unsigned char* __restrict__ rgb, f16* __restrict__ out, int B, int IH, int IW, int h, int w) {
-    const int gw = IW / w, gh = IH / h, CP = gw * gh * 3;
+    const int gw = IW / w, gh = IH / h, CP = gw * gh * 3, c8 = (CP + 7) / 8;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * h * w * CP) return;
-    const int ch = (int)(i % CP);
-    const long pix = i / CP;
+    if (i >= (long)B * h * w * c8) return;
+    const int ch0 = (int)(i % c8) * 8;
+    const long pix = i / c8;
     const int px = (int)(pix % w), py = (int)((pix / w) % h);
     const long b = pix / ((long)w * h);
-    const int gx = ch % gw, gy = (ch / gw) % gh, c = ch / (gw * gh);
-    out[i] = (f16)norm_px(rgb[((b * IH + (long)gy * h + py) * IW + (long)gx * w + px) * 3 + c], c);
+    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = ch0 + j;
+        if (ch < CP) {
+            const int gx = ch % gw, gy = (ch / gw) % gh, c = ch / (gw * gh);
+            o[j] = (f16)norm_px(rgb[((b * IH + (long)gy * h + py) * IW + (long)gx * w + px) * 3 + c], c);
+        }
+    }
+    if (ch0 + 8 <= CP) *reinterpret_cast<f16x8*>(out + pix * CP + ch0) = o;
+    else
+        for (int j = 0; ch0 + j < CP; ++j) out[pix * CP + ch0 + j] = o[j];
 }
 
 // bilinear, align_corners, f16 NHWC; src row stride lds, dst row stride ldd (elements); C % 8 == 0
@@ -126,16 +137,24 @@ __global__ __launch_bounds__(256) void bf_deform_cols_kernel(const f16* __restri
     *reinterpret_cast<f16x8*>(cols + pt * C + ch) = r;
 }
 
-// mean over the pixels of each image: x [B, n, C] (row stride ld) -> y [B, C]; one block per (image, 64-channel group)
-__global__ __launch_bounds__(256) void bf_mean_kernel(const f16* __restrict__ x, int ld, f16* __restrict__ y, long n, int C) {
+// mean over the pixels of each image: x [B, n, C] (row stride ld) -> y [B, C]. Stage 1: one block per (image, 64-channel group,
+// chunk of 256 pixels) adds its partial sums to f32 accumulators (a 256^2 map is 256 chunks per image: the whole chip reads it);
+// stage 2 divides and converts.
+constexpr int MEAN_CHUNK = 256; // 64 dependent loads per thread: short enough to be bandwidth- rather than latency-bound
+__global__ __launch_bounds__(256) void bf_mean_partial_kernel(const f16* __restrict__ x, int ld, float* __restrict__ acc, long n, int C) {
     __shared__ float part[4][64];
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    const long p0 = (long)blockIdx.z * MEAN_CHUNK, p1 = min(p0 + MEAN_CHUNK, n);
     float s = 0.0f;
     if (c < C)
-        for (long p = slice; p < n; p += 4) s += (float)x[((long)b * n + p) * ld + c];
+        for (long p = p0 + slice; p < p1; p += 4) s += (float)x[((long)b * n + p) * ld + c];
     part[slice][threadIdx.x & 63] = s;
     __syncthreads();
-    if (slice == 0 && c < C) y[(long)b * C + c] = (f16)((part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)n);
+    if (slice == 0 && c < C) atomicAdd(acc + (long)b * C + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void bf_mean_finish_kernel(const float* __restrict__ acc, f16* __restrict__ y, long n, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total) y[i] = (f16)(acc[i] / (float)n);
 }
 
 // dst[b, p, 0:C] (row stride ldd) = g[b, 0:C] for every pixel p of image b (bilinear "interpolation" of a 1 x 1 map)
@@ -180,7 +199,7 @@ int vx_bf_preprocess_half(const uint8_t* rgb, void* out8, int B, int H, int W, v
 
 int vx_bf_patches(const uint8_t* rgb, void* out, int B, int IH, int IW, int h, int w, void* stream) {
     VX_REQUIRE(rgb && out && B > 0 && h > 0 && w > 0 && IH % h == 0 && IW % w == 0, "vx_bf_patches: grid %dx%d must divide the image %dx%d", w, h, IW, IH);
-    const long n = (long)B * h * w * (IW / w) * (IH / h) * 3;
+    const long n = (long)B * h * w * (((IW / w) * (IH / h) * 3 + 7) / 8);
     hipLaunchKernelGGL(bf_patches_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), rgb, reinterpret_cast<f16*>(out), B, IH, IW, h, w);
     VX_LAUNCH_CHECK();
     return 1;
@@ -206,9 +225,13 @@ int vx_bf_deform_cols_f16(const void* x, const void* offmod, int ldom, void* col
     return 1;
 }
 
-int vx_bf_mean_f16(const void* x, int ld, void* y, int B, int64_t n, int C, void* stream) {
-    VX_REQUIRE(x && y && B > 0 && n > 0 && C > 0 && ld >= C, "vx_bf_mean_f16: bad operands");
-    hipLaunchKernelGGL(bf_mean_kernel, dim3((C + 63) / 64, B), dim3(256), 0, as_stream(stream), reinterpret_cast<const f16*>(x), ld, reinterpret_cast<f16*>(y), (long)n, C);
+int vx_bf_mean_f16(const void* x, int ld, void* y, float* acc_scratch, int B, int64_t n, int C, void* stream) {
+    VX_REQUIRE(x && y && acc_scratch && B > 0 && n > 0 && C > 0 && ld >= C, "vx_bf_mean_f16: bad operands");
+    hipStream_t s = as_stream(stream);
+    VX_CHECK(hipMemsetAsync(acc_scratch, 0, (size_t)B * C * 4, s));
+    const unsigned chunks = (unsigned)((n + MEAN_CHUNK - 1) / MEAN_CHUNK);
+    hipLaunchKernelGGL(bf_mean_partial_kernel, dim3((C + 63) / 64, B, chunks), dim3(256), 0, s, reinterpret_cast<const f16*>(x), ld, acc_scratch, (long)n, C);
+    hipLaunchKernelGGL(bf_mean_finish_kernel, dim3(blocks_for((long)B * C)), dim3(256), 0, s, acc_scratch, reinterpret_cast<f16*>(y), (long)n, B * C);
     VX_LAUNCH_CHECK();
     return 1;
 }
