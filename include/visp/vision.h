@@ -5,7 +5,7 @@
 // Header-only over the binary-stable C ABI (include/visp_c_api.h, lib/libvisioncpp.so): link with -lvisioncpp.
 //
 // Covered: backend_init / backend_device, image_view / image_data / image_alloc / image_clear / image_scale, and per family
-// *_load_model + *_compute for depth_anything, esrgan and sam (sam_encode + sam_compute with a point or a box).
+// *_load_model + *_compute for depth_anything, esrgan, birefnet and sam (sam_encode + sam_compute with a point or a box).
 // Not covered (this backend has no graph IR): the ml.h layer -- compute_graph, model_ref, tensor -- and
 // the *_process_input / *_predict graph pieces built on it; birefnet_* and migan_* (families not built).
 #pragma once
@@ -173,6 +173,11 @@ inline image_data depthany_compute(depthany_model& model, image_view image) { //
 using esrgan_model = detail::model_handle<VISP_ESRGAN>;
 inline esrgan_model esrgan_load_model(char const* filepath, backend_device const& dev) { return esrgan_model(detail::load<VISP_ESRGAN>(filepath, dev)); }
 inline image_data esrgan_compute(esrgan_model& model, image_view image) { return detail::compute<VISP_ESRGAN>(model.handle, image); }
+
+// BiRefNet (vision.h birefnet_*; vision.cpp:98-132): any 8-bit colour image -> alpha_u8 foreground mask at the input extent
+using birefnet_model = detail::model_handle<VISP_BIREFNET>;
+inline birefnet_model birefnet_load_model(char const* filepath, backend_device const& dev) { return birefnet_model(detail::load<VISP_BIREFNET>(filepath, dev)); }
+inline image_data birefnet_compute(birefnet_model& model, image_view image) { return detail::compute<VISP_BIREFNET>(model.handle, image); }
 
 // MobileSAM (vision.h:139-160): sam_encode once per image, then any number of prompts (vision.cpp:26-92) -> alpha_u8 mask
 using sam_model = detail::model_handle<VISP_SAM>;
