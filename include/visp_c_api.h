@@ -5,8 +5,8 @@
  * reference's C API (reference src/visp/c-api.cpp:145-253), i.e. exactly what the reference's
  * ctypes binding (bindings/python/visioncpp/_lib.py:118-171) binds. Return value 1 = ok,
  * 0 = error with the message available from visp_get_last_error() (thread-local,
- * c-api.cpp:6-21). Built behind it: depth_anything, esrgan and sam (MobileSAM: image encoder + prompt encoder / mask decoder);
- * birefnet and migan return an error ("not built in this backend").
+ * c-api.cpp:6-21). Built behind it: depth_anything, esrgan, sam (MobileSAM: image encoder + prompt encoder / mask decoder) and
+ * birefnet (swin-T / BiRefNet-lite); migan returns an error ("not built in this backend").
  *
  * Part 2 is the batched, device-resident extension the reference does not have (its
  * depthany_compute is batch 1, src/visp/vision.cpp:155): it is what bench.py and a
