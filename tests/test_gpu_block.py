@@ -87,10 +87,9 @@ def reference(w, x, att, eps, mlp, tap, qkv, T, q_scale):
     return out
 
 
-@pytest.fixture(params=["vx_dino_block_f16", "vx_dino_block2_f16"], ids=["one-wave", "wave-pair"])
-def block_fn(request):
-    """Both forms of the kernel: one wave per SIMD (kernels_block.hip) and the producer / consumer wave pair (kernels_block2.hip)."""
-    return getattr(api(), request.param)
+@pytest.fixture
+def block_fn():
+    return api().vx_dino_block_f16
 
 
 @pytest.mark.parametrize("M,T,mlp,tap,qkv", [

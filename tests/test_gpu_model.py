@@ -279,7 +279,7 @@ def test_errors(small, device, tmp_path):
         L.check(api.visp_model_compute(small._handle, 2, v, 2, None, 0, C.byref(L.ImageView()), C.byref(C.c_void_p())))
     with pytest.raises(L.Error, match="not built in this backend"):
         h = C.c_void_p()
-        L.check(api.visp_model_load(b"/x.gguf", device._handle, 1, C.byref(h)))  # birefnet: a family this backend does not build
+        L.check(api.visp_model_load(b"/x.gguf", device._handle, 3, C.byref(h)))  # migan: a family this backend does not build
     with pytest.raises(L.Error, match="Failed to load GGUF model"):
         vision.Model.load(tmp_path / "missing.gguf", device, vision.Arch.depth_anything)
 

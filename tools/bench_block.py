@@ -13,7 +13,7 @@ from bench_kernels import api, gemm_case, stream, timeit, L, DeviceBuffer  # noq
 D, HID, H, T = 384, 1536, 6, 1370
 
 
-def block_case(B, mlp=True, tap=False, qkv=True, fn="vx_dino_block_f16", no_dma=False):
+def block_case(B, mlp=True, tap=False, qkv=True, fn="vx_dino_block_f16"):
     M = B * T
     rng = np.random.default_rng(0)
     f16 = lambda *s, sc=1.0: np.ascontiguousarray((rng.standard_normal(s) * sc).astype(np.float16))  # noqa: E731
@@ -39,13 +39,10 @@ def block_case(B, mlp=True, tap=False, qkv=True, fn="vx_dino_block_f16", no_dma=
         a.feat, a.vec_tap = feat.ptr, bufs[4].ptr
     if qkv:
         a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, bufs[1].ptr, bufs[3].ptr
-    if no_dma:  # kernels_block2.hip diagnostic: a non-null stamps pointer switches the weight stream off
-        a.stamps = x.ptr
     launch = getattr(api, fn)
     ms = timeit(lambda: L.vx_check(launch(C.byref(a), stream)))
     flops = 2.0 * M * D * ((D + 2 * HID) * mlp + 3 * D * qkv)
-    tag = " (no weight stream)" if no_dma else ""
-    print(f"{fn}{tag} B={B} M={M} mlp={int(mlp)} tap={int(tap)} qkv={int(qkv)}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  ({-(-M // 128)} workgroups)", flush=True)
+    print(f"{fn} B={B} M={M} mlp={int(mlp)} tap={int(tap)} qkv={int(qkv)}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  ({-(-M // 128)} workgroups)", flush=True)
     return ms
 
 
@@ -59,12 +56,6 @@ if __name__ == "__main__" and "--pmc" in sys.argv:
 
 if __name__ == "__main__" and "--stamps" not in sys.argv:
     for rnd in range(2):
-        for fn2 in ("vx_dino_block2_f16",):
-            block_case(23, fn=fn2)
-            block_case(23, fn=fn2, no_dma=True)
-            block_case(32, fn=fn2)
-            block_case(32, mlp=False, fn=fn2)
-            block_case(32, qkv=False, tap=True, fn=fn2)
         block_case(23)          # 247 workgroups: one round on 256 CUs
         block_case(32)          # 343 workgroups: the north-star batch, two rounds
         block_case(32, tap=True)
