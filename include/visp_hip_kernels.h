@@ -275,6 +275,11 @@ VX_API size_t vx_dino_block_qkv_bytes(void);
 VX_API int vx_dino_block_pack_mlp(const void* wo, const void* w1, const void* w2, void* out);
 VX_API int vx_dino_block_pack_qkv(const void* wqkv, void* out);
 VX_API int vx_dino_block_f16(const vx_dino_block_args* args, void* stream);
+/* the same operation on v_mfma_f32_16x16x32_f16 with 16 tokens per wave and two waves per SIMD (kernels_block16.hip); same
+ * argument block and vectors, its own slab contents (same sizes: vx_dino_block_mlp_bytes / _qkv_bytes) */
+VX_API int vx_dino_block16_pack_mlp(const void* wo, const void* w1, const void* w2, void* out);
+VX_API int vx_dino_block16_pack_qkv(const void* wqkv, void* out);
+VX_API int vx_dino_block16_f16(const vx_dino_block_args* args, void* stream);
 
 /* ---- LayerNorm (nn.cpp:14-19): x f32 [M,C] -> y f16 [M,C]; biased variance, eps in sqrt --- */
 VX_API int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y, int M, int C,

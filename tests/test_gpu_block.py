@@ -49,14 +49,15 @@ def make_weights(seed, lam=0.1):
     return w
 
 
-def pack(w):
+def pack(w, fn=None):
     a = api()
+    pack_mlp, pack_qkv = (fn.pack_mlp, fn.pack_qkv) if fn is not None else (a.vx_dino_block_pack_mlp, a.vx_dino_block_pack_qkv)
     mlp = np.zeros(a.vx_dino_block_mlp_bytes() // 2, np.uint16)
     qkv = np.zeros(a.vx_dino_block_qkv_bytes() // 2, np.uint16)
     f16 = lambda m: np.ascontiguousarray(m.astype(np.float16))  # noqa: E731
     wo, w1, w2, wq = f16(w["wo"]), f16(w["w1"]), f16(w["w2"]), f16(w["wqkv"])
-    L.vx_check(a.vx_dino_block_pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, mlp.ctypes.data))
-    L.vx_check(a.vx_dino_block_pack_qkv(wq.ctypes.data, qkv.ctypes.data))
+    L.vx_check(pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, mlp.ctypes.data))
+    L.vx_check(pack_qkv(wq.ctypes.data, qkv.ctypes.data))
     vec_mlp = np.concatenate([w["bo"], w["lam1"], w["g2"], w["b2"], w["b1"], w["bfc2"], w["lam2"]]).astype(np.float32)
     vec_qkv = np.concatenate([w["gn"], w["bn"], w["bqkv"]]).astype(np.float32)
     vec_tap = np.concatenate([w["gf"], w["bf"]]).astype(np.float32)
@@ -87,9 +88,14 @@ def reference(w, x, att, eps, mlp, tap, qkv, T, q_scale):
     return out
 
 
-@pytest.fixture
-def block_fn():
-    return api().vx_dino_block_f16
+@pytest.fixture(params=["vx_dino_block", "vx_dino_block16"], ids=["32-token", "16-token"])
+def block_fn(request):
+    """Both forms of the kernel (kernels_block.hip: 32 tokens per wave, one wave per SIMD; kernels_block16.hip: 16 tokens per wave,
+    two waves per SIMD); each has its own weight packers, the launch carries them along for pack()."""
+    a = api()
+    fn = getattr(a, request.param + "_f16")
+    fn.pack_mlp, fn.pack_qkv = getattr(a, request.param + "_pack_mlp"), getattr(a, request.param + "_pack_qkv")
+    return fn
 
 
 @pytest.mark.parametrize("M,T,mlp,tap,qkv", [
@@ -107,7 +113,7 @@ def test_block_vs_oracle(block_fn, M, T, mlp, tap, qkv):
     eps, q_scale = 1e-6, 0.125
     want = reference(w, x0, att, eps, mlp, tap, qkv, T, q_scale)
 
-    d_mlp, d_qkv, v_mlp, v_qkv, v_tap = pack(w)
+    d_mlp, d_qkv, v_mlp, v_qkv, v_tap = pack(w, block_fn)
     xd = dev(x0)
     attd = dev(att.astype(np.float16))
     cap = empty(M * D * 4)
@@ -148,7 +154,7 @@ def test_block_rows_are_independent(block_fn):
     w = make_weights(9)
     x = (rng.standard_normal((M2, D)) * 1.5).astype(np.float32)
     att = rng.standard_normal((M2, D)).astype(np.float16)
-    d_mlp, d_qkv, v_mlp, v_qkv, v_tap = pack(w)
+    d_mlp, d_qkv, v_mlp, v_qkv, v_tap = pack(w, block_fn)
 
     def run(xs, atts):
         M = xs.shape[0]

@@ -20,8 +20,9 @@ def block_case(B, mlp=True, tap=False, qkv=True, fn="vx_dino_block_f16"):
     wo, w1, w2, wq = f16(D, D, sc=D ** -0.5), f16(HID, D, sc=D ** -0.5), f16(D, HID, sc=HID ** -0.5), f16(3 * D, D, sc=D ** -0.5)
     pm = np.zeros(api.vx_dino_block_mlp_bytes() // 2, np.uint16)
     pq = np.zeros(api.vx_dino_block_qkv_bytes() // 2, np.uint16)
-    L.vx_check(api.vx_dino_block_pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, pm.ctypes.data))
-    L.vx_check(api.vx_dino_block_pack_qkv(wq.ctypes.data, pq.ctypes.data))
+    stem = fn[:-len("_f16")]
+    L.vx_check(getattr(api, stem + "_pack_mlp")(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, pm.ctypes.data))
+    L.vx_check(getattr(api, stem + "_pack_qkv")(wq.ctypes.data, pq.ctypes.data))
     vm = np.concatenate([rng.standard_normal(384) * .1, np.full(384, .1), np.ones(384), np.zeros(384), rng.standard_normal(1536) * .1,
                          rng.standard_normal(384) * .1, np.full(384, .1)]).astype(np.float32)
     vq = np.concatenate([np.ones(384), np.zeros(384), rng.standard_normal(1152) * .1]).astype(np.float32)
@@ -54,8 +55,20 @@ if __name__ == "__main__" and "--pmc" in sys.argv:
     attn_case(32, 6, 1370)
     sys.exit(0)
 
+if __name__ == "__main__" and "--only16" in sys.argv:
+    for B in (23, 32, 11):
+        block_case(B, fn="vx_dino_block16_f16")
+    sys.exit(0)
+
 if __name__ == "__main__" and "--stamps" not in sys.argv:
     for rnd in range(2):
+        for f16 in ("vx_dino_block16_f16",):
+            block_case(23, fn=f16)
+            block_case(32, fn=f16)
+            block_case(11, fn=f16)
+            block_case(32, mlp=False, fn=f16)
+            block_case(32, qkv=False, tap=True, fn=f16)
+        block_case(11)
         block_case(23)          # 247 workgroups: one round on 256 CUs
         block_case(32)          # 343 workgroups: the north-star batch, two rounds
         block_case(32, tap=True)
@@ -77,8 +90,9 @@ def block_stamps(B):
     wo, w1, w2, wq = f16(D, D, sc=D ** -0.5), f16(HID, D, sc=D ** -0.5), f16(D, HID, sc=HID ** -0.5), f16(3 * D, D, sc=D ** -0.5)
     pm = np.zeros(api.vx_dino_block_mlp_bytes() // 2, np.uint16)
     pq = np.zeros(api.vx_dino_block_qkv_bytes() // 2, np.uint16)
-    L.vx_check(api.vx_dino_block_pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, pm.ctypes.data))
-    L.vx_check(api.vx_dino_block_pack_qkv(wq.ctypes.data, pq.ctypes.data))
+    stem = fn[:-len("_f16")]
+    L.vx_check(getattr(api, stem + "_pack_mlp")(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, pm.ctypes.data))
+    L.vx_check(getattr(api, stem + "_pack_qkv")(wq.ctypes.data, pq.ctypes.data))
     vm = np.concatenate([np.zeros(384), np.full(384, .1), np.ones(384), np.zeros(384), np.zeros(1536), np.zeros(384), np.full(384, .1)]).astype(np.float32)
     vq = np.concatenate([np.ones(384), np.zeros(384), np.zeros(1152)]).astype(np.float32)
     bufs = [DeviceBuffer.from_numpy(a) for a in (pm, pq, vm, vq)]

@@ -328,6 +328,8 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
     Wt.final_ln_b = pk.vec("backbone.layernorm.bias");
     // second packing of the encoder for the block kernel (kernels_block.hip): slab streams in the kernel's order of use
     Wt.use_block = P.dino.n_layers > 0 && vx_dino_block_supported(D, Wt.layers[0].fc1.n_real, D / P.dino.n_heads) != 0;
+    // which form of the block kernel the slab streams are packed for: 16 tokens per wave (kernels_block16.hip) unless VISP_BLOCK32=1
+    Wt.block16 = getenv("VISP_BLOCK32") == nullptr;
     if (Wt.use_block) {
         for (int i = 0; i < P.dino.n_layers; ++i) {
             std::string p = "backbone.encoder.layer." + std::to_string(i);
@@ -342,8 +344,13 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
             L.blk_mlp = ab.alloc(vx_dino_block_mlp_bytes());
             L.blk_qkv = ab.alloc(vx_dino_block_qkv_bytes());
             if (with_data) {
-                VX(vx_dino_block_pack_mlp(wo.data(), w1.data(), w2.data(), ab.data.data() + L.blk_mlp));
-                VX(vx_dino_block_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
+                if (Wt.block16) {
+                    VX(vx_dino_block16_pack_mlp(wo.data(), w1.data(), w2.data(), ab.data.data() + L.blk_mlp));
+                    VX(vx_dino_block16_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
+                } else {
+                    VX(vx_dino_block_pack_mlp(wo.data(), w1.data(), w2.data(), ab.data.data() + L.blk_mlp));
+                    VX(vx_dino_block_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
+                }
                 vm = bo;
                 pk.append_vec(vm, p + ".layer_scale1.lambda1");
                 pk.append_vec(vm, p + ".norm2.weight");
@@ -835,7 +842,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
                 bytes += (double)M * D * 2;
             }
             c.mark(group, 1, flops, bytes);
-            VX(vx_dino_block_f16(&a, stream));
+            VX(Wt.block16 ? vx_dino_block16_f16(&a, stream) : vx_dino_block_f16(&a, stream));
         };
         block(-1, 0, nullptr, "block_qkv0");
         int tap = 0;

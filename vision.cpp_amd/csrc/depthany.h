@@ -72,6 +72,7 @@ struct depthany_weights {
     std::vector<dino_layer_weights> layers;
     packed_vec final_ln_w, final_ln_b;
     bool use_block = false;   // embed dim 384 / mlp 1536 / head dim 64: one launch per layer between two attentions
+    bool block16 = true;      // slab streams packed for the 16-token form of the block kernel (kernels_block16.hip)
     size_t vec_tap = SIZE_MAX; // final layernorm w|b for the block kernel's tap
     std::array<packed_gemm, 4> re_proj;
     packed_gemm re_up0, re_up1, re_down3; // convT k4s4, convT k2s2, conv3x3 s2

@@ -1,0 +1,456 @@
+// Token-stationary DINOv2 block kernel, 16-token form (embed dim 384, MLP 1536, head dim 64) -- the same operation and the same
+// argument block as kernels_block.hip (include/visp_hip_kernels.h, vx_dino_block_args), built on v_mfma_f32_16x16x32_f16:
+//
+//   * 8 waves per workgroup, TWO per SIMD (256 registers each), a wave owns 16 token rows: D^T[16 features, 16 tokens] =
+//     W[16 features, 32 k] * X^T[32 k, 16 tokens]; lane l = (token n = l & 15, group g = l >> 4) holds features 4g .. 4g+3 of
+//     every 16-feature tile. Two accumulator tiles are the B operand of the next product's 32-wide k-block with a permuted k
+//     order (element j of group g = feature 16 (j >> 2) + 4g + (j & 3) of the block), which the host packer bakes into the
+//     weights; LayerNorm statistics are a per-lane sum + two cross-group shuffles.
+//   * The state of a wave is 96 accumulators (fc2 / residual rows) + 48 registers of LayerNorm fragments instead of 192 + 96,
+//     so two waves share a SIMD and one wave's waits (LDS latency, barrier skew, global latency, dependent VALU) are covered
+//     by the other's MFMAs -- the 32-token form's limit (one wave per SIMD: every wait is an idle SIMD).
+//     The price: a weight fragment (1 KiB) feeds 16 instead of 32 tokens, i.e. one ds_read_b128 per 16-cycle MFMA -- the LDS
+//     array's full read rate (256 B/clk/CU) at full MFMA rate.
+//   * Weights stream exactly as in the 32-token form: 24 KiB slabs (24 fragments) in consumption order, registers -> 4-stage
+//     LDS ring, one workgroup barrier per pair of slabs; 144 slabs per launch. Slab contents differ (16-row fragments), so the
+//     kernel has its own packers (vx_dino_block16_pack_*).
+#include "vx_common.h"
+
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+constexpr int D = 384, HID = 1536;
+constexpr int NT = D / 16;            // 24 feature tiles of the embed dim
+constexpr int KB = D / 32;            // 12 k-blocks over the embed dim
+constexpr int FR = 24;                // fragments per slab
+constexpr int SLAB = FR * 1024;
+constexpr int N_OUT = NT / 2;         // 12 slabs of the output projection (2 tiles each)
+constexpr int N_MLP = 2 * (HID / 32); // fc1 slabs (2 hidden tiles each) + fc2 slabs (one 32-wide hidden block each)
+constexpr int N_QKV = 3 * NT / 2;     // 36
+
+constexpr int V_BO = 0, V_LAM1 = 384, V_G2 = 768, V_B2 = 1152, V_B1 = 1536, V_BFC2 = 3072, V_LAM2 = 3456; // as kernels_block.hip
+constexpr int V_GN = 3840, V_BN = 4224, V_BQKV = 4608;
+constexpr int V_GF = 5760, V_BF = 6144;
+constexpr int V_TOTAL = 6528;
+
+constexpr int PF = 3;                 // fragment window per stream
+constexpr int SMEM_RING = 4 * SLAB;
+constexpr int SMEM_BYTES = SMEM_RING + V_TOTAL * 4;
+constexpr int PIECES = SLAB / (512 * 16); // 16-byte pieces per thread per slab: 3
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+#define CI(x) (decltype(x)::value)
+
+// sum over the four lane groups that hold one token row (lanes n, n+16, n+32, n+48)
+__device__ __forceinline__ float row_sum4(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// DBG: diagnostic builds only (-DVISP_BLOCK16_DBG=n, tools/bench_block.py): 1 no global weight loads, 2 no ring writes, 8 no fragment
+// reads, 32 no GELU, 64 no step barrier -- results are garbage, the launch time shows what each part of the stream costs
+#ifndef VISP_BLOCK16_DBG
+#define VISP_BLOCK16_DBG 0
+#endif
+constexpr int DBG = VISP_BLOCK16_DBG;
+
+template <bool MLP, bool QKV, bool TAP>
+__global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_args args) {
+    // every field in a local (see kernels_block.hip: a captured argument struct ends up in scratch)
+    float* const a_x = args.x; const void* const a_att = args.att; const void* const a_wmlp = args.w_mlp; const void* const a_wqkv = args.w_qkv;
+    const float* const a_vmlp = args.vec_mlp; const float* const a_vqkv = args.vec_qkv; const float* const a_vtap = args.vec_tap;
+    void* const a_feat = args.feat; void* const a_q = args.q; void* const a_k = args.k; void* const a_v = args.v; float* const a_cap = args.cap_x1;
+    const int a_M = args.M, a_T = args.T, a_H = args.H;
+    const float a_qs = args.q_scale, a_eps = args.eps;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem;
+    float* const vec = reinterpret_cast<float*>(smem + SMEM_RING);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int m = blockIdx.x * 128 + wave * 16 + n; // this lane's token row
+
+    constexpr int row_bytes_f32 = D * 4, row_bytes_f16 = D * 2;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a_x, 0, (int)((long)a_M * row_bytes_f32), 0x00020000);
+    // rows past M: an offset beyond any buffer (and far from wrapping) -- loads return 0, stores are dropped
+    const unsigned xoff = m < a_M ? (unsigned)m * row_bytes_f32 + 16 * g : 0x80000000u;
+    auto ld_x = [&](int T) __attribute__((always_inline)) -> f32x4 { // features 16T + 4g .. +3 of this token
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff + 64 * T, 0, 0));
+    };
+    auto st_x = [&](int T, f32x4 v) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x, xoff + 64 * T, 0, 0);
+    };
+
+    // ---- weight stream: slab k of this launch; 512 threads move 3 x 16 bytes per slab each
+    auto slab_src = [&](int k) __attribute__((always_inline)) -> const u32x4* {
+        constexpr int first_qkv = MLP ? N_OUT + N_MLP : 0;
+        const unsigned char* base = (MLP && k < first_qkv) ? static_cast<const unsigned char*>(a_wmlp) + (size_t)k * SLAB
+                                                          : static_cast<const unsigned char*>(a_wqkv) + (size_t)(k - first_qkv) * SLAB;
+        return reinterpret_cast<const u32x4*>(base) + tid;
+    };
+    constexpr int n_slabs = (MLP ? N_OUT + N_MLP : 0) + (QKV ? N_QKV : 0);
+    u32x4 G0[PIECES], G1[PIECES];
+    unsigned char* const wr0 = ring + tid * 16;
+    const unsigned char* const rd0 = ring + lane * 16;
+    {
+        const u32x4 *s0 = slab_src(0), *s1 = slab_src(1);
+#pragma unroll
+        for (int z = 0; z < PIECES; ++z) { G0[z] = s0[z * 512]; G1[z] = s1[z * 512]; }
+        if constexpr (MLP)
+            for (int i = tid; i < 3840 / 4; i += 512) reinterpret_cast<float4*>(vec)[i] = reinterpret_cast<const float4*>(a_vmlp)[i];
+        if constexpr (QKV)
+            for (int i = tid; i < 1920 / 4; i += 512) reinterpret_cast<float4*>(vec + V_GN)[i] = reinterpret_cast<const float4*>(a_vqkv)[i];
+        if constexpr (TAP)
+            for (int i = tid; i < 768 / 4; i += 512) reinterpret_cast<float4*>(vec + V_GF)[i] = reinterpret_cast<const float4*>(a_vtap)[i];
+#pragma unroll
+        for (int z = 0; z < PIECES; ++z) {
+            *reinterpret_cast<u32x4*>(wr0 + z * 8192) = G0[z];
+            *reinterpret_cast<u32x4*>(wr0 + SLAB + z * 8192) = G1[z];
+        }
+        const u32x4 *s2 = slab_src(n_slabs > 2 ? 2 : 0), *s3 = slab_src(n_slabs > 3 ? 3 : 0);
+#pragma unroll
+        for (int z = 0; z < PIECES; ++z) { G0[z] = s2[z * 512]; G1[z] = s3[z * 512]; }
+    }
+
+    int k = 0, st = 0; // first slab of the step in flight and its ring stage (0 or 2)
+    const unsigned char *curx = rd0, *cury = rd0 + SLAB;
+    unsigned char* wr = wr0 + 2 * SLAB;
+    const u32x4 *gsrc0 = slab_src(0), *gsrc1 = slab_src(0);
+    f16x8 wfx[PF] = {}, wfy[PF] = {};
+
+    auto step_open = [&]() __attribute__((always_inline)) {
+        if constexpr (!(DBG & 64)) __syncthreads(); // every wave is done with the previous pair (its stages become the write target); this pair is visible
+        curx = rd0 + st * SLAB;
+        cury = curx + SLAB;
+        wr = wr0 + (st ^ 2) * SLAB;
+        // slabs past the end of the stream are read again from its start: harmless, never consumed
+        gsrc0 = slab_src(k + 4 < n_slabs ? k + 4 : 0);
+        gsrc1 = slab_src(k + 5 < n_slabs ? k + 5 : 0);
+        st ^= 2;
+        k += 2;
+        if constexpr (!(DBG & 8)) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                wfx[i] = *reinterpret_cast<const f16x8*>(curx + i * 1024);
+                wfy[i] = *reinterpret_cast<const f16x8*>(cury + i * 1024);
+            }
+        }
+    };
+    // 48 slots: slot i consumes fragment i/2 of stream X (i even) or Y (i odd), refills that window, and every 8th slot
+    // either writes one piece of the next pair to LDS or requests one piece of the pair after it
+    auto step = [&](auto&& xm, auto&& ym, auto&& side) __attribute__((always_inline)) {
+        step_open();
+        static_for<2 * FR>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = CI(ic), f = i >> 1;
+            if constexpr ((i & 1) == 0) {
+                xm(std::integral_constant<int, f>{}, wfx[f % PF]);
+                if constexpr (f + PF < FR && !(DBG & 8)) wfx[f % PF] = *reinterpret_cast<const f16x8*>(curx + (f + PF) * 1024);
+            } else {
+                ym(std::integral_constant<int, f>{}, wfy[f % PF]);
+                if constexpr (f + PF < FR && !(DBG & 8)) wfy[f % PF] = *reinterpret_cast<const f16x8*>(cury + (f + PF) * 1024);
+            }
+            constexpr int z = i >> 3; // piece 0..5 of the pair: 0..2 even slab, 3..5 odd slab
+            if constexpr (i % 8 == 1 && !(DBG & 2)) {
+                if constexpr (z < PIECES) *reinterpret_cast<u32x4*>(wr + z * 8192) = G0[z];
+                else *reinterpret_cast<u32x4*>(wr + SLAB + (z - PIECES) * 8192) = G1[z - PIECES];
+            }
+            if constexpr (i % 8 == 5 && !(DBG & 1)) {
+                if constexpr (z < PIECES) G0[z] = gsrc0[z * 512];
+                else G1[z - PIECES] = gsrc1[(z - PIECES) * 512];
+            }
+            side(ic);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto no_side = [](auto) {};
+
+    __syncthreads(); // slabs 0 and 1 and the vectors are in LDS
+
+    auto vec4 = [&](const float* v, int T) __attribute__((always_inline)) -> f32x4 { // per-feature vector entries of tile T for this lane
+        const float4 q = *reinterpret_cast<const float4*>(v + 16 * T + 4 * g);
+        f32x4 c = {q.x, q.y, q.z, q.w};
+        return c;
+    };
+    auto mfma = [](const f16x8& w, const f16x8& b, f32x4 c) __attribute__((always_inline)) -> f32x4 {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, b, c, 0, 0, 0);
+    };
+
+    f32x4 acc[NT];   // residual-stream rows, then the fc2 accumulators
+    f16x8 xb[KB];    // B fragments over the embed dim (attention output, then LayerNorm rows)
+    // a slab of two 16-feature tiles over the embed dim, fragments ordered [k-block][tile]: accumulation chains of both tiles
+    auto pair_chain = [&](f32x4 (&c)[2]) __attribute__((always_inline)) {
+        return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
+            constexpr int f = CI(fc);
+            c[f & 1] = mfma(w, xb[f >> 1], c[f & 1]);
+        };
+    };
+
+    float mean = 0.f, rstd = 0.f;
+    auto ln_stats = [&]() __attribute__((always_inline)) { // two passes in registers (nn.cpp:14-19)
+        float s = 0.f;
+#pragma unroll
+        for (int T = 0; T < NT; ++T) s += (acc[T][0] + acc[T][1]) + (acc[T][2] + acc[T][3]);
+        mean = row_sum4(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = acc[T][j] - mean; q = fmaf(d, d, q); }
+        rstd = __builtin_amdgcn_rsqf(fmaf(row_sum4(q), 1.0f / D, a_eps));
+    };
+    // normalised row as B fragments: element j of k-block kb = feature 32 kb + 16 (j >> 2) + 4g + (j & 3) = register j & 3 of tile 2 kb + (j >> 2)
+    auto ln_to_frags = [&](const float* gamma, const float* beta) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const f32x4 gm = vec4(gamma, 2 * kb + t2), bt = vec4(beta, 2 * kb + t2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xb[kb][4 * t2 + j] = (f16)fmaf((acc[2 * kb + t2][j] - mean) * rstd, gm[j], bt[j]);
+            }
+    };
+
+    if constexpr (MLP) {
+        // ---- x += lambda1 * (att Wo^T + bo)   (dino.cpp:59-74 output dense, :80-83)
+        {
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a_att), 0, (int)((long)a_M * row_bytes_f16), 0x00020000);
+            const unsigned aoff = m < a_M ? (unsigned)m * row_bytes_f16 + 16 * g : 0x80000000u;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) xb[kb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff + 64 * kb, 0, 0));
+        }
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[T] = ld_x(T);
+        static_for<N_OUT / 2>([&](auto jc) __attribute__((always_inline)) { // step j: slabs 2j, 2j+1 = tiles 4j .. 4j+3
+            constexpr int j = CI(jc);
+            f32x4 cx[2] = {vec4(vec + V_BO, 4 * j), vec4(vec + V_BO, 4 * j + 1)}, cy[2] = {vec4(vec + V_BO, 4 * j + 2), vec4(vec + V_BO, 4 * j + 3)};
+            step(pair_chain(cx), pair_chain(cy), no_side);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 lm = vec4(vec + V_LAM1, 4 * j + t);
+                const f32x4 c = t < 2 ? cx[t] : cy[t - 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * j + t][e] = fmaf(c[e], lm[e], acc[4 * j + t][e]);
+                st_x(4 * j + t, acc[4 * j + t]); // re-read by the fc2 epilogue
+            }
+        });
+        if (a_cap) { // parity captures only (tests): the residual stream after the attention half
+            const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a_cap, 0, (int)((long)a_M * row_bytes_f32), 0x00020000);
+#pragma unroll
+            for (int T = 0; T < NT; ++T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[T]), rs_c, xoff + 64 * T, 0, 0);
+        }
+
+        // ---- mlp (dino.cpp:52-57): hidden block u (32 units = two 16-unit tiles) = gelu(W1[u] LN2(x)^T + b1[u]) goes from the fc1
+        // accumulators straight into fc2's B operand. Software pipeline over u, one step each:
+        //     stream X: fc1(u+1) | stream Y: fc2(u-1) | side work: GELU(u)
+        // Slab order: [W1(0), W1(1)], [W1(u+1), W2(u-1)] for u = 1..46, [W2(46), W2(47)].
+        ln_stats();
+        ln_to_frags(vec + V_G2, vec + V_B2);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[T] = vec4(vec + V_BFC2, T); // fc2 bias folded into the accumulators
+
+        const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f, c3 = c1 * 0.044715f;
+        f32x4 hc[2], hn[2];   // fc1 tiles being activated / being accumulated
+        f16x8 hbp, hbn;       // activated block feeding fc2 / being produced
+        auto gelu_block = [&](const f32x4 (&h)[2]) __attribute__((always_inline)) -> f16x8 { // ggml_gelu = x * sigmoid(2u), as kernels_gemm.hip
+            f16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = h[e >> 2][e & 3];
+                const float w = fmaf(x * x, c3, c1);
+                r[e] = (f16)(x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * w)));
+            }
+            return r;
+        };
+        // GELU spread over the step: element e in slots 6e .. 6e+5
+        float gt[8], g1[8];
+        auto gelu_side = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = CI(ic), e = i / 6, op = i % 6;
+            if constexpr (e < 8 && !(DBG & 32)) {
+                if constexpr (op == 0) { gt[e] = hc[e >> 2][e & 3]; g1[e] = gt[e] * gt[e]; }
+                if constexpr (op == 1) g1[e] = fmaf(g1[e], c3, c1) * gt[e];
+                if constexpr (op == 2) g1[e] = __builtin_amdgcn_exp2f(g1[e]);
+                if constexpr (op == 3) g1[e] = 1.0f + g1[e];
+                if constexpr (op == 4) g1[e] = __builtin_amdgcn_rcpf(g1[e]);
+                if constexpr (op == 5) hbn[e] = (f16)(gt[e] * g1[e]);
+            }
+        };
+        auto fc2_stream = [&](const f16x8& hb) __attribute__((always_inline)) { // fragment T = feature tile T of this hidden block
+            return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
+                constexpr int T = CI(fc);
+                acc[T] = mfma(w, hb, acc[T]);
+            };
+        };
+        hc[0] = vec4(vec + V_B1, 0); hc[1] = vec4(vec + V_B1, 1);
+        hn[0] = vec4(vec + V_B1, 2); hn[1] = vec4(vec + V_B1, 3);
+        step(pair_chain(hc), pair_chain(hn), no_side);                       // [W1(0), W1(1)]
+        hbp = gelu_block(hc);                                                // GELU(0), no cover
+        hc[0] = hn[0]; hc[1] = hn[1];
+#pragma unroll 1
+        for (int u = 1; u < HID / 32 - 1; ++u) {
+            hn[0] = vec4(vec + V_B1, 2 * (u + 1)); hn[1] = vec4(vec + V_B1, 2 * (u + 1) + 1);
+            step(pair_chain(hn), fc2_stream(hbp), gelu_side);                // [W1(u+1), W2(u-1)] | GELU(u)
+            hbp = hbn;
+            hc[0] = hn[0]; hc[1] = hn[1];
+        }
+        {   // hc = fc1(47), hbp = gelu(46)
+            const f16x8 hb46 = hbp;
+            hbn = gelu_block(hc);                                            // GELU(47), no cover
+            step(fc2_stream(hb46), fc2_stream(hbn), no_side);                // [W2(46), W2(47)]
+        }
+
+        // ---- x += lambda2 * (fc2 + b2)   (dino.cpp:85-87): all re-reads of x first, then combine and store
+        {
+            f32x4 xi[NT];
+#pragma unroll
+            for (int T = 0; T < NT; ++T) xi[T] = ld_x(T);
+#pragma unroll
+            for (int T = 0; T < NT; ++T) {
+                const f32x4 lm = vec4(vec + V_LAM2, T);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[T][e] = fmaf(acc[T][e], lm[e], xi[T][e]);
+                st_x(T, acc[T]);
+            }
+        }
+    } else {
+        // QKV-only instance (first layer): the residual stream comes from memory
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[T] = ld_x(T);
+    }
+
+    if constexpr (TAP || QKV) ln_stats(); // both LayerNorms below normalise the same row: shared statistics
+
+    if constexpr (TAP) {
+        // ---- get_intermediate_layers: feat = LN_final(x), f16 rows (dino.cpp:100-107)
+        const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(a_feat, 0, (int)((long)a_M * row_bytes_f16), 0x00020000);
+        const unsigned foff = m < a_M ? (unsigned)m * row_bytes_f16 + 8 * g : 0x80000000u;
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+            const f32x4 gm = vec4(vec + V_GF, T), bt = vec4(vec + V_BF, T);
+            f16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (f16)fmaf((acc[T][j] - mean) * rstd, gm[j], bt[j]);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_f, foff + 32 * T, 0, 0);
+        }
+    }
+
+    if constexpr (QKV) {
+        // ---- next layer: q, k, v = LN1(x) Wqkv^T + b, head-major [B, H, T, 64], q pre-scaled (dino.cpp:59-66, nn.cpp:210-216)
+        ln_to_frags(vec + V_GN, vec + V_BN);
+        const int b = m / a_T, tok = m - b * a_T;
+        const int qkv_bytes = (int)((long)a_M * row_bytes_f16); // each of q, k, v: [B, H, T, 64] f16 = M * 384 * 2 bytes
+        const unsigned tok_off = m < a_M ? ((unsigned)b * a_H * a_T + tok) * 128 + 8 * g : 0x80000000u;
+        const unsigned head_stride = (unsigned)a_T * 128;
+        auto qkv_part = [&](auto wc, void* base) __attribute__((always_inline)) {
+            constexpr int W = decltype(wc)::value;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, qkv_bytes, 0x00020000);
+            const float sc = W == 0 ? a_qs : 1.0f;
+#pragma unroll 1
+            for (int i4 = 0; i4 < NT; i4 += 4) { // tiles i4 .. i4+3 of this part = slabs (W * 24 + i4) / 2, +1
+                const int R = W * NT + i4;
+                f32x4 cx[2] = {vec4(vec + V_BQKV, R), vec4(vec + V_BQKV, R + 1)}, cy[2] = {vec4(vec + V_BQKV, R + 2), vec4(vec + V_BQKV, R + 3)};
+                step(pair_chain(cx), pair_chain(cy), no_side);
+                // the four tiles are the 64 features of head i4 / 4: feature offset 16 t + 4g inside the head row
+                const unsigned off = tok_off + (unsigned)(i4 >> 2) * head_stride;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 c = t < 2 ? cx[t] : cy[t - 2];
+                    f16x4 o = {(f16)(c[0] * sc), (f16)(c[1] * sc), (f16)(c[2] * sc), (f16)(c[3] * sc)};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs, off + 32 * t, 0, 0);
+                }
+            }
+        };
+        qkv_part(std::integral_constant<int, 0>{}, a_q);
+        qkv_part(std::integral_constant<int, 1>{}, a_k);
+        qkv_part(std::integral_constant<int, 2>{}, a_v);
+    }
+}
+
+// ---- host: weight packing ------------------------------------------------------------------------------------------------
+// fragment of 16 output rows x one 32-wide k-block: lane l = (row i = l & 15, group g = l >> 4), element j: k = 32 kb + 8g + j in
+// natural order, or 32 kb + 16 (j >> 2) + 4g + (j & 3) when the B operand of the product is a pair of accumulator tiles
+void pack_frag16(const uint16_t* w, int ld, int row0, int kb, bool permuted, uint16_t* dst) {
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+            const int i = l & 15, g = l >> 4;
+            const int k = permuted ? 32 * kb + 16 * (j >> 2) + 4 * g + (j & 3) : 32 * kb + 8 * g + j;
+            dst[l * 8 + j] = w[(size_t)(row0 + i) * ld + k];
+        }
+}
+// slab of two 16-row tiles over the embed dim, fragments ordered [k-block][tile]
+void pack_pair_slab(const uint16_t* w, int tile0, bool permuted, uint16_t* slab) {
+    for (int f = 0; f < FR; ++f) pack_frag16(w, D, 16 * (tile0 + (f & 1)), f >> 1, permuted, slab + f * 512);
+}
+
+template <bool MLP, bool QKV, bool TAP>
+int launch16(const vx_dino_block_args& a, void* stream) {
+    auto kern = dino_block16_kernel<MLP, QKV, TAP>;
+    VX_CHECK(vx_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), SMEM_BYTES));
+    hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(512), SMEM_BYTES, as_stream(stream), a);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+} // namespace
+
+extern "C" {
+
+int vx_dino_block16_pack_mlp(const void* wo, const void* w1, const void* w2, void* out) {
+    VX_REQUIRE(wo && w1 && w2 && out, "vx_dino_block16_pack_mlp: null pointer");
+    const uint16_t *o = static_cast<const uint16_t*>(wo), *a = static_cast<const uint16_t*>(w1), *b = static_cast<const uint16_t*>(w2);
+    uint16_t* dst = static_cast<uint16_t*>(out);
+    auto slab = [&](int k) { return dst + (size_t)k * (SLAB / 2); };
+    for (int s = 0; s < N_OUT; ++s) pack_pair_slab(o, 2 * s, false, slab(s)); // B operand = attention rows in natural order
+    auto fc1 = [&](int u, uint16_t* sl) { pack_pair_slab(a, 2 * u, true, sl); };
+    auto fc2 = [&](int u, uint16_t* sl) { // the 24 feature tiles of hidden block u
+        for (int T = 0; T < NT; ++T) pack_frag16(b, HID, 16 * T, u, true, sl + T * 512);
+    };
+    constexpr int NU = HID / 32;
+    int k = N_OUT;
+    fc1(0, slab(k++));
+    fc1(1, slab(k++));
+    for (int u = 1; u < NU - 1; ++u) {
+        fc1(u + 1, slab(k++));
+        fc2(u - 1, slab(k++));
+    }
+    fc2(NU - 2, slab(k++));
+    fc2(NU - 1, slab(k++));
+    return k == N_OUT + N_MLP ? 1 : 0;
+}
+
+int vx_dino_block16_pack_qkv(const void* wqkv, void* out) {
+    VX_REQUIRE(wqkv && out, "vx_dino_block16_pack_qkv: null pointer");
+    uint16_t* dst = static_cast<uint16_t*>(out);
+    for (int v = 0; v < N_QKV; ++v) pack_pair_slab(static_cast<const uint16_t*>(wqkv), 2 * v, true, dst + (size_t)v * (SLAB / 2));
+    return 1;
+}
+
+int vx_dino_block16_f16(const vx_dino_block_args* args, void* stream) {
+    const vx_dino_block_args& a = *args;
+    VX_REQUIRE(a.M > 0 && a.x, "vx_dino_block16_f16: empty problem");
+    const bool mlp = a.att != nullptr, qkv = a.q != nullptr, tap = a.feat != nullptr;
+    VX_REQUIRE(mlp || qkv, "vx_dino_block16_f16: nothing to do (neither att nor q given)");
+    if (mlp) VX_REQUIRE(a.w_mlp && a.vec_mlp, "vx_dino_block16_f16: the MLP half needs w_mlp and vec_mlp");
+    if (qkv) VX_REQUIRE(a.w_qkv && a.vec_qkv && a.k && a.v && a.T > 0 && a.H > 0 && a.M % a.T == 0, "vx_dino_block16_f16: the QKV half needs w_qkv, vec_qkv, k, v, T, H and M %% T == 0");
+    if (tap) VX_REQUIRE(a.vec_tap, "vx_dino_block16_f16: the tap needs vec_tap");
+    VX_REQUIRE((long)a.M * D * 4 < 0x7fffffffL, "vx_dino_block16_f16: M = %d rows exceed the 2 GiB buffer range", a.M);
+    if (mlp && qkv && tap) return launch16<true, true, true>(a, stream);
+    if (mlp && qkv) return launch16<true, true, false>(a, stream);
+    if (mlp && tap) return launch16<true, false, true>(a, stream);
+    if (mlp) return launch16<true, false, false>(a, stream);
+    VX_REQUIRE(!tap, "vx_dino_block16_f16: a tap without the MLP half is not an instance of this kernel");
+    return launch16<false, true, false>(a, stream);
+}
+
+} // extern "C"
