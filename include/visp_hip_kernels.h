@@ -276,7 +276,9 @@ VX_API int vx_dino_block_pack_mlp(const void* wo, const void* w1, const void* w2
 VX_API int vx_dino_block_pack_qkv(const void* wqkv, void* out);
 VX_API int vx_dino_block_f16(const vx_dino_block_args* args, void* stream);
 /* the same operation on v_mfma_f32_16x16x32_f16 with 16 tokens per wave and two waves per SIMD (kernels_block16.hip); same
- * argument block and vectors, its own slab contents (same sizes: vx_dino_block_mlp_bytes / _qkv_bytes) */
+ * argument block, its own slab contents (same sizes: vx_dino_block_mlp_bytes / _qkv_bytes). It expects LayerScale FOLDED in by the
+ * caller: wo / w2 rows and bo / b2 scaled by lambda1 / lambda2 (the lambda slots of vec_mlp are not read) -- the residual stream then
+ * stays in the MFMA accumulators from the attention output to the next layer's q, k, v (x read once, written once). */
 VX_API int vx_dino_block16_pack_mlp(const void* wo, const void* w1, const void* w2, void* out);
 VX_API int vx_dino_block16_pack_qkv(const void* wqkv, void* out);
 VX_API int vx_dino_block16_f16(const vx_dino_block_args* args, void* stream);

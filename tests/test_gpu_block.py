@@ -55,10 +55,12 @@ def pack(w, fn=None):
     mlp = np.zeros(a.vx_dino_block_mlp_bytes() // 2, np.uint16)
     qkv = np.zeros(a.vx_dino_block_qkv_bytes() // 2, np.uint16)
     f16 = lambda m: np.ascontiguousarray(m.astype(np.float16))  # noqa: E731
-    wo, w1, w2, wq = f16(w["wo"]), f16(w["w1"]), f16(w["w2"]), f16(w["wqkv"])
+    fold = fn is not None and getattr(fn, "folded", False)  # the 16-token form takes LayerScale folded into Wo / W2 and their biases
+    l1, l2 = (w["lam1"], w["lam2"]) if fold else (np.ones(D, np.float32), np.ones(D, np.float32))
+    wo, w1, w2, wq = f16(l1[:, None] * w["wo"]), f16(w["w1"]), f16(l2[:, None] * w["w2"]), f16(w["wqkv"])
     L.vx_check(pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, mlp.ctypes.data))
     L.vx_check(pack_qkv(wq.ctypes.data, qkv.ctypes.data))
-    vec_mlp = np.concatenate([w["bo"], w["lam1"], w["g2"], w["b2"], w["b1"], w["bfc2"], w["lam2"]]).astype(np.float32)
+    vec_mlp = np.concatenate([l1 * w["bo"], w["lam1"], w["g2"], w["b2"], w["b1"], l2 * w["bfc2"], w["lam2"]]).astype(np.float32)
     vec_qkv = np.concatenate([w["gn"], w["bn"], w["bqkv"]]).astype(np.float32)
     vec_tap = np.concatenate([w["gf"], w["bf"]]).astype(np.float32)
     assert vec_mlp.size == 3840 and vec_qkv.size == 1920 and vec_tap.size == 768
@@ -95,6 +97,7 @@ def block_fn(request):
     a = api()
     fn = getattr(a, request.param + "_f16")
     fn.pack_mlp, fn.pack_qkv = getattr(a, request.param + "_pack_mlp"), getattr(a, request.param + "_pack_qkv")
+    fn.folded = request.param.endswith("16")
     return fn
 
 

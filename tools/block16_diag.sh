@@ -1,15 +1,20 @@
 #!/bin/bash
-# A/B of diagnostic builds of kernels_block16.hip (VISP_BLOCK16_DBG bits, see the kernel): what each part of the stream costs
+# A/B of builds of kernels_block16.hip on ONE box: VARIANTS is a list of name=flags (flags: -DVISP_BLOCK16_DBG=n diagnostic bits,
+# -DVISP_BLOCK16_PF=n fragment window, -DVISP_BLOCK16_GRP=0/1 grouped waits, ...); launch times at batch 23 / 32 / 11
 set -e
 cd vision.cpp_amd/csrc
-for dbg in ${DBGS:-0 1 3 8 11 32 64}; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 ${EXTRA} -DVISP_BLOCK16_DBG=$dbg -c kernels_block16.hip -o build/kernels_block16.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libvisioncpp_dbg$dbg.so build/*.o -Wl,--no-undefined
+IFS=';' read -ra VS <<< "${VARIANTS:-base=;nofeed=-DVISP_BLOCK16_DBG=1;nofrag=-DVISP_BLOCK16_DBG=8;nogelu=-DVISP_BLOCK16_DBG=32;nobarrier=-DVISP_BLOCK16_DBG=64}"
+for v in "${VS[@]}"; do
+  name=${v%%=*}; flags=${v#*=}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 $flags -c kernels_block16.hip -o build/kernels_block16.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libvisioncpp_v_$name.so build/*.o -Wl,--no-undefined
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -c kernels_block16.hip -o build/kernels_block16.o
 cd ../..
-for dbg in ${DBGS:-0 1 3 8 11 32 64}; do
-  echo "== DBG=$dbg"
-  VISP_LIBRARY=vision.cpp_amd/lib/libvisioncpp_dbg$dbg.so python tools/bench_block.py --only16 2>&1 | grep block16 | head -3
+for rnd in 1 2; do
+for v in "${VS[@]}"; do
+  name=${v%%=*}
+  echo "== $name: $(VISP_LIBRARY=vision.cpp_amd/lib/libvisioncpp_v_$name.so python tools/bench_block.py --only16 2>&1 | grep block16 | sed 's/.*qkv=1://' | tr '\n' '|')"
 done
-rm -f vision.cpp_amd/lib/libvisioncpp_dbg*.so
+done
+rm -f vision.cpp_amd/lib/libvisioncpp_v_*.so

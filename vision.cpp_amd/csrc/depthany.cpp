@@ -344,6 +344,20 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
             L.blk_mlp = ab.alloc(vx_dino_block_mlp_bytes());
             L.blk_qkv = ab.alloc(vx_dino_block_qkv_bytes());
             if (with_data) {
+                std::vector<float> l1, l2;
+                pk.append_vec(l1, p + ".layer_scale1.lambda1");
+                pk.append_vec(l2, p + ".layer_scale2.lambda1");
+                if (Wt.block16) {
+                    // the 16-token kernel keeps the residual stream in its accumulators: LayerScale is folded into the two residual
+                    // products (exact in real arithmetic; the scaled weights are re-rounded to f16): x1 = x + Wo' att + bo', x2 = x1 + W2' h + b2'
+                    const int Hd = (int)b1.size();
+                    for (int n = 0; n < D; ++n) {
+                        for (int k = 0; k < D; ++k) wo[(size_t)n * D + k] = f32_to_f16(f16_to_f32(wo[(size_t)n * D + k]) * l1[n]);
+                        for (int k = 0; k < Hd; ++k) w2[(size_t)n * Hd + k] = f32_to_f16(f16_to_f32(w2[(size_t)n * Hd + k]) * l2[n]);
+                        bo[n] *= l1[n];
+                        b2[n] *= l2[n];
+                    }
+                }
                 if (Wt.block16) {
                     VX(vx_dino_block16_pack_mlp(wo.data(), w1.data(), w2.data(), ab.data.data() + L.blk_mlp));
                     VX(vx_dino_block16_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
@@ -352,12 +366,12 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
                     VX(vx_dino_block_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
                 }
                 vm = bo;
-                pk.append_vec(vm, p + ".layer_scale1.lambda1");
+                vm.insert(vm.end(), l1.begin(), l1.end());
                 pk.append_vec(vm, p + ".norm2.weight");
                 pk.append_vec(vm, p + ".norm2.bias");
                 vm.insert(vm.end(), b1.begin(), b1.end());
                 vm.insert(vm.end(), b2.begin(), b2.end());
-                pk.append_vec(vm, p + ".layer_scale2.lambda1");
+                vm.insert(vm.end(), l2.begin(), l2.end());
                 pk.append_vec(vq, p + ".norm1.weight");
                 pk.append_vec(vq, p + ".norm1.bias");
                 vq.insert(vq.end(), bqkv.begin(), bqkv.end());

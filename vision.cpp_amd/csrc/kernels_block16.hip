@@ -1,5 +1,8 @@
 // Token-stationary DINOv2 block kernel, 16-token form (embed dim 384, MLP 1536, head dim 64) -- the same operation and the same
-// argument block as kernels_block.hip (include/visp_hip_kernels.h, vx_dino_block_args), built on v_mfma_f32_16x16x32_f16:
+// argument block as kernels_block.hip (include/visp_hip_kernels.h, vx_dino_block_args), built on v_mfma_f32_16x16x32_f16. One
+// difference at the interface: LayerScale is expected FOLDED into the residual products (rows of Wo / W2 and bo / b2 scaled by
+// lambda1 / lambda2 before packing), so that the residual stream can live in the MFMA accumulators from the attention output to
+// the next layer's q, k, v: x is read once and written once per launch.
 //
 //   * 8 waves per workgroup, TWO per SIMD (256 registers each), a wave owns 16 token rows: D^T[16 features, 16 tokens] =
 //     W[16 features, 32 k] * X^T[32 k, 16 tokens]; lane l = (token n = l & 15, group g = l >> 4) holds features 4g .. 4g+3 of
@@ -31,15 +34,22 @@ constexpr int N_OUT = NT / 2;         // 12 slabs of the output projection (2 ti
 constexpr int N_MLP = 2 * (HID / 32); // fc1 slabs (2 hidden tiles each) + fc2 slabs (one 32-wide hidden block each)
 constexpr int N_QKV = 3 * NT / 2;     // 36
 
-constexpr int V_BO = 0, V_LAM1 = 384, V_G2 = 768, V_B2 = 1152, V_B1 = 1536, V_BFC2 = 3072, V_LAM2 = 3456; // as kernels_block.hip
+constexpr int V_BO = 0, V_G2 = 768, V_B2 = 1152, V_B1 = 1536, V_BFC2 = 3072; // layout of kernels_block.hip; bo and b2 arrive scaled by lambda1 / lambda2, the lambda slots are not read
 constexpr int V_GN = 3840, V_BN = 4224, V_BQKV = 4608;
 constexpr int V_GF = 5760, V_BF = 6144;
 constexpr int V_TOTAL = 6528;
 
-constexpr int PF = 3;                 // fragment window per stream
+#ifndef VISP_BLOCK16_PF
+#define VISP_BLOCK16_PF 6
+#endif
+#ifndef VISP_BLOCK16_GRP
+#define VISP_BLOCK16_GRP 1
+#endif
+constexpr int PF = VISP_BLOCK16_PF;   // fragment window per stream (A/B builds: tools/block16_diag.sh)
+constexpr bool GROUPED = VISP_BLOCK16_GRP != 0;
 constexpr int SMEM_RING = 4 * SLAB;
 constexpr int SMEM_BYTES = SMEM_RING + V_TOTAL * 4;
-constexpr int PIECES = SLAB / (512 * 16); // 16-byte pieces per thread per slab: 3
+constexpr int WP = 2 * FR / 8;        // 1 KiB pieces of a slab pair per wave: 6
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -55,6 +65,17 @@ __device__ __forceinline__ float row_sum4(float v) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
+}
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// 16 bytes per lane global -> LDS (global_load_lds_dwordx4; LDS destination = M0 + 16 * lane), issued from inline asm so that hipcc
+// does not count it: with the builtin it waits vmcnt(0) in front of every later LDS read (it cannot tell the ring stages apart).
+// The kernel's own vmcnt(0) in front of the step barrier is the wait these copies need. M0 is written in the same statement.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 // DBG: diagnostic builds only (-DVISP_BLOCK16_DBG=n, tools/bench_block.py): 1 no global weight loads, 2 no ring writes, 8 no fragment
@@ -93,51 +114,45 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x, xoff + 64 * T, 0, 0);
     };
 
-    // ---- weight stream: slab k of this launch; 512 threads move 3 x 16 bytes per slab each
-    auto slab_src = [&](int k) __attribute__((always_inline)) -> const u32x4* {
+    // ---- weight stream: slab pair (k, k+1) = 48 contiguous 1 KiB pieces; wave w copies pieces 6w .. 6w+5 by LDS-DMA into the
+    // ring pair that the step before last finished reading: issued right after the step barrier, waited for (vmcnt(0)) in front of
+    // the next one -- a whole step of MFMAs in between, no registers, no VGPR -> LDS store path
+    auto pair_src = [&](int k) __attribute__((always_inline)) -> const unsigned char* {
         constexpr int first_qkv = MLP ? N_OUT + N_MLP : 0;
         const unsigned char* base = (MLP && k < first_qkv) ? static_cast<const unsigned char*>(a_wmlp) + (size_t)k * SLAB
                                                           : static_cast<const unsigned char*>(a_wqkv) + (size_t)(k - first_qkv) * SLAB;
-        return reinterpret_cast<const u32x4*>(base) + tid;
+        return base + (wave * WP) * 1024 + lane * 16;
     };
     constexpr int n_slabs = (MLP ? N_OUT + N_MLP : 0) + (QKV ? N_QKV : 0);
-    u32x4 G0[PIECES], G1[PIECES];
-    unsigned char* const wr0 = ring + tid * 16;
+    const unsigned ring_lds = (unsigned)(size_t)(lptr_t)ring;
+    auto feed_pair = [&](int k, int stage) __attribute__((always_inline)) { // slabs k, k+1 -> stages stage, stage+1
+        if constexpr (DBG & 1) return;
+        const unsigned char* src = pair_src(k);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + stage * SLAB + wave * WP * 1024);
+#pragma unroll
+        for (int z = 0; z < WP; ++z) lds_dma16(src + z * 1024, dst + z * 1024);
+    };
     const unsigned char* const rd0 = ring + lane * 16;
     {
-        const u32x4 *s0 = slab_src(0), *s1 = slab_src(1);
-#pragma unroll
-        for (int z = 0; z < PIECES; ++z) { G0[z] = s0[z * 512]; G1[z] = s1[z * 512]; }
+        feed_pair(0, 0);
         if constexpr (MLP)
             for (int i = tid; i < 3840 / 4; i += 512) reinterpret_cast<float4*>(vec)[i] = reinterpret_cast<const float4*>(a_vmlp)[i];
         if constexpr (QKV)
             for (int i = tid; i < 1920 / 4; i += 512) reinterpret_cast<float4*>(vec + V_GN)[i] = reinterpret_cast<const float4*>(a_vqkv)[i];
         if constexpr (TAP)
             for (int i = tid; i < 768 / 4; i += 512) reinterpret_cast<float4*>(vec + V_GF)[i] = reinterpret_cast<const float4*>(a_vtap)[i];
-#pragma unroll
-        for (int z = 0; z < PIECES; ++z) {
-            *reinterpret_cast<u32x4*>(wr0 + z * 8192) = G0[z];
-            *reinterpret_cast<u32x4*>(wr0 + SLAB + z * 8192) = G1[z];
-        }
-        const u32x4 *s2 = slab_src(n_slabs > 2 ? 2 : 0), *s3 = slab_src(n_slabs > 3 ? 3 : 0);
-#pragma unroll
-        for (int z = 0; z < PIECES; ++z) { G0[z] = s2[z * 512]; G1[z] = s3[z * 512]; }
     }
 
     int k = 0, st = 0; // first slab of the step in flight and its ring stage (0 or 2)
     const unsigned char *curx = rd0, *cury = rd0 + SLAB;
-    unsigned char* wr = wr0 + 2 * SLAB;
-    const u32x4 *gsrc0 = slab_src(0), *gsrc1 = slab_src(0);
     f16x8 wfx[PF] = {}, wfy[PF] = {};
 
     auto step_open = [&]() __attribute__((always_inline)) {
-        if constexpr (!(DBG & 64)) __syncthreads(); // every wave is done with the previous pair (its stages become the write target); this pair is visible
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the pair about to be read have landed
+        if constexpr (!(DBG & 64)) __syncthreads();      // ... everybody's have; every wave is done with the other pair: it is the next write target
         curx = rd0 + st * SLAB;
         cury = curx + SLAB;
-        wr = wr0 + (st ^ 2) * SLAB;
-        // slabs past the end of the stream are read again from its start: harmless, never consumed
-        gsrc0 = slab_src(k + 4 < n_slabs ? k + 4 : 0);
-        gsrc1 = slab_src(k + 5 < n_slabs ? k + 5 : 0);
+        if (k + 2 < n_slabs) feed_pair(k + 2, st ^ 2);
         st ^= 2;
         k += 2;
         if constexpr (!(DBG & 8)) {
@@ -148,35 +163,47 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             }
         }
     };
-    // 48 slots: slot i consumes fragment i/2 of stream X (i even) or Y (i odd), refills that window, and every 8th slot
-    // either writes one piece of the next pair to LDS or requests one piece of the pair after it
+    // 12 groups of 4 MFMAs: fragments 2gi, 2gi+1 of stream X and of stream Y, then their window refills, then 4 slots of side work.
+    // The group's first MFMA takes the fragment that was requested LAST (Y, 2gi+1): LDS reads return in order, so hipcc emits one
+    // lgkmcnt wait per group instead of one per MFMA (a wait is an issue slot of the wave like any other instruction).
     auto step = [&](auto&& xm, auto&& ym, auto&& side) __attribute__((always_inline)) {
         step_open();
-        static_for<2 * FR>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = CI(ic), f = i >> 1;
-            if constexpr ((i & 1) == 0) {
-                xm(std::integral_constant<int, f>{}, wfx[f % PF]);
-                if constexpr (f + PF < FR && !(DBG & 8)) wfx[f % PF] = *reinterpret_cast<const f16x8*>(curx + (f + PF) * 1024);
-            } else {
-                ym(std::integral_constant<int, f>{}, wfy[f % PF]);
-                if constexpr (f + PF < FR && !(DBG & 8)) wfy[f % PF] = *reinterpret_cast<const f16x8*>(cury + (f + PF) * 1024);
+        if constexpr (!GROUPED) { // one MFMA per slot, X and Y alternating
+            static_for<2 * FR>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = CI(ic), f = i >> 1;
+                if constexpr ((i & 1) == 0) {
+                    xm(std::integral_constant<int, f>{}, wfx[f % PF]);
+                    if constexpr (f + PF < FR && !(DBG & 8)) wfx[f % PF] = *reinterpret_cast<const f16x8*>(curx + (f + PF) * 1024);
+                } else {
+                    ym(std::integral_constant<int, f>{}, wfy[f % PF]);
+                    if constexpr (f + PF < FR && !(DBG & 8)) wfy[f % PF] = *reinterpret_cast<const f16x8*>(cury + (f + PF) * 1024);
+                }
+                side(ic);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else
+        static_for<FR / 2>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int f0 = 2 * CI(gc), f1 = f0 + 1;
+            ym(std::integral_constant<int, f1>{}, wfy[f1 % PF]);
+            xm(std::integral_constant<int, f1>{}, wfx[f1 % PF]);
+            ym(std::integral_constant<int, f0>{}, wfy[f0 % PF]);
+            xm(std::integral_constant<int, f0>{}, wfx[f0 % PF]);
+            if constexpr (f0 + PF < FR && !(DBG & 8)) {
+                wfx[f0 % PF] = *reinterpret_cast<const f16x8*>(curx + (f0 + PF) * 1024);
+                wfy[f0 % PF] = *reinterpret_cast<const f16x8*>(cury + (f0 + PF) * 1024);
+                wfx[f1 % PF] = *reinterpret_cast<const f16x8*>(curx + (f1 + PF) * 1024);
+                wfy[f1 % PF] = *reinterpret_cast<const f16x8*>(cury + (f1 + PF) * 1024);
             }
-            constexpr int z = i >> 3; // piece 0..5 of the pair: 0..2 even slab, 3..5 odd slab
-            if constexpr (i % 8 == 1 && !(DBG & 2)) {
-                if constexpr (z < PIECES) *reinterpret_cast<u32x4*>(wr + z * 8192) = G0[z];
-                else *reinterpret_cast<u32x4*>(wr + SLAB + (z - PIECES) * 8192) = G1[z - PIECES];
-            }
-            if constexpr (i % 8 == 5 && !(DBG & 1)) {
-                if constexpr (z < PIECES) G0[z] = gsrc0[z * 512];
-                else G1[z - PIECES] = gsrc1[(z - PIECES) * 512];
-            }
-            side(ic);
+            side(std::integral_constant<int, 2 * f0>{});
+            side(std::integral_constant<int, 2 * f0 + 1>{});
+            side(std::integral_constant<int, 2 * f0 + 2>{});
+            side(std::integral_constant<int, 2 * f0 + 3>{});
             __builtin_amdgcn_sched_barrier(0);
         });
     };
     auto no_side = [](auto) {};
 
-    __syncthreads(); // slabs 0 and 1 and the vectors are in LDS
+    // (the first step's barrier makes slabs 0, 1 and the vectors visible)
 
     auto vec4 = [&](const float* v, int T) __attribute__((always_inline)) -> f32x4 { // per-feature vector entries of tile T for this lane
         const float4 q = *reinterpret_cast<const float4*>(v + 16 * T + 4 * g);
@@ -230,20 +257,23 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) xb[kb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff + 64 * kb, 0, 0));
         }
+        // LayerScale is folded into the weights by the caller (Wo' = lambda1 Wo, bo' = lambda1 bo; W2', b2' likewise), so the residual
+        // stream itself is the accumulator: acc = x + bo', the out-proj chains add Wo' att onto it and acc IS x1 afterwards -- no
+        // epilogue arithmetic, and x1 never goes to memory (the fc2 chains continue on it).
 #pragma unroll
-        for (int T = 0; T < NT; ++T) acc[T] = ld_x(T);
+        for (int T = 0; T < NT; ++T) {
+            const f32x4 v = ld_x(T), bo = vec4(vec + V_BO, T);
+            acc[T] = v + bo;
+        }
+        auto acc_chain = [&](auto t0c) __attribute__((always_inline)) { // slab of tiles t0, t0+1, fragments [k-block][tile]
+            return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
+                constexpr int f = CI(fc), T = CI(t0c) + (f & 1);
+                acc[T] = mfma(w, xb[f >> 1], acc[T]);
+            };
+        };
         static_for<N_OUT / 2>([&](auto jc) __attribute__((always_inline)) { // step j: slabs 2j, 2j+1 = tiles 4j .. 4j+3
             constexpr int j = CI(jc);
-            f32x4 cx[2] = {vec4(vec + V_BO, 4 * j), vec4(vec + V_BO, 4 * j + 1)}, cy[2] = {vec4(vec + V_BO, 4 * j + 2), vec4(vec + V_BO, 4 * j + 3)};
-            step(pair_chain(cx), pair_chain(cy), no_side);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 lm = vec4(vec + V_LAM1, 4 * j + t);
-                const f32x4 c = t < 2 ? cx[t] : cy[t - 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * j + t][e] = fmaf(c[e], lm[e], acc[4 * j + t][e]);
-                st_x(4 * j + t, acc[4 * j + t]); // re-read by the fc2 epilogue
-            }
+            step(acc_chain(std::integral_constant<int, 4 * j>{}), acc_chain(std::integral_constant<int, 4 * j + 2>{}), no_side);
         });
         if (a_cap) { // parity captures only (tests): the residual stream after the attention half
             const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a_cap, 0, (int)((long)a_M * row_bytes_f32), 0x00020000);
@@ -257,8 +287,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         // Slab order: [W1(0), W1(1)], [W1(u+1), W2(u-1)] for u = 1..46, [W2(46), W2(47)].
         ln_stats();
         ln_to_frags(vec + V_G2, vec + V_B2);
-#pragma unroll
-        for (int T = 0; T < NT; ++T) acc[T] = vec4(vec + V_BFC2, T); // fc2 bias folded into the accumulators
+        // acc keeps x1: the fc2 chains below accumulate W2' h (lambda2 folded in) onto the residual stream directly
 
         const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f, c3 = c1 * 0.044715f;
         f32x4 hc[2], hn[2];   // fc1 tiles being activated / being accumulated
@@ -310,18 +339,11 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             step(fc2_stream(hb46), fc2_stream(hbn), no_side);                // [W2(46), W2(47)]
         }
 
-        // ---- x += lambda2 * (fc2 + b2)   (dino.cpp:85-87): all re-reads of x first, then combine and store
-        {
-            f32x4 xi[NT];
+        // ---- x2 = x1 + lambda2 (fc2 + b2) (dino.cpp:85-87) = acc + b2': the only write of the residual stream
 #pragma unroll
-            for (int T = 0; T < NT; ++T) xi[T] = ld_x(T);
-#pragma unroll
-            for (int T = 0; T < NT; ++T) {
-                const f32x4 lm = vec4(vec + V_LAM2, T);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[T][e] = fmaf(acc[T][e], lm[e], xi[T][e]);
-                st_x(T, acc[T]);
-            }
+        for (int T = 0; T < NT; ++T) {
+            acc[T] = acc[T] + vec4(vec + V_BFC2, T);
+            st_x(T, acc[T]);
         }
     } else {
         // QKV-only instance (first layer): the residual stream comes from memory
