@@ -147,8 +147,12 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     const unsigned char *curx = rd0, *cury = rd0 + SLAB;
     f16x8 wfx[PF] = {}, wfy[PF] = {};
 
-    auto step_open = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the pair about to be read have landed
+    // YOUNGER = vector-memory operations this wave issued AFTER the copies of the pair about to be read (the output stores of the
+    // step before): they retire in order behind the copies, so a counted wait leaves them in flight instead of exposing a store's
+    // acknowledgement latency at every step barrier (CDNA4 counts stores in vmcnt)
+    auto step_open = [&](auto yc) __attribute__((always_inline)) {
+        constexpr int YOUNGER = CI(yc);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory"); // this wave's pieces of the pair about to be read have landed
         if constexpr (!(DBG & 64)) __syncthreads();      // ... everybody's have; every wave is done with the other pair: it is the next write target
         curx = rd0 + st * SLAB;
         cury = curx + SLAB;
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     // 12 groups of 4 MFMAs: fragments 2gi, 2gi+1 of stream X and of stream Y, then their window refills, then 4 slots of side work.
     // The group's first MFMA takes the fragment that was requested LAST (Y, 2gi+1): LDS reads return in order, so hipcc emits one
     // lgkmcnt wait per group instead of one per MFMA (a wait is an issue slot of the wave like any other instruction).
-    auto step = [&](auto&& xm, auto&& ym, auto&& side) __attribute__((always_inline)) {
-        step_open();
+    auto step = [&](auto&& xm, auto&& ym, auto&& side, auto yc) __attribute__((always_inline)) {
+        step_open(yc);
         if constexpr (!GROUPED) { // one MFMA per slot, X and Y alternating
             static_for<2 * FR>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = CI(ic), f = i >> 1;
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         });
     };
     auto no_side = [](auto) {};
+    constexpr std::integral_constant<int, 0> none{};
 
     // (the first step's barrier makes slabs 0, 1 and the vectors visible)
 
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         };
         static_for<N_OUT / 2>([&](auto jc) __attribute__((always_inline)) { // step j: slabs 2j, 2j+1 = tiles 4j .. 4j+3
             constexpr int j = CI(jc);
-            step(acc_chain(std::integral_constant<int, 4 * j>{}), acc_chain(std::integral_constant<int, 4 * j + 2>{}), no_side);
+            step(acc_chain(std::integral_constant<int, 4 * j>{}), acc_chain(std::integral_constant<int, 4 * j + 2>{}), no_side, none);
         });
         if (a_cap) { // parity captures only (tests): the residual stream after the attention half
             const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a_cap, 0, (int)((long)a_M * row_bytes_f32), 0x00020000);
@@ -302,7 +307,29 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             }
             return r;
         };
-        // GELU spread over the step: element e in slots 6e .. 6e+5
+        // GELU spread over the step, on PACKED f16 pairs (v_pk_mul / v_pk_fma / v_pk_add, v_exp_f16, v_rcp_f16): the result is an f16
+        // MFMA operand anyway, and the wave's issue slots are what the MLP loop runs out of. Pair q = elements 2q, 2q+1 in slots
+        // 12q .. 12q+9. (GELU_F32: the f32 form, 6 slots per element, kept for A/B builds.)
+#ifndef VISP_BLOCK16_GELU_F32
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 gp[4], ga[4], ge[4];
+        const h2 hc1 = {(f16)c1, (f16)c1}, hc3 = {(f16)c3, (f16)c3}, one = {(f16)1.0f, (f16)1.0f};
+        auto gelu_side = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = CI(ic), q = i / 12, op = i % 12;
+            if constexpr (q < 4 && !(DBG & 32)) {
+                if constexpr (op == 0) { const h2 v = {(f16)hc[q >> 1][2 * (q & 1)], (f16)hc[q >> 1][2 * (q & 1) + 1]}; gp[q] = v; }
+                if constexpr (op == 1) ga[q] = gp[q] * gp[q];
+                if constexpr (op == 2) ga[q] = ga[q] * hc3 + hc1;
+                if constexpr (op == 3) ga[q] = ga[q] * gp[q];
+                if constexpr (op == 4) ge[q][0] = __builtin_exp2f16(ga[q][0]);
+                if constexpr (op == 5) ge[q][1] = __builtin_exp2f16(ga[q][1]);
+                if constexpr (op == 6) ge[q] = ge[q] + one;
+                if constexpr (op == 7) ge[q][0] = __builtin_amdgcn_rcph(ge[q][0]);
+                if constexpr (op == 8) ge[q][1] = __builtin_amdgcn_rcph(ge[q][1]);
+                if constexpr (op == 9) { const h2 y = gp[q] * ge[q]; hbn[2 * q] = y[0]; hbn[2 * q + 1] = y[1]; }
+            }
+        };
+#else
         float gt[8], g1[8];
         auto gelu_side = [&](auto ic) __attribute__((always_inline)) {
             constexpr int i = CI(ic), e = i / 6, op = i % 6;
@@ -315,6 +342,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
                 if constexpr (op == 5) hbn[e] = (f16)(gt[e] * g1[e]);
             }
         };
+#endif
         auto fc2_stream = [&](const f16x8& hb) __attribute__((always_inline)) { // fragment T = feature tile T of this hidden block
             return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
                 constexpr int T = CI(fc);
@@ -323,20 +351,20 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         };
         hc[0] = vec4(vec + V_B1, 0); hc[1] = vec4(vec + V_B1, 1);
         hn[0] = vec4(vec + V_B1, 2); hn[1] = vec4(vec + V_B1, 3);
-        step(pair_chain(hc), pair_chain(hn), no_side);                       // [W1(0), W1(1)]
+        step(pair_chain(hc), pair_chain(hn), no_side, none);                 // [W1(0), W1(1)]
         hbp = gelu_block(hc);                                                // GELU(0), no cover
         hc[0] = hn[0]; hc[1] = hn[1];
 #pragma unroll 1
         for (int u = 1; u < HID / 32 - 1; ++u) {
             hn[0] = vec4(vec + V_B1, 2 * (u + 1)); hn[1] = vec4(vec + V_B1, 2 * (u + 1) + 1);
-            step(pair_chain(hn), fc2_stream(hbp), gelu_side);                // [W1(u+1), W2(u-1)] | GELU(u)
+            step(pair_chain(hn), fc2_stream(hbp), gelu_side, none);          // [W1(u+1), W2(u-1)] | GELU(u)
             hbp = hbn;
             hc[0] = hn[0]; hc[1] = hn[1];
         }
         {   // hc = fc1(47), hbp = gelu(46)
             const f16x8 hb46 = hbp;
             hbn = gelu_block(hc);                                            // GELU(47), no cover
-            step(fc2_stream(hb46), fc2_stream(hbn), no_side);                // [W2(46), W2(47)]
+            step(fc2_stream(hb46), fc2_stream(hbn), no_side, none);          // [W2(46), W2(47)]
         }
 
         // ---- x2 = x1 + lambda2 (fc2 + b2) (dino.cpp:85-87) = acc + b2': the only write of the residual stream
@@ -378,11 +406,10 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             constexpr int W = decltype(wc)::value;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, qkv_bytes, 0x00020000);
             const float sc = W == 0 ? a_qs : 1.0f;
-#pragma unroll 1
-            for (int i4 = 0; i4 < NT; i4 += 4) { // tiles i4 .. i4+3 of this part = slabs (W * 24 + i4) / 2, +1
+            auto head = [&](int i4, auto yc) __attribute__((always_inline)) { // tiles i4 .. i4+3 of this part = one head = slabs (W * 24 + i4) / 2, +1
                 const int R = W * NT + i4;
                 f32x4 cx[2] = {vec4(vec + V_BQKV, R), vec4(vec + V_BQKV, R + 1)}, cy[2] = {vec4(vec + V_BQKV, R + 2), vec4(vec + V_BQKV, R + 3)};
-                step(pair_chain(cx), pair_chain(cy), no_side);
+                step(pair_chain(cx), pair_chain(cy), no_side, yc);
                 // the four tiles are the 64 features of head i4 / 4: feature offset 16 t + 4g inside the head row
                 const unsigned off = tok_off + (unsigned)(i4 >> 2) * head_stride;
 #pragma unroll
@@ -391,7 +418,13 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
                     f16x4 o = {(f16)(c[0] * sc), (f16)(c[1] * sc), (f16)(c[2] * sc), (f16)(c[3] * sc)};
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs, off + 32 * t, 0, 0);
                 }
-            }
+            };
+            // every head follows the 4 stores of the head before it; the first head of q follows the 24 residual-stream stores of the
+            // fc2 epilogue (+ 24 of the tap), all younger than the copies of its slabs (QKV-only instance: the x loads, already consumed)
+            if constexpr (W == 0) head(0, std::integral_constant<int, MLP ? (TAP ? 2 * NT : NT) : 0>{});
+            else head(0, std::integral_constant<int, 4>{});
+#pragma unroll 1
+            for (int i4 = 4; i4 < NT; i4 += 4) head(i4, std::integral_constant<int, 4>{});
         };
         qkv_part(std::integral_constant<int, 0>{}, a_q);
         qkv_part(std::integral_constant<int, 1>{}, a_k);
