@@ -116,10 +116,16 @@ typedef struct {
     /* SWIN (swin.cpp:141-156): win_res_h > 0 makes the map win_res (width) x win_res_h (height); win_shift > 0 undoes the cyclic
      * shift as well (window row -> padded position -> + shift modulo the padded extent -> pixel, dropped if outside the map) */
     int win_res_h, win_shift;
+    /* split-K for deep reductions on few output tiles (3x3 convs with thousands of input channels on small maps): k_splits > 1
+     * cuts the k-loop into that many ranges, one workgroup each, partial sums f32 in k_partial [k_splits][M][N] (caller's scratch),
+     * summed in a fixed order by a second launch that applies bias / ReLU / res1 -- deterministic. Epilogues F16, F16_RELU, F16_ADD. */
+    int k_splits; float* k_partial;
     void* debug_stamps; /* diagnostics only: u64 [blocks][8] s_memtime stamps per phase, NULL in product */
 } vx_gemm_args;
 
 VX_API int vx_gemm_f16(const vx_gemm_args* args, void* stream);
+/* heuristic for vx_gemm_args.k_splits: > 1 only when the tile grid fills less than half the chip and the k-loop has >= 16 tiles */
+VX_API int vx_gemm_pick_k_splits(int M, int N, int K);
 
 /* 3x3 / stride 1 / pad 1 NHWC convolution with the input halo staged once in LDS (Cin, Cout in {32, 64};
  * epilogues F16, F16_RELU, F16_ADD, HEAD_OUT). Same argument block as the implicit-GEMM form (conv_* fields,

@@ -401,3 +401,44 @@ def test_layernorm_with_deferred_residual(M, Cc):
     L.vx_check(api().vx_layernorm_resid_f32_f16(xd2.ptr, dev(y.astype(np.float16)).ptr, dev(lam).ptr, None, None, None, M, Cc, 1e-6, None))
     sync()
     np.testing.assert_allclose(xd2.to_numpy(np.float32, (M, Cc)), x_new, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout,stride,hw,epi", [(384, 64, 1, (19, 19), "plain"), (192, 64, 1, (37, 37), "relu"), (384, 384, 2, (37, 37), "plain"),
+                                                      (256, 64, 1, (9, 13), "add")])
+def test_conv_split_k(cin, cout, stride, hw, epi):
+    """Deep reductions on few output tiles (the DPT neck convs on the 37 x 37 / 19 x 19 maps, depth-anything.cpp:66-69, 62-63): the k-loop
+    cut into ranges (vx_gemm_args.k_splits), partial sums added in a fixed order by a second launch. Same result as the oracle,
+    bit-identical between two launches, and the heuristic picks a split for exactly these shapes."""
+    rng = np.random.default_rng(cin + cout + hw[0])
+    B, (Hh, Ww) = 2, hw
+    x = _h(_rand(rng, B, Hh, Ww, cin))
+    w, b = _h(_rand(rng, cout, 3, 3, cin, scale=(9 * cin) ** -0.5)), _rand(rng, cout, scale=0.1)
+    OH, OW = (Hh + 2 - 3) // stride + 1, (Ww + 2 - 3) // stride + 1
+    M = B * OH * OW
+    wp = pad_weight(w.reshape(cout, -1))
+    ks = api().vx_gemm_pick_k_splits(M, wp.shape[0], wp.shape[1])
+    assert ks > 1, "the heuristic is meant to split these shapes"
+    assert api().vx_gemm_pick_k_splits(32 * 148 * 148, 64, 448) == 1 and api().vx_gemm_pick_k_splits(M, wp.shape[0], 576) == 1
+    part = empty(ks * M * wp.shape[0] * 4)
+    kw = dict(conv_kh=3, conv_kw=3, conv_stride=stride, conv_pad=1, conv_H=Hh, conv_W=Ww, conv_Cin=cin, conv_OH=OH, conv_OW=OW, n_valid=cout,
+              k_splits=ks, k_partial=part)
+    xd = dev(x.astype(np.float16))
+    outs = []
+    r1 = _h(_rand(rng, B, OH, OW, cout))
+    for _ in range(2):
+        out = empty(M * cout * 2)
+        if epi == "plain":
+            gemm(xd, wp, pad_vec(b, wp.shape[0]), M, L.EPI_F16, out=out, ldo=cout, **kw)
+        elif epi == "relu":
+            gemm(xd, wp, pad_vec(b, wp.shape[0]), M, L.EPI_F16_RELU, out=out, ldo=cout, **kw)
+        else:
+            gemm(xd, wp, pad_vec(b, wp.shape[0]), M, L.EPI_F16_ADD, out=out, ldo=cout, res1=dev(r1.astype(np.float16)), **kw)
+        outs.append(out.to_numpy(np.float16, (B, OH, OW, cout)))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    want = oracle.conv2d_nhwc(x, w, b, stride, 1)
+    want = np.maximum(want, 0) if epi == "relu" else (want + r1 if epi == "add" else want)
+    assert rel_err(outs[0].astype(np.float32), want) < F16_TOL
+    # misuse is reported
+    g = L.GemmArgs()
+    g.M, g.N, g.K, g.k_splits, g.A, g.W = 128, 64, 128, 4, xd.ptr, xd.ptr
+    assert api().vx_gemm_f16(C.byref(g), None) == 0 and b"k_partial" in api().vx_last_error()

@@ -65,7 +65,7 @@ class GemmArgs(ctypes.Structure):  # == vx_gemm_args
         ("q_scale", c_float),
         ("ps_s", c_int), ("ps_Cout", c_int), ("ps_H", c_int), ("ps_W", c_int),
         ("res1", c_void_p), ("res2", c_void_p), ("n_valid", c_int), ("stages", c_int), ("head_bias", c_float), ("head_scale", c_float),
-        ("post_gelu", c_int), ("win_ws", c_int), ("win_res", c_int), ("win_res_h", c_int), ("win_shift", c_int), ("debug_stamps", c_void_p),
+        ("post_gelu", c_int), ("win_ws", c_int), ("win_res", c_int), ("win_res_h", c_int), ("win_shift", c_int), ("k_splits", c_int), ("k_partial", c_void_p), ("debug_stamps", c_void_p),
     ]
 
 
@@ -109,7 +109,7 @@ KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
     "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_malloc_host", "vx_free_host", "vx_memcpy_h2d_async", "vx_memcpy_d2h_async", "vx_event_sync", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
     "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_stream_wait_event", "vx_graph_begin_capture",
-    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_conv3x3_supported", "vx_conv3x3_f16",
+    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_gemm_pick_k_splits", "vx_conv3x3_supported", "vx_conv3x3_f16",
     "vx_attention_f16",
     "vx_layernorm_f32_f16", "vx_layernorm_resid_supported", "vx_layernorm_resid_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
@@ -239,6 +239,7 @@ def init() -> ctypes.CDLL:
     lib.vx_graph_launch.argtypes = [c_void_p, c_void_p]
     lib.vx_graph_destroy.argtypes = [c_void_p]
     lib.vx_gemm_f16.argtypes = [POINTER(GemmArgs), c_void_p]
+    lib.vx_gemm_pick_k_splits.argtypes = [c_int, c_int, c_int]
     lib.vx_conv3x3_supported.argtypes = [POINTER(GemmArgs)]
     lib.vx_conv3x3_f16.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.vx_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]

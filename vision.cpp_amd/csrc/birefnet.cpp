@@ -113,6 +113,8 @@ struct bf_exec {
     uint8_t* base = nullptr;
     size_t cur = 0, peak = 0;
     timing_marks tm;
+    void* splitk = nullptr; // scratch of split-K convs (f32 partial sums)
+    size_t splitk_bytes = 0;
 
     void* take(size_t bytes) {
         const size_t off = cur;
@@ -155,6 +157,13 @@ struct bf_exec {
         a.W = wa + g.w; a.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b);
         a.M = B * H * W; a.N = g.N; a.K = g.K; a.n_valid = (g.n_real + 7) / 8 * 8; // 1-, 3-, 27-, 147-column outputs: the pad columns (zero weights) land in the row's slack
         a.epi = epi; a.out = out; a.ldo = ldo;
+        // 3x3 convs over thousands of channels on 32 x 32 maps (squeeze / block4 conv_in: K = 25920 / 29160, 64 workgroups): split-K.
+        // The split is chosen from the shape of ONE image, so a result never depends on the batch it was computed in.
+        const int ks = vx_gemm_pick_k_splits(8 * H * W, g.N, g.K);
+        if (ks > 1 && splitk && (size_t)ks * a.M * g.N * 4 <= splitk_bytes && (epi == VX_EPI_F16 || epi == VX_EPI_F16_RELU)) {
+            a.k_splits = ks;
+            a.k_partial = static_cast<float*>(splitk);
+        }
         mark(group, 2.0 * a.M * g.n_real * g.k_real, (double)B * H * W * Cpix * 2 + (double)a.M * g.n_real * 2);
         VX(vx_gemm_f16(&a, stream));
     }
@@ -280,6 +289,8 @@ void birefnet_compute_batch_device(birefnet_model& m, void const* rgb_dev, int B
         ex.base = static_cast<uint8_t*>(m.dws.ptr);
         long Mi[4];
         void* F[4];
+        ex.splitk_bytes = (size_t)8 * B * dims[2][0] * dims[2][1] * 128 * 4; // up to 8 ranges of a stage-2-sized map, 128 columns
+        ex.splitk = ex.take(ex.splitk_bytes);
         for (int i = 0; i < 4; ++i) {
             Mi[i] = (long)B * dims[i][0] * dims[i][1];
             F[i] = ex.take((size_t)Mi[i] * ccat[i] * 2);

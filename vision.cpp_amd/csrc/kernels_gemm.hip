@@ -19,6 +19,10 @@
 //    stream, token rows) use batched 16-byte loads/stores straight from the registers.
 #include "vx_common.h"
 
+#include <algorithm>
+
+extern "C" int vx_gemm_f16_raw(const vx_gemm_args* args, void* stream); // the single launch behind vx_gemm_f16
+
 namespace {
 
 constexpr int BK = 64;          // k elements per LDS tile row (128 bytes)
@@ -81,9 +85,21 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
         const int q = nwg >> 3, rem = nwg & 7, xcd = b & 7;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
     }
+    // split-K: the grid holds k_splits copies of the tile set, copy ks reduces k-tiles [kbase, kbase + nk)
+    int ks = 0;
+    if (p.k_splits > 1) {
+        const int n_tiles = gridDim.x / p.k_splits;
+        ks = tile / n_tiles;
+        tile -= ks * n_tiles;
+    }
     const int tile_m = tile / n_tiles_n, tile_n = tile - tile_m * n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.K / BK;
+    int kbase = 0, nk = p.K / BK;
+    if (p.k_splits > 1) {
+        const int per = (nk + p.k_splits - 1) / p.k_splits;
+        kbase = ks * per;
+        nk = min(per, nk - kbase); // >= 1: the host picks k_splits so that no range is empty
+    }
 
     // per-column epilogue vectors (bias, LayerScale lambda) are fetched ONCE, now, into a small LDS side
     // buffer behind the operand ring: their L2 latency hides under the k-loop instead of stalling the
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
     auto issue_loads = [&](int kt, int stage) {
         unsigned char* const sa = smem + stage * STAGE_BYTES;
         unsigned char* const sb = sa + BM * BK * 2;
-        const int k0 = kt * BK;
+        const int k0 = (kbase + kt) * BK;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             const f16* src;
@@ -276,6 +292,23 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_kernel(const 
 
     const int n_valid = p.n_valid > 0 ? p.n_valid : p.N;
     stamp(3);
+
+    if (p.k_splits > 1) { // raw partial sums: a lane owns row m and 4 consecutive columns per register group
+        float* const part = p.k_partial + (long)ks * p.M * p.N;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wr * WM + mi * 32 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = {acc[mi][ni][4 * g + 0], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                    *reinterpret_cast<float4*>(part + (long)m * p.N + n0 + wc * WN + ni * 32 + 8 * g + 4 * h) = v;
+                }
+        }
+        return;
+    }
 
     if constexpr (!epi_is_f16_tile(EPI)) {
         // ---- f32 outputs (residual stream x): a lane owns row m and 4 consecutive columns per register
@@ -448,7 +481,7 @@ int launch(const vx_gemm_args& a, hipStream_t s) {
     auto kern = gemm_kernel<BM, BN, WM, WN, STAGES, EPI, CONV>;
     if constexpr (smem > 48 * 1024) VX_CHECK(vx_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem)); // per (kernel, device)
     int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * (BM / WM) * (BN / WN)), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * (a.k_splits > 1 ? a.k_splits : 1)), dim3(64 * (BM / WM) * (BN / WN)), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
 }
@@ -508,9 +541,74 @@ int dispatch_epi(const vx_gemm_args& a, hipStream_t s) {
     return 0;
 }
 
+// second launch of a split-K GEMM: out[m, n] = act(sum_s partial[s][m][n] + bias[n]) (+ res1), 8 columns per thread, fixed order
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int S, long M, int N, const float* __restrict__ bias, int epi,
+                                                            f16* __restrict__ out, long ldo, int n_valid, const f16* __restrict__ res1) {
+    const int c8 = n_valid / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * c8) return;
+    const long m = i / c8;
+    const int n = (int)(i - m * c8) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bias ? bias[n + j] : 0.0f;
+    for (int s2 = 0; s2 < S; ++s2) {
+        const float* p = part + ((long)s2 * M + m) * N + n;
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    f16x8 o;
+    if (epi == VX_EPI_F16_ADD && res1) {
+        const f16x8 rr = *reinterpret_cast<const f16x8*>(res1 + m * ldo + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)(epi == VX_EPI_F16_RELU ? fmaxf(v[j], 0.0f) : v[j]);
+    *reinterpret_cast<f16x8*>(out + m * ldo + n) = o;
+}
+
 } // namespace
 
+// how many k ranges are worth it for an M x N x K product: only when the tile grid leaves most CUs idle and the reduction is deep
+extern "C" int vx_gemm_pick_k_splits(int M, int N, int K) {
+    const int bn = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
+    const long tiles = (long)((M + 127) / 128) * (N / bn);
+    const int nk = K / BK;
+    if (tiles >= 128 || nk < 16) return 1;
+    int s = (int)std::min<long>(std::min(8, nk / 8), (256 + tiles - 1) / tiles);
+    while (s > 1 && ((nk + s - 1) / s) * (s - 1) >= nk) --s; // no empty range
+    return s > 1 ? s : 1;
+}
+
 extern "C" int vx_gemm_f16(const vx_gemm_args* args, void* stream) {
+    if (args->k_splits > 1) { // split-K: partial sums + deterministic finish
+        vx_gemm_args a = *args;
+        VX_REQUIRE(a.k_partial, "vx_gemm_f16: split-K needs the k_partial scratch (k_splits * M * N floats)");
+        VX_REQUIRE(a.epi == VX_EPI_F16 || a.epi == VX_EPI_F16_RELU || (a.epi == VX_EPI_F16_ADD && !a.res2 && !a.post_gelu && a.win_ws == 0),
+                   "vx_gemm_f16: split-K supports the F16, F16_RELU and plain F16_ADD epilogues");
+        VX_REQUIRE(a.K % BK == 0 && a.k_splits <= a.K / BK && ((a.K / BK + a.k_splits - 1) / a.k_splits) * (a.k_splits - 1) < a.K / BK,
+                   "vx_gemm_f16: k_splits = %d leaves an empty k range for K = %d", a.k_splits, a.K);
+        const int nv = a.n_valid > 0 ? a.n_valid : a.N;
+        VX_REQUIRE(nv % 8 == 0 && a.ldo % 8 == 0, "vx_gemm_f16: split-K output columns and row stride must be multiples of 8");
+        const int epi = a.epi;
+        const void* res1 = a.res1;
+        a.epi = VX_EPI_F16; // the GEMM launch only stores raw partial sums
+        a.res1 = nullptr;
+        a.k_splits = 0;
+        vx_gemm_args g = a;
+        g.k_splits = args->k_splits;
+        if (!vx_gemm_f16_raw(&g, stream)) return 0;
+        const long items = (long)a.M * (nv / 8);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, as_stream(stream), a.k_partial, args->k_splits, (long)a.M, a.N, a.bias, epi,
+                           reinterpret_cast<f16*>(a.out), (long)a.ldo, nv, reinterpret_cast<const f16*>(res1));
+        VX_LAUNCH_CHECK();
+        return 1;
+    }
+    return vx_gemm_f16_raw(args, stream);
+}
+
+extern "C" int vx_gemm_f16_raw(const vx_gemm_args* args, void* stream) {
     const vx_gemm_args& a = *args;
     VX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "vx_gemm_f16: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     VX_REQUIRE(a.K % BK == 0, "vx_gemm_f16: K=%d must be a multiple of %d (pad the weights)", a.K, BK);
