@@ -82,7 +82,7 @@ if __name__ == "__main__" and "--stamps" not in sys.argv:
         gemm_case("out_resid", M, 384, 384, L.EPI_RESID_F32, 0)
 
 
-def block_stamps(B):
+def block_stamps(B, fn="vx_dino_block_f16"):
     """Per-workgroup phase anatomy from in-kernel s_memtime stamps (diagnostic)."""
     M = B * T
     rng = np.random.default_rng(0)
@@ -106,15 +106,16 @@ def block_stamps(B):
     a.x, a.M, a.T, a.H, a.q_scale, a.eps = x.ptr, M, T, H, 0.125, 1e-6
     a.att, a.w_mlp, a.vec_mlp = att.ptr, bufs[0].ptr, bufs[2].ptr
     a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, bufs[1].ptr, bufs[3].ptr
+    launch = getattr(api, fn)
     for _ in range(50):
-        L.vx_check(api.vx_dino_block_f16(C.byref(a), stream))
+        L.vx_check(launch(C.byref(a), stream))
     a.stamps = st.ptr
-    L.vx_check(api.vx_dino_block_f16(C.byref(a), stream))
+    L.vx_check(launch(C.byref(a), stream))
     L.vx_check(api.vx_stream_sync(stream))
     t = st.to_numpy(np.uint64, (nblk, 16)).astype(np.int64)
     names = ["prologue (att, vectors, slabs 0-3)", "to first tile", "out-proj 12 tiles", "LN2", "MLP 96 slabs", "fc2 epilogue (x re-read, write)",
              "LN stats", "(tap)", "LN1 -> frags", "QKV 36 tiles"]
-    print(f"--- dino_block B={B}: {nblk} workgroups; span {t[:, 10].max() - t[:, 0].min()} ticks")
+    print(f"--- {fn} B={B}: {nblk} workgroups; span {t[:, 10].max() - t[:, 0].min()} ticks")
     for i, nm in enumerate(names):
         d = t[:, i + 1] - t[:, i]
         print(f"   {nm:36s} median {np.median(d):9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}")
@@ -127,6 +128,11 @@ def block_stamps(B):
     print("   start ticks (deciles):", [int(np.percentile(starts, p)) for p in range(0, 101, 10)])
 
 
+if __name__ == "__main__" and "--stamps16" in sys.argv:
+    block_stamps(11, "vx_dino_block16_f16")
+    sys.exit(0)
+
 if __name__ == "__main__" and "--stamps" in sys.argv:
-    block_stamps(23)
-    block_stamps(32)
+    for fn in ("vx_dino_block16_f16", "vx_dino_block_f16"):
+        block_stamps(11, fn)
+        block_stamps(23, fn)

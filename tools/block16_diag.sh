@@ -11,10 +11,11 @@ for v in "${VS[@]}"; do
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -c kernels_block16.hip -o build/kernels_block16.o
 cd ../..
-for rnd in 1 2; do
+for rnd in ${ROUNDS:-1 2}; do
 for v in "${VS[@]}"; do
   name=${v%%=*}
-  echo "== $name: $(VISP_LIBRARY=vision.cpp_amd/lib/libvisioncpp_v_$name.so python tools/bench_block.py --only16 2>&1 | grep block16 | sed 's/.*qkv=1://' | tr '\n' '|')"
+  if [ -n "$STAMPS" ]; then echo "== $name"; VISP_LIBRARY=vision.cpp_amd/lib/libvisioncpp_v_$name.so python tools/bench_block.py --stamps16 2>&1 | grep -E "out-proj|MLP|QKV|lifetime|clock"; else
+  echo "== $name: $(VISP_LIBRARY=vision.cpp_amd/lib/libvisioncpp_v_$name.so python tools/bench_block.py --only16 2>&1 | grep block16 | sed 's/.*qkv=1://' | tr '\n' '|')"; fi
 done
 done
 rm -f vision.cpp_amd/lib/libvisioncpp_v_*.so

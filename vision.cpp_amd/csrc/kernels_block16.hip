@@ -93,6 +93,12 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     void* const a_feat = args.feat; void* const a_q = args.q; void* const a_k = args.k; void* const a_v = args.v; float* const a_cap = args.cap_x1;
     const int a_M = args.M, a_T = args.T, a_H = args.H;
     const float a_qs = args.q_scale, a_eps = args.eps;
+    unsigned long long* const a_stamps = static_cast<unsigned long long*>(args.stamps); // diagnostics (tools/bench_block.py --stamps): s_memtime per phase, NULL in the product
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (a_stamps && threadIdx.x == 0) a_stamps[(size_t)blockIdx.x * 16 + slot] = slot >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    stamp(14);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             for (int i = tid; i < 768 / 4; i += 512) reinterpret_cast<float4*>(vec + V_GF)[i] = reinterpret_cast<const float4*>(a_vtap)[i];
     }
 
+    stamp(1);
     int k = 0, st = 0; // first slab of the step in flight and its ring stage (0 or 2)
     const unsigned char *curx = rd0, *cury = rd0 + SLAB;
     f16x8 wfx[PF] = {}, wfy[PF] = {};
@@ -270,6 +277,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             const f32x4 v = ld_x(T), bo = vec4(vec + V_BO, T);
             acc[T] = v + bo;
         }
+        stamp(2);
         auto acc_chain = [&](auto t0c) __attribute__((always_inline)) { // slab of tiles t0, t0+1, fragments [k-block][tile]
             return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
                 constexpr int f = CI(fc), T = CI(t0c) + (f & 1);
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             constexpr int j = CI(jc);
             step(acc_chain(std::integral_constant<int, 4 * j>{}), acc_chain(std::integral_constant<int, 4 * j + 2>{}), no_side, none);
         });
+        stamp(3);
         if (a_cap) { // parity captures only (tests): the residual stream after the attention half
             const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a_cap, 0, (int)((long)a_M * row_bytes_f32), 0x00020000);
 #pragma unroll
@@ -292,6 +301,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         // Slab order: [W1(0), W1(1)], [W1(u+1), W2(u-1)] for u = 1..46, [W2(46), W2(47)].
         ln_stats();
         ln_to_frags(vec + V_G2, vec + V_B2);
+        stamp(4);
         // acc keeps x1: the fc2 chains below accumulate W2' h (lambda2 folded in) onto the residual stream directly
 
         const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f, c3 = c1 * 0.044715f;
@@ -367,6 +377,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             step(fc2_stream(hb46), fc2_stream(hbn), no_side, none);          // [W2(46), W2(47)]
         }
 
+        stamp(5);
         // ---- x2 = x1 + lambda2 (fc2 + b2) (dino.cpp:85-87) = acc + b2': the only write of the residual stream
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
@@ -379,7 +390,9 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         for (int T = 0; T < NT; ++T) acc[T] = ld_x(T);
     }
 
+    stamp(6);
     if constexpr (TAP || QKV) ln_stats(); // both LayerNorms below normalise the same row: shared statistics
+    stamp(7);
 
     if constexpr (TAP) {
         // ---- get_intermediate_layers: feat = LN_final(x), f16 rows (dino.cpp:100-107)
@@ -397,7 +410,9 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
 
     if constexpr (QKV) {
         // ---- next layer: q, k, v = LN1(x) Wqkv^T + b, head-major [B, H, T, 64], q pre-scaled (dino.cpp:59-66, nn.cpp:210-216)
+        stamp(8);
         ln_to_frags(vec + V_GN, vec + V_BN);
+        stamp(9);
         const int b = m / a_T, tok = m - b * a_T;
         const int qkv_bytes = (int)((long)a_M * row_bytes_f16); // each of q, k, v: [B, H, T, 64] f16 = M * 384 * 2 bytes
         const unsigned tok_off = m < a_M ? ((unsigned)b * a_H * a_T + tok) * 128 + 8 * g : 0x80000000u;
@@ -430,6 +445,8 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         qkv_part(std::integral_constant<int, 1>{}, a_k);
         qkv_part(std::integral_constant<int, 2>{}, a_v);
     }
+    stamp(10);
+    stamp(15);
 }
 
 // ---- host: weight packing ------------------------------------------------------------------------------------------------
