@@ -2,6 +2,7 @@
 """Micro-benchmark of the token-stationary DINOv2 block kernel (vx_dino_block_f16) at the north-star shape
 (M = 32 x 1370 tokens), next to the launches it replaces (LayerNorm + QKV / out-proj / fc1 / fc2 GEMMs)."""
 import ctypes as C
+import os
 import sys
 from pathlib import Path
 
@@ -129,7 +130,7 @@ def block_stamps(B, fn="vx_dino_block_f16"):
 
 
 if __name__ == "__main__" and "--stamps16" in sys.argv:
-    block_stamps(11, "vx_dino_block16_f16")
+    block_stamps(int(os.environ.get("STAMPS_B", "11")), "vx_dino_block16_f16")
     sys.exit(0)
 
 if __name__ == "__main__" and "--stamps" in sys.argv:
