@@ -264,8 +264,14 @@ def main():
             # pass, on tools/bench_block.py --pmc = the same launch shapes; units and corrections in tools/pmc_summary.py)
             pmc = ROOT / "profiles" / ("r02_pmc" if (ROOT / "profiles" / "r02_pmc" / "traffic.json").exists() else "r01_pmc") / "traffic.json"
             if pmc.exists():
-                k = json.loads(pmc.read_text())["kernels"].get(dom["name"])
+                ks = json.loads(pmc.read_text())["kernels"]
+                # one entry per launch shape ("block@343wg"): this object describes the unsplit batch-32 launch (the timing pass runs
+                # the batch on one stream), i.e. the entry with the most workgroups
+                shaped = [v for n, v in ks.items() if n.startswith(dom["name"] + "@")]
+                k = ks.get(dom["name"]) or (max(shaped, key=lambda v: v.get("workgroups", 0)) if shaped else None)
                 if k:
+                    res["roofline"]["launch_shape"] = (f"batch {B} on one stream ({k.get('workgroups', '?')} workgroups), as in the per-group timing pass; the timed "
+                                                       "step issues the same work as 3 sub-batch launches on parallel streams (kernel_stats_by_grid in profiles/)")
                     res["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
                     res["roofline"]["traffic_source"] = f"profiles/{pmc.parent.name}/traffic.json (FETCH_SIZE{' x2' if k.get('fetch_doubled', True) else ''} + WRITE_SIZE)"
                     if "mfma_busy_pct" in k:

@@ -51,8 +51,11 @@ def block_case(B, mlp=True, tap=False, qkv=True, fn="vx_dino_block_f16"):
 if __name__ == "__main__" and "--pmc" in sys.argv:
     # target of the rocprofv3 --pmc passes (profiles/r02_pmc/): the north-star launch shapes once each, nothing else
     from bench_kernels import attn_case
-    block_case(32)
-    block_case(32, mlp=False)
+    # (batch 32 runs as three sub-batches of 11 / 11 / 10 images on parallel streams: these are the shapes of its launches)
+    block_case(11, fn="vx_dino_block16_f16")
+    block_case(11, mlp=False, fn="vx_dino_block16_f16")
+    attn_case(11, 6, 1370)
+    block_case(32, fn="vx_dino_block16_f16")
     attn_case(32, 6, 1370)
     sys.exit(0)
 

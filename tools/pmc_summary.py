@@ -19,7 +19,8 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-GROUPS = {"dino_block_kernel<true, true": "block", "dino_block_kernel<false, true": "block_qkv0", "attention_kernel": "attention"}
+GROUPS = {"dino_block16_kernel<true, true": "block", "dino_block16_kernel<false, true": "block_qkv0",
+          "dino_block_kernel<true, true": "block", "dino_block_kernel<false, true": "block_qkv0", "attention_kernel": "attention"}
 FETCH_X2 = {"attention": True, "block": False, "block_qkv0": False}
 
 
@@ -28,8 +29,11 @@ def collect(path):
     for r in csv.DictReader(open(path)):
         for key, grp in GROUPS.items():
             if key in r["Kernel_Name"]:
+                wgs = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
+                grp = f"{grp}@{wgs}wg"   # one entry per launch shape
                 acc[grp][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 acc[grp]["_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                acc[grp]["_wgs"].append(wgs)
                 break
     return {g: {k: sum(v) / len(v) for k, v in d.items()} for g, d in acc.items()}
 
@@ -41,15 +45,16 @@ if __name__ == "__main__":
     res = {}
     for g in sorted(fetch):
         raw = fetch[g]["FETCH_SIZE"] * 1024.0
-        fb = raw * (2.0 if FETCH_X2[g] else 1.0)
+        x2 = FETCH_X2[g.split("@")[0]]
+        fb = raw * (2.0 if x2 else 1.0)
         wb = write[g]["WRITE_SIZE"] * 1024.0
         cyc = grbm[g]["GRBM_GUI_ACTIVE"] / 8.0
-        res[g] = {"fetch_bytes_raw": round(raw), "fetch_doubled": FETCH_X2[g], "fetch_bytes": round(fb), "write_bytes": round(wb),
+        res[g] = {"workgroups": round(fetch[g]["_wgs"]), "fetch_bytes_raw": round(raw), "fetch_doubled": x2, "fetch_bytes": round(fb), "write_bytes": round(wb),
                   "hbm_bytes_per_launch": round(fb + wb), "launch_us_under_pmc": round(grbm[g]["_us"], 1),
                   "shader_clock_ghz": round(cyc / grbm[g]["_us"] / 1e3, 2),
-                  "mfma_busy_pct": round(100.0 * sq[g]["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 1),
+                  "mfma_busy_pct": round(100.0 * sq[g]["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 1),  # of all 1024 SIMDs of the chip
                   "sq": {k: round(v) for k, v in sq[g].items() if not k.startswith("_")}}
     out.parent.mkdir(parents=True, exist_ok=True)
-    out.write_text(json.dumps({"source": "rocprofv3 --pmc passes of tools/profile_round.sh on tools/bench_block.py --pmc (B=32, T=1370, D=384); "
+    out.write_text(json.dumps({"source": "rocprofv3 --pmc passes of tools/profile_round.sh on tools/bench_block.py --pmc (sub-batch 11 = the product launch shape, and batch 32; T=1370, D=384); "
                                          "see tools/pmc_summary.py for units and corrections", "kernels": res}, indent=1))
     print(json.dumps(res, indent=1))

@@ -415,31 +415,33 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         stamp(9);
         const int b = m / a_T, tok = m - b * a_T;
         const int qkv_bytes = (int)((long)a_M * row_bytes_f16); // each of q, k, v: [B, H, T, 64] f16 = M * 384 * 2 bytes
-        const unsigned tok_off = m < a_M ? ((unsigned)b * a_H * a_T + tok) * 128 + 8 * g : 0x80000000u;
+        const unsigned tok_off = m < a_M ? ((unsigned)b * a_H * a_T + tok) * 128 + 16 * g : 0x80000000u;
         const unsigned head_stride = (unsigned)a_T * 128;
         auto qkv_part = [&](auto wc, void* base) __attribute__((always_inline)) {
             constexpr int W = decltype(wc)::value;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, qkv_bytes, 0x00020000);
             const float sc = W == 0 ? a_qs : 1.0f;
             auto head = [&](int i4, auto yc) __attribute__((always_inline)) { // tiles i4 .. i4+3 of this part = one head = slabs (W * 24 + i4) / 2, +1
-                const int R = W * NT + i4;
-                f32x4 cx[2] = {vec4(vec + V_BQKV, R), vec4(vec + V_BQKV, R + 1)}, cy[2] = {vec4(vec + V_BQKV, R + 2), vec4(vec + V_BQKV, R + 3)};
+                // vx_dino_block16_pack_qkv orders the rows of a tile pair so that this lane's 4 + 4 results are the 8 CONSECUTIVE features
+                // 32 p + 8g .. + 7 of the head: one 16-byte store per pair, 64 contiguous bytes per token row
+                const float* bq = vec + V_BQKV + 16 * (W * NT + i4) + 8 * g;
+                auto b4 = [&](int o) __attribute__((always_inline)) -> f32x4 { const float4 q = *reinterpret_cast<const float4*>(bq + o); f32x4 c = {q.x, q.y, q.z, q.w}; return c; };
+                f32x4 cx[2] = {b4(0), b4(4)}, cy[2] = {b4(32), b4(36)};
                 step(pair_chain(cx), pair_chain(cy), no_side, yc);
-                // the four tiles are the 64 features of head i4 / 4: feature offset 16 t + 4g inside the head row
                 const unsigned off = tok_off + (unsigned)(i4 >> 2) * head_stride;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f32x4 c = t < 2 ? cx[t] : cy[t - 2];
-                    f16x4 o = {(f16)(c[0] * sc), (f16)(c[1] * sc), (f16)(c[2] * sc), (f16)(c[3] * sc)};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs, off + 32 * t, 0, 0);
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const f32x4 c0 = p2 ? cy[0] : cx[0], c1 = p2 ? cy[1] : cx[1];
+                    f16x8 o = {(f16)(c0[0] * sc), (f16)(c0[1] * sc), (f16)(c0[2] * sc), (f16)(c0[3] * sc), (f16)(c1[0] * sc), (f16)(c1[1] * sc), (f16)(c1[2] * sc), (f16)(c1[3] * sc)};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, off + 64 * p2, 0, 0);
                 }
             };
-            // every head follows the 4 stores of the head before it; the first head of q follows the 24 residual-stream stores of the
+            // every head follows the 2 stores of the head before it; the first head of q follows the 24 residual-stream stores of the
             // fc2 epilogue (+ 24 of the tap), all younger than the copies of its slabs (QKV-only instance: the x loads, already consumed)
             if constexpr (W == 0) head(0, std::integral_constant<int, MLP ? (TAP ? 2 * NT : NT) : 0>{});
-            else head(0, std::integral_constant<int, 4>{});
+            else head(0, std::integral_constant<int, 2>{});
 #pragma unroll 1
-            for (int i4 = 4; i4 < NT; i4 += 4) head(i4, std::integral_constant<int, 4>{});
+            for (int i4 = 4; i4 < NT; i4 += 4) head(i4, std::integral_constant<int, 2>{});
         };
         qkv_part(std::integral_constant<int, 0>{}, a_q);
         qkv_part(std::integral_constant<int, 1>{}, a_k);
@@ -504,7 +506,21 @@ int vx_dino_block16_pack_mlp(const void* wo, const void* w1, const void* w2, voi
 int vx_dino_block16_pack_qkv(const void* wqkv, void* out) {
     VX_REQUIRE(wqkv && out, "vx_dino_block16_pack_qkv: null pointer");
     uint16_t* dst = static_cast<uint16_t*>(out);
-    for (int v = 0; v < N_QKV; ++v) pack_pair_slab(static_cast<const uint16_t*>(wqkv), 2 * v, true, dst + (size_t)v * (SLAB / 2));
+    const uint16_t* w = static_cast<const uint16_t*>(wqkv);
+    // slab v = output features 32v .. 32v+31 as two tiles; row i of tile e is feature 32v + 8 (i >> 2) + 4e + (i & 3), so that the
+    // lane holding rows 4g .. 4g+3 of both tiles owns 8 consecutive features (one 16-byte store in the kernel)
+    for (int v = 0; v < N_QKV; ++v)
+        for (int f = 0; f < FR; ++f) {
+            const int e = f & 1, kb = f >> 1;
+            uint16_t* frag = dst + (size_t)v * (SLAB / 2) + f * 512;
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int i = l & 15, g = l >> 4;
+                    const int row = 32 * v + 8 * (i >> 2) + 4 * e + (i & 3);
+                    const int k = 32 * kb + 16 * (j >> 2) + 4 * g + (j & 3);
+                    frag[l * 8 + j] = w[(size_t)row * D + k];
+                }
+        }
     return 1;
 }
 
