@@ -20,10 +20,11 @@
 //   * the 192 fc2 accumulators (384 features x 32 tokens per wave) stay live over the whole hidden loop, the hidden
 //     activations only ever exist as one 32 x 32 tile per wave.
 // Only weights move: the host packs them as a stream of 24 KiB slabs (the 24 A fragments of one tile, 1 KiB each, in
-// the exact order of use); the four waves copy a slab with plain 16-byte loads two slabs ahead (registers), write it
-// to a 2-stage LDS ring one slab ahead, and every wave reads all fragments with conflict-free ds_read_b128. One
-// workgroup barrier per slab (= per 24 MFMAs per wave). All waits are the compiler's counted waits: no LDS-DMA here,
-// because one wave per SIMD cannot hide the issue cost of LDS-DMA pieces behind another wave's MFMAs.
+// the exact order of use); the four waves copy a PAIR of slabs with plain 16-byte loads one step ahead (registers), write it
+// into the free half of a 4-stage LDS ring during the step, and every wave reads all fragments with conflict-free
+// ds_read_b128. One workgroup barrier per pair of slabs (= per 48 MFMAs per wave). All waits are the compiler's counted
+// waits: no LDS-DMA here, because one wave per SIMD cannot hide the issue cost of LDS-DMA pieces behind another wave's MFMAs
+// (kernels_block16.hip, the default since round 2, has two waves per SIMD and does use it).
 #include "vx_common.h"
 
 #include <cstdlib>
@@ -80,7 +81,7 @@ __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
 
 // ---- the schedule ---------------------------------------------------------------------------------------------------
 // With one wave per SIMD nothing hides a stall, so the instruction stream is laid out by hand as SLOTS: one MFMA, the
-// ds_read that refills the fragment window PF fragments ahead (crossing into the next slab, which the 3-stage ring
+// ds_read that refills the fragment window PF fragments ahead (crossing into the next slab, which the 4-stage ring
 // made visible one barrier earlier), at most one piece of the slab feed (ds_write of slab k+2 / global load of slab
 // k+4) and a few VALU instructions of "side work" (the GELU of the previous hidden tile, the epilogue of the previous
 // output tile). __builtin_amdgcn_sched_barrier(0) closes every slot: left alone, hipcc issues ds_read -> wait ->
