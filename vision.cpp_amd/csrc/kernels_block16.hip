@@ -79,7 +79,7 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
 }
 
 // DBG: diagnostic builds only (-DVISP_BLOCK16_DBG=n, tools/bench_block.py): 1 no global weight loads, 2 no ring writes, 8 no fragment
-// reads, 32 no GELU, 64 no step barrier -- results are garbage, the launch time shows what each part of the stream costs
+// reads, 32 no GELU, 64 no step barrier, 128 no q/k/v stores -- results are garbage, the launch time shows what each part of the stream costs
 #ifndef VISP_BLOCK16_DBG
 #define VISP_BLOCK16_DBG 0
 #endif
@@ -417,35 +417,61 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         const int qkv_bytes = (int)((long)a_M * row_bytes_f16); // each of q, k, v: [B, H, T, 64] f16 = M * 384 * 2 bytes
         const unsigned tok_off = m < a_M ? ((unsigned)b * a_H * a_T + tok) * 128 + 16 * g : 0x80000000u;
         const unsigned head_stride = (unsigned)a_T * 128;
+        // The two 16-byte stores of a head are issued in the MIDDLE of the next head's step (8 waves x 2 KiB = a few hundred cycles of
+        // the CU's store path, which otherwise sit between the last MFMA of a step and the barrier of the next one)
+        u32x4 pend0 = {}, pend1 = {};
+        unsigned pend_off = 0x80000000u;
+        __amdgpu_buffer_rsrc_t pend_rs = __builtin_amdgcn_make_buffer_rsrc(a_q, 0, qkv_bytes, 0x00020000);
+        auto flush_side = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = CI(ic);
+            if constexpr (!(DBG & 128)) {
+                if constexpr (i == 16) __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
+                if constexpr (i == 32) __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off + 64, 0, 0);
+            }
+        };
         auto qkv_part = [&](auto wc, void* base) __attribute__((always_inline)) {
             constexpr int W = decltype(wc)::value;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, qkv_bytes, 0x00020000);
             const float sc = W == 0 ? a_qs : 1.0f;
-            auto head = [&](int i4, auto yc) __attribute__((always_inline)) { // tiles i4 .. i4+3 of this part = one head = slabs (W * 24 + i4) / 2, +1
+            auto head = [&](int i4, auto yc, auto pendc) __attribute__((always_inline)) { // tiles i4 .. i4+3 of this part = one head = slabs (W * 24 + i4) / 2, +1
                 // vx_dino_block16_pack_qkv orders the rows of a tile pair so that this lane's 4 + 4 results are the 8 CONSECUTIVE features
                 // 32 p + 8g .. + 7 of the head: one 16-byte store per pair, 64 contiguous bytes per token row
                 const float* bq = vec + V_BQKV + 16 * (W * NT + i4) + 8 * g;
                 auto b4 = [&](int o) __attribute__((always_inline)) -> f32x4 { const float4 q = *reinterpret_cast<const float4*>(bq + o); f32x4 c = {q.x, q.y, q.z, q.w}; return c; };
                 f32x4 cx[2] = {b4(0), b4(4)}, cy[2] = {b4(32), b4(36)};
-                step(pair_chain(cx), pair_chain(cy), no_side, yc);
-                const unsigned off = tok_off + (unsigned)(i4 >> 2) * head_stride;
-#pragma unroll
-                for (int p2 = 0; p2 < 2; ++p2) {
-                    const f32x4 c0 = p2 ? cy[0] : cx[0], c1 = p2 ? cy[1] : cx[1];
+                if constexpr (CI(pendc)) step(pair_chain(cx), pair_chain(cy), flush_side, yc);
+                else step(pair_chain(cx), pair_chain(cy), no_side, yc);
+                auto cvt8 = [&](const f32x4& c0, const f32x4& c1) __attribute__((always_inline)) -> u32x4 {
                     f16x8 o = {(f16)(c0[0] * sc), (f16)(c0[1] * sc), (f16)(c0[2] * sc), (f16)(c0[3] * sc), (f16)(c1[0] * sc), (f16)(c1[1] * sc), (f16)(c1[2] * sc), (f16)(c1[3] * sc)};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, off + 64 * p2, 0, 0);
-                }
+                    return __builtin_bit_cast(u32x4, o);
+                };
+                pend0 = cvt8(cx[0], cx[1]);
+                pend1 = cvt8(cy[0], cy[1]);
+                pend_off = tok_off + (unsigned)(i4 >> 2) * head_stride;
+                pend_rs = rs;
             };
-            // every head follows the 2 stores of the head before it; the first head of q follows the 24 residual-stream stores of the
-            // fc2 epilogue (+ 24 of the tap), all younger than the copies of its slabs (QKV-only instance: the x loads, already consumed)
-            if constexpr (W == 0) head(0, std::integral_constant<int, MLP ? (TAP ? 2 * NT : NT) : 0>{});
-            else head(0, std::integral_constant<int, 2>{});
+            // YOUNGER at the boundary in front of a head = the stores issued during the step before it: the 2 of the head before last;
+            // none in front of the second head of q; in front of the first one the 24 residual-stream stores of the fc2 epilogue (+ 24 of
+            // the tap), all younger than the copies of its slabs (QKV-only instance: the x loads, already consumed)
+            constexpr std::integral_constant<int, 2> two{};
+            constexpr std::integral_constant<int, 1> yes{};
+            if constexpr (W == 0) {
+                head(0, std::integral_constant<int, MLP ? (TAP ? 2 * NT : NT) : 0>{}, none);
+                head(4, none, yes);
 #pragma unroll 1
-            for (int i4 = 4; i4 < NT; i4 += 4) head(i4, std::integral_constant<int, 2>{});
+                for (int i4 = 8; i4 < NT; i4 += 4) head(i4, two, yes);
+            } else {
+#pragma unroll 1
+                for (int i4 = 0; i4 < NT; i4 += 4) head(i4, two, yes);
+            }
         };
         qkv_part(std::integral_constant<int, 0>{}, a_q);
         qkv_part(std::integral_constant<int, 1>{}, a_k);
         qkv_part(std::integral_constant<int, 2>{}, a_v);
+        if constexpr (!(DBG & 128)) {
+            __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off + 64, 0, 0);
+        }
     }
     stamp(10);
     stamp(15);
