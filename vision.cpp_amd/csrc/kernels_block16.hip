@@ -113,11 +113,13 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a_x, 0, (int)((long)a_M * row_bytes_f32), 0x00020000);
     // rows past M: an offset beyond any buffer (and far from wrapping) -- loads return 0, stores are dropped
     const unsigned xoff = m < a_M ? (unsigned)m * row_bytes_f32 + 16 * g : 0x80000000u;
+    // (the per-tile constant goes into the instruction's scalar offset: added to the lane offset it becomes 24 more live registers,
+    // which hipcc spills and reloads in between the stores -- each reload a vmcnt wait behind the stores just issued)
     auto ld_x = [&](int T) __attribute__((always_inline)) -> f32x4 { // features 16T + 4g .. +3 of this token
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff + 64 * T, 0, 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, 64 * T, 0));
     };
     auto st_x = [&](int T, f32x4 v) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x, xoff + 64 * T, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x, xoff, 64 * T, 0);
     };
 
     // ---- weight stream: slab pair (k, k+1) = 48 contiguous 1 KiB pieces; wave w copies pieces 6w .. 6w+5 by LDS-DMA into the
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a_att), 0, (int)((long)a_M * row_bytes_f16), 0x00020000);
             const unsigned aoff = m < a_M ? (unsigned)m * row_bytes_f16 + 16 * g : 0x80000000u;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) xb[kb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff + 64 * kb, 0, 0));
+            for (int kb = 0; kb < KB; ++kb) xb[kb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff, 64 * kb, 0));
         }
         // LayerScale is folded into the weights by the caller (Wo' = lambda1 Wo, bo' = lambda1 bo; W2', b2' likewise), so the residual
         // stream itself is the accumulator: acc = x + bo', the out-proj chains add Wo' att onto it and acc IS x1 afterwards -- no
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         if (a_cap) { // parity captures only (tests): the residual stream after the attention half
             const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a_cap, 0, (int)((long)a_M * row_bytes_f32), 0x00020000);
 #pragma unroll
-            for (int T = 0; T < NT; ++T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[T]), rs_c, xoff + 64 * T, 0, 0);
+            for (int T = 0; T < NT; ++T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[T]), rs_c, xoff, 64 * T, 0);
         }
 
         // ---- mlp (dino.cpp:52-57): hidden block u (32 units = two 16-unit tiles) = gelu(W1[u] LN2(x)^T + b1[u]) goes from the fc1
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             f16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (f16)fmaf((acc[T][j] - mean) * rstd, gm[j], bt[j]);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_f, foff + 32 * T, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_f, foff, 32 * T, 0);
         }
     }
 
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             constexpr int i = CI(ic);
             if constexpr (!(DBG & 128)) {
                 if constexpr (i == 16) __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
-                if constexpr (i == 32) __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off + 64, 0, 0);
+                if constexpr (i == 32) __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
             }
         };
         auto qkv_part = [&](auto wc, void* base) __attribute__((always_inline)) {
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         qkv_part(std::integral_constant<int, 2>{}, a_v);
         if constexpr (!(DBG & 128)) {
             __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off + 64, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
         }
     }
     stamp(10);
