@@ -40,13 +40,20 @@ constexpr int V_GF = 5760, V_BF = 6144;
 constexpr int V_TOTAL = 6528;
 
 #ifndef VISP_BLOCK16_PF
-#define VISP_BLOCK16_PF 6
+#define VISP_BLOCK16_PF 4
+#endif
+#ifndef VISP_BLOCK16_DEFER
+#define VISP_BLOCK16_DEFER 1
+#endif
+#ifndef VISP_BLOCK16_DEFER_MLP
+#define VISP_BLOCK16_DEFER_MLP 0
 #endif
 #ifndef VISP_BLOCK16_GRP
 #define VISP_BLOCK16_GRP 1
 #endif
 constexpr int PF = VISP_BLOCK16_PF;   // fragment window per stream (A/B builds: tools/block16_diag.sh)
-constexpr bool GROUPED = VISP_BLOCK16_GRP != 0;
+constexpr int DG = VISP_BLOCK16_DEFER; // groups of a step that run after the next pair's boundary (0: every step opens with its own boundary)
+static_assert(PF % 2 == 0 && FR % PF == 0 && PF - 2 * DG >= 2, "the window must hold the deferred groups and the next step's first group");
 constexpr int SMEM_RING = 4 * SLAB;
 constexpr int SMEM_BYTES = SMEM_RING + V_TOTAL * 4;
 constexpr int WP = 2 * FR / 8;        // 1 KiB pieces of a slab pair per wave: 6
@@ -156,56 +163,53 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     const unsigned char *curx = rd0, *cury = rd0 + SLAB;
     f16x8 wfx[PF] = {}, wfy[PF] = {};
 
-    // YOUNGER = vector-memory operations this wave issued AFTER the copies of the pair about to be read (the output stores of the
-    // step before): they retire in order behind the copies, so a counted wait leaves them in flight instead of exposing a store's
-    // acknowledgement latency at every step barrier (CDNA4 counts stores in vmcnt)
-    auto step_open = [&](auto yc) __attribute__((always_inline)) {
+    // A BOUNDARY in front of a slab pair: this wave's copies of the pair have landed (counted vmcnt wait), everybody's have and every
+    // wave is done reading the other pair (workgroup barrier), the window is (re)filled and the copies of the pair after it are requested
+    // into the stages just freed. YOUNGER = vector-memory operations this wave issued AFTER the copies it waits for (output stores):
+    // they retire in order behind the copies, so the counted wait leaves them in flight instead of exposing a store's acknowledgement
+    // latency at every boundary (CDNA4 counts stores in vmcnt). 0 is always safe.
+    auto boundary = [&](auto yc, auto nfill) __attribute__((always_inline)) {
         constexpr int YOUNGER = CI(yc);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory"); // this wave's pieces of the pair about to be read have landed
-        if constexpr (!(DBG & 64)) __syncthreads();      // ... everybody's have; every wave is done with the other pair: it is the next write target
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+        if constexpr (!(DBG & 64)) __syncthreads();
         curx = rd0 + st * SLAB;
         cury = curx + SLAB;
-        if (k + 2 < n_slabs) feed_pair(k + 2, st ^ 2);
-        st ^= 2;
-        k += 2;
+        // the window fill goes first: the scalar work and the issue of the 6 copies run under its LDS latency
         if constexpr (!(DBG & 8)) {
 #pragma unroll
-            for (int i = 0; i < PF; ++i) {
+            for (int i = 0; i < CI(nfill); ++i) {
                 wfx[i] = *reinterpret_cast<const f16x8*>(curx + i * 1024);
                 wfy[i] = *reinterpret_cast<const f16x8*>(cury + i * 1024);
             }
         }
+        if (k + 2 < n_slabs) feed_pair(k + 2, st ^ 2);
+        st ^= 2;
+        k += 2;
     };
-    // 12 groups of 4 MFMAs: fragments 2gi, 2gi+1 of stream X and of stream Y, then their window refills, then 4 slots of side work.
-    // The group's first MFMA takes the fragment that was requested LAST (Y, 2gi+1): LDS reads return in order, so hipcc emits one
-    // lgkmcnt wait per group instead of one per MFMA (a wait is an issue slot of the wave like any other instruction).
-    auto step = [&](auto&& xm, auto&& ym, auto&& side, auto yc) __attribute__((always_inline)) {
-        step_open(yc);
-        if constexpr (!GROUPED) { // one MFMA per slot, X and Y alternating
-            static_for<2 * FR>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = CI(ic), f = i >> 1;
-                if constexpr ((i & 1) == 0) {
-                    xm(std::integral_constant<int, f>{}, wfx[f % PF]);
-                    if constexpr (f + PF < FR && !(DBG & 8)) wfx[f % PF] = *reinterpret_cast<const f16x8*>(curx + (f + PF) * 1024);
-                } else {
-                    ym(std::integral_constant<int, f>{}, wfy[f % PF]);
-                    if constexpr (f + PF < FR && !(DBG & 8)) wfy[f % PF] = *reinterpret_cast<const f16x8*>(cury + (f + PF) * 1024);
-                }
-                side(ic);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        } else
+    // A step = one slab pair = 12 groups of 4 MFMAs: fragments 2g, 2g+1 of stream X and of stream Y, then their window refills, then 4
+    // slots of side work. The group's first MFMA takes the fragment that was requested LAST (Y, 2g+1): LDS reads return in order, so
+    // hipcc emits one lgkmcnt wait per group instead of one per MFMA (a wait is an issue slot of the wave like any other instruction).
+    // COLD: the step begins with its own boundary (after a LayerNorm phase). CONT: another step follows directly -- its boundary is
+    // taken DG groups before the end of this one: those groups' fragments are in registers already, so their MFMAs run under the
+    // barrier skew and the LDS latency of the next pair's first fragments instead of an idle MFMA pipe; the window slots they free
+    // are refilled from the new pair.
+    auto stepx = [&](auto&& xm, auto&& ym, auto&& side, auto coldc, auto contc, auto yo, auto yc) __attribute__((always_inline)) {
+        constexpr bool COLD = CI(coldc) != 0, CONT = CI(contc) != 0 && DG > 0;
+        if constexpr (COLD || DG == 0) boundary(yo, std::integral_constant<int, PF>{});
         static_for<FR / 2>([&](auto gc) __attribute__((always_inline)) {
-            constexpr int f0 = 2 * CI(gc), f1 = f0 + 1;
+            constexpr int gi = CI(gc), f0 = 2 * gi, f1 = f0 + 1;
+            if constexpr (CONT && gi == FR / 2 - DG) boundary(yc, std::integral_constant<int, PF - 2 * DG>{});
             ym(std::integral_constant<int, f1>{}, wfy[f1 % PF]);
             xm(std::integral_constant<int, f1>{}, wfx[f1 % PF]);
             ym(std::integral_constant<int, f0>{}, wfy[f0 % PF]);
             xm(std::integral_constant<int, f0>{}, wfx[f0 % PF]);
-            if constexpr (f0 + PF < FR && !(DBG & 8)) {
-                wfx[f0 % PF] = *reinterpret_cast<const f16x8*>(curx + (f0 + PF) * 1024);
-                wfy[f0 % PF] = *reinterpret_cast<const f16x8*>(cury + (f0 + PF) * 1024);
-                wfx[f1 % PF] = *reinterpret_cast<const f16x8*>(curx + (f1 + PF) * 1024);
-                wfy[f1 % PF] = *reinterpret_cast<const f16x8*>(cury + (f1 + PF) * 1024);
+            // refill: PF fragments ahead in this pair; from the deferred groups on, the next pair's (curx / cury moved at the boundary)
+            constexpr int r0 = f0 + PF < FR ? f0 + PF : (CONT && gi >= FR / 2 - DG ? f0 + PF - FR : -1);
+            if constexpr (r0 >= 0 && !(DBG & 8)) {
+                wfx[f0 % PF] = *reinterpret_cast<const f16x8*>(curx + r0 * 1024);
+                wfy[f0 % PF] = *reinterpret_cast<const f16x8*>(cury + r0 * 1024);
+                wfx[f1 % PF] = *reinterpret_cast<const f16x8*>(curx + (r0 + 1) * 1024);
+                wfy[f1 % PF] = *reinterpret_cast<const f16x8*>(cury + (r0 + 1) * 1024);
             }
             side(std::integral_constant<int, 2 * f0>{});
             side(std::integral_constant<int, 2 * f0 + 1>{});
@@ -214,10 +218,9 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             __builtin_amdgcn_sched_barrier(0);
         });
     };
+    constexpr std::integral_constant<int, 1> yes{};
     auto no_side = [](auto) {};
     constexpr std::integral_constant<int, 0> none{};
-
-    // (the first step's barrier makes slabs 0, 1 and the vectors visible)
 
     auto vec4 = [&](const float* v, int T) __attribute__((always_inline)) -> f32x4 { // per-feature vector entries of tile T for this lane
         const float4 q = *reinterpret_cast<const float4*>(v + 16 * T + 4 * g);
@@ -275,10 +278,10 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         // stream itself is the accumulator: acc = x + bo', the out-proj chains add Wo' att onto it and acc IS x1 afterwards -- no
         // epilogue arithmetic, and x1 never goes to memory (the fc2 chains continue on it).
 #pragma unroll
-        for (int T = 0; T < NT; ++T) {
-            const f32x4 v = ld_x(T), bo = vec4(vec + V_BO, T);
-            acc[T] = v + bo;
-        }
+        for (int T = 0; T < NT; ++T) acc[T] = ld_x(T);
+        __syncthreads(); // the vectors staged by all waves in the prologue are visible (the row loads above are in flight meanwhile)
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[T] = acc[T] + vec4(vec + V_BO, T);
         stamp(2);
         auto acc_chain = [&](auto t0c) __attribute__((always_inline)) { // slab of tiles t0, t0+1, fragments [k-block][tile]
             return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
@@ -288,7 +291,8 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         };
         static_for<N_OUT / 2>([&](auto jc) __attribute__((always_inline)) { // step j: slabs 2j, 2j+1 = tiles 4j .. 4j+3
             constexpr int j = CI(jc);
-            step(acc_chain(std::integral_constant<int, 4 * j>{}), acc_chain(std::integral_constant<int, 4 * j + 2>{}), no_side, none);
+            stepx(acc_chain(std::integral_constant<int, 4 * j>{}), acc_chain(std::integral_constant<int, 4 * j + 2>{}), no_side,
+                  std::integral_constant<int, j == 0>{}, std::integral_constant<int, (j + 1 < N_OUT / 2)>{}, none, none);
         });
         stamp(3);
         if (a_cap) { // parity captures only (tests): the residual stream after the attention half
@@ -363,20 +367,24 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         };
         hc[0] = vec4(vec + V_B1, 0); hc[1] = vec4(vec + V_B1, 1);
         hn[0] = vec4(vec + V_B1, 2); hn[1] = vec4(vec + V_B1, 3);
-        step(pair_chain(hc), pair_chain(hn), no_side, none);                 // [W1(0), W1(1)]
+        // (in the MLP loop the early boundary costs more than it hides -- measured 161k against 154k cycles -- so every MLP step opens
+        // with its own boundary: MLPC = 0)
+        constexpr std::integral_constant<int, VISP_BLOCK16_DEFER_MLP != 0> mlpc{};
+        constexpr std::integral_constant<int, VISP_BLOCK16_DEFER_MLP == 0> mlpo{};
+        stepx(pair_chain(hc), pair_chain(hn), no_side, yes, mlpc, none, none); // [W1(0), W1(1)]
         hbp = gelu_block(hc);                                                // GELU(0), no cover
         hc[0] = hn[0]; hc[1] = hn[1];
 #pragma unroll 1
         for (int u = 1; u < HID / 32 - 1; ++u) {
             hn[0] = vec4(vec + V_B1, 2 * (u + 1)); hn[1] = vec4(vec + V_B1, 2 * (u + 1) + 1);
-            step(pair_chain(hn), fc2_stream(hbp), gelu_side, none);          // [W1(u+1), W2(u-1)] | GELU(u)
+            stepx(pair_chain(hn), fc2_stream(hbp), gelu_side, mlpo, mlpc, none, none); // [W1(u+1), W2(u-1)] | GELU(u)
             hbp = hbn;
             hc[0] = hn[0]; hc[1] = hn[1];
         }
         {   // hc = fc1(47), hbp = gelu(46)
             const f16x8 hb46 = hbp;
             hbn = gelu_block(hc);                                            // GELU(47), no cover
-            step(fc2_stream(hb46), fc2_stream(hbn), no_side, none);          // [W2(46), W2(47)]
+            stepx(fc2_stream(hb46), fc2_stream(hbn), no_side, mlpo, none, none, none); // [W2(46), W2(47)]
         }
 
         stamp(5);
@@ -390,6 +398,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         // QKV-only instance (first layer): the residual stream comes from memory
 #pragma unroll
         for (int T = 0; T < NT; ++T) acc[T] = ld_x(T);
+        __syncthreads(); // the vectors staged by all waves in the prologue are visible
     }
 
     stamp(6);
@@ -435,14 +444,14 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             constexpr int W = decltype(wc)::value;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, qkv_bytes, 0x00020000);
             const float sc = W == 0 ? a_qs : 1.0f;
-            auto head = [&](int i4, auto yc, auto pendc) __attribute__((always_inline)) { // tiles i4 .. i4+3 of this part = one head = slabs (W * 24 + i4) / 2, +1
+            auto head = [&](int i4, auto coldc, auto contc, auto yo, auto yc, auto pendc) __attribute__((always_inline)) { // tiles i4 .. i4+3 of this part = one head
                 // vx_dino_block16_pack_qkv orders the rows of a tile pair so that this lane's 4 + 4 results are the 8 CONSECUTIVE features
                 // 32 p + 8g .. + 7 of the head: one 16-byte store per pair, 64 contiguous bytes per token row
                 const float* bq = vec + V_BQKV + 16 * (W * NT + i4) + 8 * g;
                 auto b4 = [&](int o) __attribute__((always_inline)) -> f32x4 { const float4 q = *reinterpret_cast<const float4*>(bq + o); f32x4 c = {q.x, q.y, q.z, q.w}; return c; };
                 f32x4 cx[2] = {b4(0), b4(4)}, cy[2] = {b4(32), b4(36)};
-                if constexpr (CI(pendc)) step(pair_chain(cx), pair_chain(cy), flush_side, yc);
-                else step(pair_chain(cx), pair_chain(cy), no_side, yc);
+                if constexpr (CI(pendc)) stepx(pair_chain(cx), pair_chain(cy), flush_side, coldc, contc, yo, yc);
+                else stepx(pair_chain(cx), pair_chain(cy), no_side, coldc, contc, yo, yc);
                 auto cvt8 = [&](const f32x4& c0, const f32x4& c1) __attribute__((always_inline)) -> u32x4 {
                     f16x8 o = {(f16)(c0[0] * sc), (f16)(c0[1] * sc), (f16)(c0[2] * sc), (f16)(c0[3] * sc), (f16)(c1[0] * sc), (f16)(c1[1] * sc), (f16)(c1[2] * sc), (f16)(c1[3] * sc)};
                     return __builtin_bit_cast(u32x4, o);
@@ -452,19 +461,23 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
                 pend_off = tok_off + (unsigned)(i4 >> 2) * head_stride;
                 pend_rs = rs;
             };
-            // YOUNGER at the boundary in front of a head = the stores issued during the step before it: the 2 of the head before last;
-            // none in front of the second head of q; in front of the first one the 24 residual-stream stores of the fc2 epilogue (+ 24 of
-            // the tap), all younger than the copies of its slabs (QKV-only instance: the x loads, already consumed)
+            // YOUNGER. The first head of q opens COLD: behind the copies of its pair lie the 24 residual-stream stores of the fc2 epilogue
+            // (+ 24 of the tap) (QKV-only instance: the x loads, already consumed). A boundary taken inside a head's step (for the
+            // next head) follows the stores issued in that step: the 2 pending ones of the head before (none in q's first head).
+            // (yo of the later heads only matters for DG == 0, where every step opens with its own boundary.)
             constexpr std::integral_constant<int, 2> two{};
-            constexpr std::integral_constant<int, 1> yes{};
             if constexpr (W == 0) {
-                head(0, std::integral_constant<int, MLP ? (TAP ? 2 * NT : NT) : 0>{}, none);
-                head(4, none, yes);
+                head(0, yes, yes, std::integral_constant<int, MLP ? (TAP ? 2 * NT : NT) : 0>{}, none, none);
+                head(4, none, yes, none, two, yes);
 #pragma unroll 1
-                for (int i4 = 8; i4 < NT; i4 += 4) head(i4, two, yes);
+                for (int i4 = 8; i4 < NT; i4 += 4) head(i4, none, yes, two, two, yes);
+            } else if constexpr (W == 1) {
+#pragma unroll 1
+                for (int i4 = 0; i4 < NT; i4 += 4) head(i4, none, yes, two, two, yes);
             } else {
 #pragma unroll 1
-                for (int i4 = 0; i4 < NT; i4 += 4) head(i4, two, yes);
+                for (int i4 = 0; i4 < NT - 4; i4 += 4) head(i4, none, yes, two, two, yes);
+                head(NT - 4, none, none, two, two, yes); // the last step of the launch
             }
         };
         qkv_part(std::integral_constant<int, 0>{}, a_q);
