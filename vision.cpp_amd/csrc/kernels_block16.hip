@@ -277,11 +277,14 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         // LayerScale is folded into the weights by the caller (Wo' = lambda1 Wo, bo' = lambda1 bo; W2', b2' likewise), so the residual
         // stream itself is the accumulator: acc = x + bo', the out-proj chains add Wo' att onto it and acc IS x1 afterwards -- no
         // epilogue arithmetic, and x1 never goes to memory (the fc2 chains continue on it).
+        // Only the tiles of the first two steps are loaded up front; step j requests the tiles of step j+2 and adds bo' to those of step
+        // j+1 just before the boundary in front of it (where the wait for the copies issued before these loads is due anyway): the cold
+        // HBM read of the residual stream (192 KiB per workgroup, all workgroups at once) runs under the out-proj MFMAs.
 #pragma unroll
-        for (int T = 0; T < NT; ++T) acc[T] = ld_x(T);
+        for (int T = 0; T < 8; ++T) acc[T] = ld_x(T);
         __syncthreads(); // the vectors staged by all waves in the prologue are visible (the row loads above are in flight meanwhile)
 #pragma unroll
-        for (int T = 0; T < NT; ++T) acc[T] = acc[T] + vec4(vec + V_BO, T);
+        for (int T = 0; T < 4; ++T) acc[T] = acc[T] + vec4(vec + V_BO, T);
         stamp(2);
         auto acc_chain = [&](auto t0c) __attribute__((always_inline)) { // slab of tiles t0, t0+1, fragments [k-block][tile]
             return [&](auto fc, const f16x8& w) __attribute__((always_inline)) {
@@ -291,7 +294,12 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         };
         static_for<N_OUT / 2>([&](auto jc) __attribute__((always_inline)) { // step j: slabs 2j, 2j+1 = tiles 4j .. 4j+3
             constexpr int j = CI(jc);
-            stepx(acc_chain(std::integral_constant<int, 4 * j>{}), acc_chain(std::integral_constant<int, 4 * j + 2>{}), no_side,
+            auto x_side = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = CI(ic);
+                if constexpr (i >= 2 && i < 10 && i % 2 == 0 && j + 2 < N_OUT / 2) { constexpr int T = 4 * (j + 2) + (i - 2) / 2; acc[T] = ld_x(T); }
+                if constexpr (i >= 40 && i < 44 && j + 1 < N_OUT / 2) { constexpr int T = 4 * (j + 1) + (i - 40); acc[T] = acc[T] + vec4(vec + V_BO, T); }
+            };
+            stepx(acc_chain(std::integral_constant<int, 4 * j>{}), acc_chain(std::integral_constant<int, 4 * j + 2>{}), x_side,
                   std::integral_constant<int, j == 0>{}, std::integral_constant<int, (j + 1 < N_OUT / 2)>{}, none, none);
         });
         stamp(3);
