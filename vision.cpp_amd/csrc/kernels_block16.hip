@@ -14,9 +14,13 @@
 //     by the other's MFMAs -- the 32-token form's limit (one wave per SIMD: every wait is an idle SIMD).
 //     The price: a weight fragment (1 KiB) feeds 16 instead of 32 tokens, i.e. one ds_read_b128 per 16-cycle MFMA -- the LDS
 //     array's full read rate (256 B/clk/CU) at full MFMA rate.
-//   * Weights stream exactly as in the 32-token form: 24 KiB slabs (24 fragments) in consumption order, registers -> 4-stage
-//     LDS ring, one workgroup barrier per pair of slabs; 144 slabs per launch. Slab contents differ (16-row fragments), so the
-//     kernel has its own packers (vx_dino_block16_pack_*).
+//   * Weights stream as 24 KiB slabs (24 fragments) in consumption order -- 144 per launch, global -> LDS by DMA
+//     (global_load_lds_dwordx4 issued from inline asm so that hipcc's vmcnt bookkeeping does not see it; the kernel places its own
+//     counted waits) into a 4-stage ring = two slab PAIRS. A step consumes one pair as two interleaved MFMA streams (four
+//     accumulation chains); one workgroup barrier per step (72 per launch). Outside the MLP loop the barrier in front of the next
+//     pair is taken one MFMA group before the end of the step, so the last group runs under the barrier skew and the window fill.
+//     Slab contents differ from the 32-token form (16-row fragments), so the kernel has its own packers (vx_dino_block16_pack_*).
+//   * What was measured and dropped (slab-granular ring, four-wave workgroups, priorities, store placement): profiles/r02_block16_variants.txt.
 #include "vx_common.h"
 
 #include <cstdlib>
