@@ -1,14 +1,15 @@
 #!/bin/bash
-# end-to-end A/B on ONE box of two sources of the 16-token block kernel: $1, $2 = .hip files; bench.py step time with each
+# end-to-end A/B on ONE box of two sources of one kernel file (OBJ=kernels_attn ...): $1, $2 = source files in csrc/; bench.py step time with each
 set -e
+OBJ=${OBJ:-kernels_block16}
 cd vision.cpp_amd/csrc
 i=0
 for src in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -x hip -c "$src" -o build/kernels_block16.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -x hip -c "$src" -o build/$OBJ.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libvisioncpp_ab_$i.so build/*.o -Wl,--no-undefined
   i=$((i+1))
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -c kernels_block16.hip -o build/kernels_block16.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -c $OBJ.hip -o build/$OBJ.o
 cd ../..
 for rnd in 1 2; do
   for j in $(seq 0 $((i-1))); do
