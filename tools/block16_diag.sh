@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of builds of kernels_block16.hip on ONE box: VARIANTS is a list of name=flags (flags: -DVISP_BLOCK16_DBG=n diagnostic bits,
-# -DVISP_BLOCK16_PF=n fragment window, -DVISP_BLOCK16_GRP=0/1 grouped waits, ...); launch times at batch 23 / 32 / 11
+# -DVISP_BLOCK16_PF=n fragment window, -DVISP_BLOCK16_DEFER=n / _DEFER_MLP=n groups run after the next pair's boundary, ...); launch times at batch 23 / 32 / 11
 set -e
 cd vision.cpp_amd/csrc
 IFS=';' read -ra VS <<< "${VARIANTS:-base=;nofeed=-DVISP_BLOCK16_DBG=1;nofrag=-DVISP_BLOCK16_DBG=8;nogelu=-DVISP_BLOCK16_DBG=32;nobarrier=-DVISP_BLOCK16_DBG=64}"

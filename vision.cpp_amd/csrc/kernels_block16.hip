@@ -52,9 +52,6 @@ constexpr int V_TOTAL = 6528;
 #ifndef VISP_BLOCK16_DEFER_MLP
 #define VISP_BLOCK16_DEFER_MLP 0
 #endif
-#ifndef VISP_BLOCK16_GRP
-#define VISP_BLOCK16_GRP 1
-#endif
 constexpr int PF = VISP_BLOCK16_PF;   // fragment window per stream (A/B builds: tools/block16_diag.sh)
 constexpr int DG = VISP_BLOCK16_DEFER; // groups of a step that run after the next pair's boundary (0: every step opens with its own boundary)
 static_assert(PF % 2 == 0 && FR % PF == 0 && PF - 2 * DG >= 2, "the window must hold the deferred groups and the next step's first group");
