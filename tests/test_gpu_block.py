@@ -106,6 +106,8 @@ def block_fn(request):
     (300, 75, True, False, True),      # tail workgroup: 44 valid rows, two waves with none; images straddle workgroups
     (130, 65, True, True, False),      # last layer: tap, no next QKV
     (257, 257, False, False, True),    # first layer: LN1 + QKV only
+    (200, 50, True, False, False),     # MLP half alone (no tap, no next layer)
+    (16, 16, True, True, True),        # a single wave's worth of rows
     (1370 * 2, 1370, True, True, True),  # two images of the north-star grid
 ])
 def test_block_vs_oracle(block_fn, M, T, mlp, tap, qkv):
