@@ -205,10 +205,13 @@ def test_non_square_extent_vs_oracle(small):
     assert _rel(raw[0], want_raw) < 3e-2
 
 
-def test_overlapped_host_pipeline_is_bit_identical(small):
-    """visp_depthany_pipeline_*: batches streamed through 3 slots (upload / compute / download overlapped on three streams)
+@pytest.mark.parametrize("executors", [2, 1])
+def test_overlapped_host_pipeline_is_bit_identical(small, executors, monkeypatch):
+    """visp_depthany_pipeline_*: batches streamed through 3 slots (upload / compute / download overlapped on three streams,
+    consecutive forwards on two executors = two workspaces / graphs / compute streams over the same weights, or on one)
     give exactly the synchronous entry point's results, in submission order, from pageable and from pinned input; a slot
     cannot be reused before its result was read."""
+    monkeypatch.setenv("VISP_PIPELINE_EXECUTORS", str(executors))
     imgs = synth.images(8, 518, 518, seed=91)
     want = small.compute_batch(imgs)
     small.use_graph(True)

@@ -114,6 +114,7 @@ struct depthany_model : model_base { // vision.h:339-347 counterpart
     depthany_params params;
     depthany_weights weights;
     device_buffer weight_arena;
+    bool owns_weights = true; // false for an executor cloned from another model (depthany_clone_executor): the arena is borrowed
     bool weights_uploaded = false;
     depthany_workspace ws;
     bool use_graph = false, captures = false, timing = false;
@@ -133,6 +134,10 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
 // after a load_no_upload model's arena has been filled (RCCL broadcast from the rank that read the file)
 void depthany_weights_ready(depthany_model&);
 
+// a second executor over the SAME device weights: its own workspace, streams, events and hipGraph, so that two forwards can be in
+// flight on the device at once (the source model must outlive it)
+depthany_model* depthany_clone_executor(depthany_model const&);
+
 void depthany_reserve(depthany_model&, int batch, int w, int h);
 // rgb_u8 [B,h,w,3] on the device -> out f32 [B,h,w] normalised (+ raw depth if raw_out != null)
 void depthany_compute_batch_device(depthany_model&, void const* rgb_dev, int batch, int w, int h, void* out_dev,
@@ -143,9 +148,13 @@ void depthany_compute_batch_host(depthany_model&, uint8_t const* rgb, int batch,
 // input (pinned staging -> HBM on a copy stream), the forward (the model's compute stream) and the download of its output
 // (HBM -> pinned, second copy stream) are chained by events, so the upload of batch k+1 and the download of batch k-1 run
 // under the compute of batch k. The reference times upload + compute + download per call (tests/benchmark.cpp:55-91); this
-// is that loop with the transfers hidden.
+// is that loop with the transfers hidden. VISP_PIPELINE_EXECUTORS=2 lets consecutive batches overlap ON the device as well
+// (alternating executors: own workspace, graph and compute stream over the same weights). Measured at batch 32: 7.0-7.2 ms per
+// batch against 6.85 with one executor -- three sub-batch streams already fill the chip, six contend -- so the default is one.
 struct depthany_pipeline {
     depthany_model* model = nullptr;
+    std::vector<depthany_model*> exec;      // exec[0] = model, the others are clones owned by the pipeline
+    std::vector<void*> compute_stream;      // one per executor; [0] = the backend's stream
     int batch = 0, w = 0, h = 0, n_slots = 0;
     size_t in_bytes = 0, out_bytes = 0;
     struct slot {
@@ -156,6 +165,7 @@ struct depthany_pipeline {
     std::vector<slot> slots;
     void *h2d_stream = nullptr, *d2h_stream = nullptr;
     int next = 0;
+    long n_submitted = 0;
     ~depthany_pipeline();
 };
 depthany_pipeline* depthany_pipeline_create(depthany_model&, int batch, int w, int h, int n_slots);
