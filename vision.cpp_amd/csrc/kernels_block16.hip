@@ -262,8 +262,13 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 const f32x4 gm = vec4(gamma, 2 * kb + t2), bt = vec4(beta, 2 * kb + t2);
+                // as x * (rstd g) + (b - mean rstd g): written as (x - mean) * rstd * g + b, hipcc keeps the 96 differences of the
+                // variance pass alive for this loop (common subexpression) and spills 56 registers around it
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xb[kb][4 * t2 + j] = (f16)fmaf((acc[2 * kb + t2][j] - mean) * rstd, gm[j], bt[j]);
+                for (int j = 0; j < 4; ++j) {
+                    const float a = rstd * gm[j];
+                    xb[kb][4 * t2 + j] = (f16)fmaf(acc[2 * kb + t2][j], a, fmaf(-mean, a, bt[j]));
+                }
             }
     };
 
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             const f32x4 gm = vec4(vec + V_GF, T), bt = vec4(vec + V_BF, T);
             f16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (f16)fmaf((acc[T][j] - mean) * rstd, gm[j], bt[j]);
+            for (int j = 0; j < 4; ++j) { const float a = rstd * gm[j]; o[j] = (f16)fmaf(acc[T][j], a, fmaf(-mean, a, bt[j])); }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_f, foff, 32 * T, 0);
         }
     }
