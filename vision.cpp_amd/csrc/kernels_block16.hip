@@ -442,17 +442,48 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         const int qkv_bytes = (int)((long)a_M * row_bytes_f16); // each of q, k, v: [B, H, T, 64] f16 = M * 384 * 2 bytes
         const unsigned tok_off = m < a_M ? ((unsigned)b * a_H * a_T + tok) * 128 + 16 * g : 0x80000000u;
         const unsigned head_stride = (unsigned)a_T * 128;
-        // The two 16-byte stores of a head are issued in the MIDDLE of the next head's step (8 waves x 2 KiB = a few hundred cycles of
-        // the CU's store path, which otherwise sit between the last MFMA of a step and the barrier of the next one)
+        // Everything a head needs around its 48 MFMAs is side work of the NEIGHBOURING steps, so that nothing but register renaming lies
+        // between two steps: its bias tiles are read during the step before (nb), its results are converted and stored (two 16-byte
+        // stores: 8 waves x 2 KiB = a few hundred cycles of the CU's store path) during the step after (raw -> pend).
+        f32x4 nb[4];                 // bias tiles of the next head
+        f32x4 raw[4];                // results of the head before, f32
+        float raw_sc = 1.0f;
         u32x4 pend0 = {}, pend1 = {};
         unsigned pend_off = 0x80000000u;
         __amdgpu_buffer_rsrc_t pend_rs = __builtin_amdgcn_make_buffer_rsrc(a_q, 0, qkv_bytes, 0x00020000);
-        auto flush_side = [&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = CI(ic);
-            if constexpr (!(DBG & 128)) {
-                if constexpr (i == 16) __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
-                if constexpr (i == 32) __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
-            }
+        auto bias4 = [&](int R, int o) __attribute__((always_inline)) -> f32x4 { // tile group R (4 tiles = one head), floats o .. o+3 of this lane's 8
+            const float4 q = *reinterpret_cast<const float4*>(vec + V_BQKV + 16 * R + 8 * g + o);
+            f32x4 c = {q.x, q.y, q.z, q.w};
+            return c;
+        };
+        auto cvt4 = [&](const f32x4& c, float sc, u32x4& dst, auto halfc) __attribute__((always_inline)) { // 4 results -> half of a 16-byte store
+            typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+            const h2t a = {(f16)(c[0] * sc), (f16)(c[1] * sc)}, bb = {(f16)(c[2] * sc), (f16)(c[3] * sc)};
+            dst[2 * CI(halfc)] = __builtin_bit_cast(unsigned, a);
+            dst[2 * CI(halfc) + 1] = __builtin_bit_cast(unsigned, bb);
+        };
+        // side work of a head's step: R = its first tile (global over q | k | v), PREV: a head before it left raw results, NEXT: one follows
+        auto head_side = [&](int R, auto prevc, auto nextc) __attribute__((always_inline)) {
+            return [&, R](auto ic) __attribute__((always_inline)) {
+                constexpr int i = CI(ic);
+                (void)R;
+                if constexpr (CI(prevc) != 0) {
+                    if constexpr (i == 2) cvt4(raw[0], raw_sc, pend0, none);
+                    if constexpr (i == 4) cvt4(raw[1], raw_sc, pend0, yes);
+                    if constexpr (i == 6) cvt4(raw[2], raw_sc, pend1, none);
+                    if constexpr (i == 8) cvt4(raw[3], raw_sc, pend1, yes);
+                    if constexpr (!(DBG & 128)) {
+                        if constexpr (i == 16) __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
+                        if constexpr (i == 32) __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
+                    }
+                }
+                if constexpr (CI(nextc) != 0) {
+                    if constexpr (i == 34) nb[0] = bias4(R + 4, 0);
+                    if constexpr (i == 35) nb[1] = bias4(R + 4, 4);
+                    if constexpr (i == 36) nb[2] = bias4(R + 4, 32);
+                    if constexpr (i == 37) nb[3] = bias4(R + 4, 36);
+                }
+            };
         };
         auto qkv_part = [&](auto wc, void* base) __attribute__((always_inline)) {
             constexpr int W = decltype(wc)::value;
@@ -461,17 +492,12 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             auto head = [&](int i4, auto coldc, auto contc, auto yo, auto yc, auto pendc) __attribute__((always_inline)) { // tiles i4 .. i4+3 of this part = one head
                 // vx_dino_block16_pack_qkv orders the rows of a tile pair so that this lane's 4 + 4 results are the 8 CONSECUTIVE features
                 // 32 p + 8g .. + 7 of the head: one 16-byte store per pair, 64 contiguous bytes per token row
-                const float* bq = vec + V_BQKV + 16 * (W * NT + i4) + 8 * g;
-                auto b4 = [&](int o) __attribute__((always_inline)) -> f32x4 { const float4 q = *reinterpret_cast<const float4*>(bq + o); f32x4 c = {q.x, q.y, q.z, q.w}; return c; };
-                f32x4 cx[2] = {b4(0), b4(4)}, cy[2] = {b4(32), b4(36)};
-                if constexpr (CI(pendc)) stepx(pair_chain(cx), pair_chain(cy), flush_side, coldc, contc, yo, yc);
-                else stepx(pair_chain(cx), pair_chain(cy), no_side, coldc, contc, yo, yc);
-                auto cvt8 = [&](const f32x4& c0, const f32x4& c1) __attribute__((always_inline)) -> u32x4 {
-                    f16x8 o = {(f16)(c0[0] * sc), (f16)(c0[1] * sc), (f16)(c0[2] * sc), (f16)(c0[3] * sc), (f16)(c1[0] * sc), (f16)(c1[1] * sc), (f16)(c1[2] * sc), (f16)(c1[3] * sc)};
-                    return __builtin_bit_cast(u32x4, o);
-                };
-                pend0 = cvt8(cx[0], cx[1]);
-                pend1 = cvt8(cy[0], cy[1]);
+                const int R = W * NT + i4;
+                f32x4 cx[2] = {nb[0], nb[1]}, cy[2] = {nb[2], nb[3]};
+                // the stores of the head before go to ITS part's buffer: pend_off / pend_rs still describe it during this step
+                stepx(pair_chain(cx), pair_chain(cy), head_side(R, pendc, contc), coldc, contc, yo, yc);
+                raw[0] = cx[0]; raw[1] = cx[1]; raw[2] = cy[0]; raw[3] = cy[1];
+                raw_sc = sc;
                 pend_off = tok_off + (unsigned)(i4 >> 2) * head_stride;
                 pend_rs = rs;
             };
@@ -481,6 +507,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             // (yo of the later heads only matters for DG == 0, where every step opens with its own boundary.)
             constexpr std::integral_constant<int, 2> two{};
             if constexpr (W == 0) {
+                nb[0] = bias4(0, 0); nb[1] = bias4(0, 4); nb[2] = bias4(0, 32); nb[3] = bias4(0, 36);
                 head(0, yes, yes, std::integral_constant<int, MLP ? (TAP ? 2 * NT : NT) : 0>{}, none, none);
                 head(4, none, yes, none, two, yes);
 #pragma unroll 1
@@ -497,6 +524,8 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         qkv_part(std::integral_constant<int, 0>{}, a_q);
         qkv_part(std::integral_constant<int, 1>{}, a_k);
         qkv_part(std::integral_constant<int, 2>{}, a_v);
+        cvt4(raw[0], raw_sc, pend0, none); cvt4(raw[1], raw_sc, pend0, yes);
+        cvt4(raw[2], raw_sc, pend1, none); cvt4(raw[3], raw_sc, pend1, yes);
         if constexpr (!(DBG & 128)) {
             __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
