@@ -475,6 +475,9 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
                     if constexpr (!(DBG & 128)) {
                         if constexpr (i == 16) __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
                         if constexpr (i == 32) __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
+                    } else { // keep the results alive so that the MFMAs stay
+                        if constexpr (i == 16) asm volatile("" ::"v"(pend0));
+                        if constexpr (i == 32) asm volatile("" ::"v"(pend1));
                     }
                 }
                 if constexpr (CI(nextc) != 0) {
