@@ -674,7 +674,16 @@ int launch_variant(const vx_dconv_args& a, hipStream_t s) {
     constexpr int smem = dconv_smem_bytes<COUT, RES, HSV>();
     if (!prepare_variant<COUT, EPI, AR, STAMP, RES, HSV>()) return 0;
     const long tiles = (long)a.B * tile_grid(a.H, a.W).total();
-    const int blocks = (int)(tiles < dconv_grid_blocks() ? tiles : dconv_grid_blocks());
+    // Persistent blocks, one per CU at most. The number of ROUNDS (tiles per block) is what the launch takes; given the rounds, the
+    // fewest blocks that still do it in that many leave the other CUs to concurrent launches (550 tiles: 184 blocks x 3 instead of
+    // 256 blocks doing 3 or 2 -- the step is CU-time bound). Per XCD, because the kernel deals the tiles out by XCD.
+    int blocks = (int)(tiles < dconv_grid_blocks() ? tiles : dconv_grid_blocks());
+    if (tiles > dconv_grid_blocks() && dconv_grid_blocks() % 8 == 0) {
+        const long per_xcd = (tiles + 7) / 8, cu_per_xcd = dconv_grid_blocks() / 8;
+        const long rounds = (per_xcd + cu_per_xcd - 1) / cu_per_xcd;
+        const long blocks_per_xcd = (per_xcd + rounds - 1) / rounds;
+        blocks = (int)(8 * blocks_per_xcd);
+    }
     hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV>), dim3(blocks), dim3(512), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
