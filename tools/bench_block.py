@@ -125,6 +125,10 @@ def block_stamps(B, fn="vx_dino_block_f16"):
         print(f"   {nm:36s} median {np.median(d):9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}")
     life = t[:, 10] - t[:, 0]
     print(f"   {'workgroup lifetime':36s} median {np.median(life):9.0f}  p10 {np.percentile(life, 10):9.0f}  p90 {np.percentile(life, 90):9.0f}")
+    if t[:, 13].max() > 0:  # -DVISP_BLOCK16_DBG=1024: waits of the two waves of SIMD 0 at the boundaries
+        for nm, col in (("wave 0", 11), ("wave 4", 12)):
+            vm, bar = t[:, col] >> 32, t[:, col] & 0xffffffff
+            print(f"   {nm}: {int(np.median(t[:, 13]))} boundaries; waiting for its copies: median {np.median(vm):9.0f} cycles in total, at the barrier: {np.median(bar):9.0f}")
     rt = (t[:, 15] - t[:, 14]).astype(np.float64)
     ok = rt > 0
     print(f"   shader clock: median {np.median(life[ok] / rt[ok] * 100.0):.0f} MHz")

@@ -87,7 +87,7 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
 }
 
 // DBG: diagnostic builds only (-DVISP_BLOCK16_DBG=n, tools/bench_block.py): 1 no global weight loads, 2 no ring writes, 8 no fragment
-// reads, 32 no GELU, 64 no step barrier, 128 no q/k/v stores -- results are garbage, the launch time shows what each part of the stream costs
+// reads, 32 no GELU, 64 no step barrier, 128 no q/k/v stores, 1024 time the waits at every boundary (valid results) -- results are garbage, the launch time shows what each part of the stream costs
 #ifndef VISP_BLOCK16_DBG
 #define VISP_BLOCK16_DBG 0
 #endif
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     const unsigned char *curx = rd0, *cury = rd0 + SLAB;
     f16x8 wfx[PF] = {}, wfy[PF] = {};
 
+    unsigned long long w_vm = 0, w_bar = 0, w_n = 0; // DBG & 1024 only
     // A BOUNDARY in front of a slab pair: this wave's copies of the pair have landed (counted vmcnt wait), everybody's have and every
     // wave is done reading the other pair (workgroup barrier), the window is (re)filled and the copies of the pair after it are requested
     // into the stages just freed. YOUNGER = vector-memory operations this wave issued AFTER the copies it waits for (output stores):
@@ -171,8 +172,17 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     // latency at every boundary (CDNA4 counts stores in vmcnt). 0 is always safe.
     auto boundary = [&](auto yc, auto nfill) __attribute__((always_inline)) {
         constexpr int YOUNGER = CI(yc);
+        if constexpr (DBG & 1024) { // diagnostic: how long this wave waits for its copies / at the barrier (slots 11 .. 13 of the stamps)
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            w_vm += t1 - t0; w_bar += t2 - t1; w_n += 1;
+        } else {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
         if constexpr (!(DBG & 64)) __syncthreads();
+        }
         curx = rd0 + st * SLAB;
         cury = curx + SLAB;
         // the window fill goes first: the scalar work and the issue of the 6 copies run under its LDS latency
@@ -536,6 +546,13 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     }
     stamp(10);
     stamp(15);
+    if constexpr (DBG & 1024) {
+        if (a_stamps && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 4)) { // the two waves of SIMD 0
+            unsigned long long* o = a_stamps + (size_t)blockIdx.x * 16 + (wave == 0 ? 11 : 12);
+            o[0] = (w_vm << 32) | (w_bar & 0xffffffffull);
+            if (wave == 0) a_stamps[(size_t)blockIdx.x * 16 + 13] = w_n;
+        }
+    }
 }
 
 // ---- host: weight packing ------------------------------------------------------------------------------------------------
