@@ -6,6 +6,9 @@ BASELINE.json configs[2].)
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: started without RANK in the environment, `--gpus N` launches the second form itself as a
+CHILD process (before this process has imported torch or loaded the HIP library; never an exec) and exits with its code.
+
 One process per GPU. A step = one pass of the hot path (depthany_compute semantics per image:
 pre-process, DINOv2-S encoder, DPT neck/head, min-max normalise) over one batch of 32 synthetic
 518x518x3 uint8 images that are already resident in HBM. Images are independent units, so the
@@ -26,7 +29,40 @@ import tempfile
 import time
 from pathlib import Path
 
-import numpy as np
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: start N fresh rank processes through
+    torch.distributed.run as a child of this (still GPU-free) process and return its exit code. The ranks inherit stdout,
+    so rank 0's JSON line is this command's one line of output."""
+    n = 1
+    for i, a in enumerate(sys.argv[1:]):
+        if a == "--gpus" and i + 2 < len(sys.argv):
+            n = int(sys.argv[i + 2])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "RANK" in os.environ:
+        return None
+    import socket
+    import subprocess
+
+    with socket.socket() as so:  # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "16")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+if __name__ == "__main__":
+    _rc = _self_launch()
+    if _rc is not None:
+        raise SystemExit(_rc)
+
+import numpy as np  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

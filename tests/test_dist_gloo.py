@@ -69,3 +69,39 @@ def test_two_rank_gloo(tmp_path):
     got = np.load(tmp_path / "gathered.npy")
     want = synth.images(5, 28, 28, seed=1).astype(np.float32).mean(axis=-1)
     np.testing.assert_array_equal(got, want)
+
+
+def test_bench_self_launch_starts_n_ranks_and_returns_child_code():
+    """`python bench.py --gpus 2` without RANK in the environment must start two fresh rank processes through
+    torch.distributed.run as a child (never an exec) and hand back its exit code. On this CPU box every rank refuses
+    ("needs an MI355X", no CPU fallback), which is exactly what shows both ranks ran the real entry."""
+    import subprocess
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box this test stays a CPU test
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-backend", "gloo",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_gloo_two_ranks_one_gpu():
+    """The N > 1 launch path end to end on the one GPU of the box: two ranks over gloo, both on device 0, weight arena
+    broadcast from rank 0, one JSON line with n_gpus 2 from rank 0."""
+    import json
+    import subprocess
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo",
+                        "--device", "0", "--min-seconds", "0", "--no-pipeline", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 64 and res["value"] > 0
