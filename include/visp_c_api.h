@@ -216,6 +216,10 @@ VISP_API int32_t visp_swin_encode_batch_device(visp_model* m, void const* rgb_u8
                                                void* stream);
 VISP_API int32_t visp_swin_encode_batch_host(visp_model* m, uint8_t const* rgb_u8, int32_t batch, int32_t w, int32_t h, float* const outs[4]);
 /* test hooks as for the other families: "patch_embed", "block_<layer>_<i>" (f16 -> f32), per-kernel-group timing */
+/* Shift-mask semantics of the window attention. 0 (default) = the reference as written: swin::layer passes the layer's attn_mask to
+ * every block and swin::block forwards it unconditionally (swin.cpp:128-139, 226-237), so the edge windows of UNSHIFTED blocks are
+ * masked too. 1 = shifted blocks only, as the reference's torch twin / the original Swin (tests/test_birefnet.py:249-255). */
+VISP_API int32_t visp_swin_set_mask_mode(visp_model* m, int32_t shifted_only);
 VISP_API int32_t visp_swin_enable_captures(visp_model* m, int32_t enable);
 VISP_API int32_t visp_swin_read_capture(visp_model* m, char const* name, float* host_out, int64_t capacity, int64_t* n_written, int64_t shape[4]);
 VISP_API int32_t visp_swin_enable_timing(visp_model* m, int32_t enable);

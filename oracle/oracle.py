@@ -561,6 +561,8 @@ def _swin_lib():
         L.vo_swin_encode.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(SwinParams), fp, C.c_int, C.c_int, fp * 4, (C.c_int * 3) * 4,
                                      C.POINTER(Capture), C.c_int]
         L.vo_free.argtypes = [C.c_void_p]
+        L.vo_swin_set_mask_mode.argtypes = [C.c_int]
+        L.vo_swin_get_mask_mode.restype = C.c_int
         L._swin_ready = True
     return L
 
@@ -579,11 +581,25 @@ def swin_attention_mask(w: int, h: int, window: int) -> np.ndarray:
     return out
 
 
-def swin_block(model: "Model", prefix: str, x: np.ndarray, w: int, h: int, heads: int, window: int, shift: int) -> np.ndarray:
-    """x: tokens [h*w, C] (row = y*w + x) -> same shape."""
+def swin_set_mask_mode(shifted_only: bool) -> None:
+    """False (default) = the reference as written: the layer's shift mask acts in every block (swin.cpp:128-139, 226-237);
+    True = shifted blocks only (the reference's torch twin / HuggingFace Swin, which tests/golden/swin_mini.npz was made with)."""
+    _swin_lib().vo_swin_set_mask_mode(int(bool(shifted_only)))
+
+
+def swin_get_mask_mode() -> bool:
+    return bool(_swin_lib().vo_swin_get_mask_mode())
+
+
+def swin_block(model: "Model", prefix: str, x: np.ndarray, w: int, h: int, heads: int, window: int, shift: int,
+               masked: bool | None = None) -> np.ndarray:
+    """x: tokens [h*w, C] (row = y*w + x) -> same shape. masked: apply the layer's shift mask (None = as the current mask mode
+    would: always for shifted blocks, for unshifted ones only in the reference-as-written mode)."""
     x = _f32(x).copy()
     assert x.shape[0] == w * h
-    mask = swin_attention_mask(w, h, window) if shift > 0 else None
+    if masked is None:
+        masked = shift > 0 or not swin_get_mask_mode()
+    mask = swin_attention_mask(w, h, window) if masked else None
     _check(_swin_lib().vo_swin_block(model._h, prefix.encode(), _fp(x), w, h, x.shape[1], heads, window, shift, _fp(mask)))
     return x
 

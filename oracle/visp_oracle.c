@@ -2111,7 +2111,17 @@ static int swin_window_attention(const vo_model* m, const char* prefix, const fl
     return 1;
 }
 
-/* block (swin.cpp:117-163) on tokens x [h*w][C] (row = y*w + x), in place. shift > 0 needs the mask of (w, h). */
+/* Which blocks the shift mask acts in. 0 (default) = the reference as written: swin::layer fetches the layer's attn_mask once
+ * and hands it to EVERY block (swin.cpp:226-237); swin::block forwards it to window_attention unconditionally (:128-139), which
+ * adds it whenever it is non-null (:82-91) -- so the edge windows of the unshifted blocks are masked too. 1 = shifted blocks
+ * only, the semantics of the reference's torch twin (tests/test_birefnet.py:249-255) and of HuggingFace's Swin, which the
+ * tests/golden/swin_mini.npz fixture was generated with. */
+static int g_swin_mask_shifted_only = 0;
+void vo_swin_set_mask_mode(int shifted_only) { g_swin_mask_shifted_only = shifted_only != 0; }
+int vo_swin_get_mask_mode(void) { return g_swin_mask_shifted_only; }
+
+/* block (swin.cpp:117-163) on tokens x [h*w][C] (row = y*w + x), in place. The mask is applied iff it is non-NULL, exactly as
+ * swin::block does; shift > 0 needs the mask of (w, h) (the reference's ASSERT at :133). */
 int vo_swin_block(const vo_model* m, const char* prefix, float* x, int w, int h, int C, int heads, int ws, int shift, const float* mask) {
     char p[200];
     const int64_t T = (int64_t)w * h;
@@ -2134,7 +2144,7 @@ int vo_swin_block(const vo_model* m, const char* prefix, float* x, int w, int h,
     free(ln);
     float* aw = (float*)malloc((size_t)n_win * N * C * 4);
     snprintf(p, sizeof p, "%s.attn", prefix);
-    int ok = swin_window_attention(m, p, win, (int)n_win, ws, C, heads, shift > 0 ? mask : NULL, (int)n_win, aw);
+    int ok = swin_window_attention(m, p, win, (int)n_win, ws, C, heads, mask, (int)n_win, aw);
     free(win);
     if (!ok) { free(aw); return 0; }
     /* window_reverse, roll back by +shift, crop, + shortcut */
@@ -2220,14 +2230,15 @@ int vo_swin_encode(const vo_model* m, const char* prefix, const vo_swin_params* 
     for (int l = 0; l < 4 && ok; ++l) {
         const int ws = P->window_size, heads = P->n_heads[l];
         float* mask = NULL;
-        if (P->depths[l] > 1) {
+        if (P->depths[l] > 1 || !g_swin_mask_shifted_only) { /* swin_precompute makes one per layer (swin.cpp:304-313) */
             const int nwx = (w + ws - 1) / ws, nwy = (h + ws - 1) / ws;
             mask = (float*)malloc((size_t)nwx * nwy * ws * ws * ws * ws * 4);
             vo_swin_attention_mask(w, h, ws, mask);
         }
         for (int b = 0; b < P->depths[l] && ok; ++b) {
             snprintf(p, sizeof p, "%s.layers.%d.blocks.%d", prefix, l, b);
-            ok = vo_swin_block(m, p, x, w, h, C, heads, ws, b % 2 == 0 ? 0 : ws / 2, mask);
+            const int shift = b % 2 == 0 ? 0 : ws / 2;
+            ok = vo_swin_block(m, p, x, w, h, C, heads, ws, shift, (shift > 0 || !g_swin_mask_shifted_only) ? mask : NULL);
             snprintf(cname, sizeof cname, "block_%d_%d", l, b);
             if (ok) capture(captures, n_captures, cname, x, (int64_t)w * h * C);
         }

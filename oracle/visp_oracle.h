@@ -203,11 +203,15 @@ int vo_sam_compute(const vo_model*, const float* embed, int res, int dim, int im
 typedef struct { int embed_dim, window_size, depths[4], n_heads[4]; } vo_swin_params; /* swin_t: 96, 7, {2,2,6,2}, {3,6,12,24} (swin.cpp:266-275) */
 void vo_swin_rel_pos_index(int window, int32_t* dst /*[ws^4]*/);                      /* swin.cpp:26-38 */
 void vo_swin_attention_mask(int w, int h, int window, float* out /*[nw_y*nw_x][ws^2][ws^2]*/); /* swin.cpp:165-213 */
-/* block (swin.cpp:117-163) on tokens x [h*w][C] in place; mask = vo_swin_attention_mask(w, h) when shift > 0 */
+/* block (swin.cpp:117-163) on tokens x [h*w][C] in place; the mask (vo_swin_attention_mask(w, h)) is applied iff non-NULL, as swin::block does */
 int vo_swin_block(const vo_model*, const char* prefix, float* x, int w, int h, int C, int heads, int window, int shift, const float* mask);
 /* patch_merging (swin.cpp:140-161): *out malloc'd [(h/2)*(w/2)][*cout], free with vo_free */
 int vo_swin_patch_merging(const vo_model*, const char* prefix, const float* x, int w, int h, int C, float** out, int* cout);
 /* swin_encode (swin.cpp:237-262): normalised rgb_f32 image [H][W][3] -> four normed stage outputs (NHWC, malloc'd: vo_free) */
+/* 0 (default) = the reference as written: swin::layer passes the shift mask to every block (swin.cpp:226-237); 1 = shifted
+ * blocks only (the reference's torch twin, HuggingFace Swin). Process-wide; used by vo_swin_encode and vo_birefnet_predict. */
+void vo_swin_set_mask_mode(int shifted_only);
+int vo_swin_get_mask_mode(void);
 int vo_swin_encode(const vo_model*, const char* prefix, const vo_swin_params*, const float* image, int W, int H, float* outs[4],
                    int dims[4][3], vo_capture* captures, int n_captures);
 void vo_free(void* p);

@@ -142,10 +142,22 @@ def _load(device, tmp_path, cfg, seed):
     return vision.SwinEncoder.load(path, device), oracle.Model(tensors, conv_idx), oracle.swin_params(cfg.embed_dim, cfg.window_size, cfg.depths, cfg.n_heads)
 
 
-def test_swin_mini_every_block_boundary(device, tmp_path):
-    """256 x 288 image: maps 64x72, 32x36, 16x18, 8x9 -- window padding and shifted-window masks at every stage."""
+@pytest.mark.parametrize("shifted_only", [False, True])
+def test_swin_mini_every_block_boundary(device, tmp_path, shifted_only):
+    """256 x 288 image: maps 64x72, 32x36, 16x18, 8x9 -- window padding and shifted-window masks at every stage. Both mask
+    semantics: the reference as written (default: the layer's mask acts in every block, swin.cpp:128-139, 226-237) and the
+    torch twin's (shifted blocks only), each against the oracle in the same mode -- and the two must differ."""
     cfg = synth.SWIN_MINI
     enc, om, P = _load(device, tmp_path, cfg, 5)
+    enc.swin_set_mask_mode(shifted_only)
+    oracle.swin_set_mask_mode(shifted_only)
+    try:
+        _check_every_block_boundary(enc, om, P, cfg, shifted_only)
+    finally:
+        oracle.swin_set_mask_mode(False)
+
+
+def _check_every_block_boundary(enc, om, P, cfg, shifted_only):
     W, H = 256, 288
     imgs = synth.images(2, W, H, seed=11)
     assert enc.output_dims(W, H) == [(64, 72, 32), (32, 36, 64), (16, 18, 128), (8, 9, 256)]
@@ -170,6 +182,11 @@ def test_swin_mini_every_block_boundary(device, tmp_path):
     again = enc.encode_batch(imgs[::-1].copy())
     for i in range(4):
         np.testing.assert_array_equal(again[i][::-1], outs[i])
+    # the other semantics give a different first stage (edge windows of the unshifted blocks)
+    enc.swin_set_mask_mode(not shifted_only)
+    other = enc.encode_batch(imgs)
+    enc.swin_set_mask_mode(shifted_only)
+    assert np.abs(other[0] - outs[0]).max() > 1e-3
 
 
 def test_swin_t_configuration(device, tmp_path):

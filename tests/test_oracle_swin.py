@@ -64,12 +64,14 @@ def test_swin_encoder_matches_transformers_fixture(golden):
     img = _input(W, H, int(golden["input_seed"]))
     P = oracle.swin_params(cfg.embed_dim, cfg.window_size, cfg.depths, cfg.n_heads)
     oracle.tinyvit_set_gelu_modes(other_mode=oracle.GELU_ERF_F32)  # transformers' "gelu" is the exact form
+    oracle.swin_set_mask_mode(True)  # transformers (like the reference's torch twin) masks the shifted blocks only
     try:
         T = (W // 4) * (H // 4)
         feats, caps = oracle.swin_encode(model, P, img, "bb", captures={"patch_embed": T * 32, "block_0_0": T * 32, "block_0_1": T * 32})
         merged = oracle.swin_patch_merging(model, "bb.layers.0.downsample", caps["block_0_1"].reshape(T, 32), W // 4, H // 4)
     finally:
         oracle.tinyvit_set_gelu_modes()
+        oracle.swin_set_mask_mode(False)
     for name, got in (("patch_embed", caps["patch_embed"]), ("block0", caps["block_0_0"]), ("block1", caps["block_0_1"])):
         want = golden[name]
         got = got.reshape(T, 32)[:: int(golden[f"step_{name}"])]
@@ -107,3 +109,44 @@ def test_swin_block_properties():
         oracle.swin_patch_merging(model, "bb.layers.0.downsample", x[: 7 * 14], 7, 14)
     with pytest.raises(RuntimeError, match="multiple of the patch size"):
         oracle.swin_encode(model, oracle.swin_params(32, 7, cfg.depths, cfg.n_heads), np.zeros((30, 32, 3), np.float32))
+
+
+def test_unshifted_block_mask_semantics_follow_the_reference_as_written():
+    """The reference's swin::layer hands the layer's attn_mask to every block and swin::block forwards it unconditionally
+    (swin.cpp:128-139, 226-237): the -inf edge mask of compute_attention_mask also acts in UNSHIFTED blocks, in the windows of
+    the last row / column. Its torch twin (tests/test_birefnet.py:249-255) masks shifted blocks only. The default here is the
+    reference as written; this pins what that means on a 14x14 map (2x2 windows of 7, shift zone = last 3 rows / columns):
+    with the mask, the tokens of the shift zone and the rest of an edge window do not see each other."""
+    cfg = synth.SWIN_MINI
+    model = _model(cfg, 1)
+    rng = np.random.default_rng(5)
+    w = h = 14
+    x = rng.standard_normal((w * h, 32)).astype(np.float32)
+    assert oracle.swin_get_mask_mode() is False  # default: reference as written
+    pfx = "bb.layers.0.blocks.0"
+    y_ref = oracle.swin_block(model, pfx, x, w, h, 1, 7, 0).reshape(h, w, 32)                 # default = masked
+    y_msk = oracle.swin_block(model, pfx, x, w, h, 1, 7, 0, masked=True).reshape(h, w, 32)
+    y_tor = oracle.swin_block(model, pfx, x, w, h, 1, 7, 0, masked=False).reshape(h, w, 32)   # torch twin
+    np.testing.assert_array_equal(y_ref, y_msk)
+    # the interior window (0, 0) carries no mask: identical either way; every edge window differs
+    np.testing.assert_array_equal(y_msk[:7, :7], y_tor[:7, :7])
+    for sl in ((slice(0, 7), slice(7, 14)), (slice(7, 14), slice(0, 7)), (slice(7, 14), slice(7, 14))):
+        assert np.abs(y_msk[sl] - y_tor[sl]).max() > 1e-3
+    # masked: perturbing the non-shift part (rows 7..10) of window (1, 0) leaves its shift-zone rows 11..13 bit-identical;
+    # unmasked they change
+    x2 = x.copy().reshape(h, w, 32)
+    x2[7:11, 0:7] += rng.standard_normal((4, 7, 32)).astype(np.float32)
+    y2_msk = oracle.swin_block(model, pfx, x2.reshape(-1, 32), w, h, 1, 7, 0, masked=True).reshape(h, w, 32)
+    y2_tor = oracle.swin_block(model, pfx, x2.reshape(-1, 32), w, h, 1, 7, 0, masked=False).reshape(h, w, 32)
+    np.testing.assert_array_equal(y2_msk[11:14, 0:7], y_msk[11:14, 0:7])
+    assert np.abs(y2_tor[11:14, 0:7] - y_tor[11:14, 0:7]).max() > 1e-4
+    # and swin_encode composes blocks per the mode: stage outputs differ between the two modes on a map with edge windows
+    P = oracle.swin_params(cfg.embed_dim, cfg.window_size, cfg.depths, cfg.n_heads)
+    img = rng.standard_normal((64, 64, 3)).astype(np.float32)
+    a = oracle.swin_encode(model, P, img)
+    oracle.swin_set_mask_mode(True)
+    try:
+        b = oracle.swin_encode(model, P, img)
+    finally:
+        oracle.swin_set_mask_mode(False)
+    assert np.abs(a[0] - b[0]).max() > 1e-4

@@ -103,7 +103,7 @@ C_API_SYMBOLS = [
     "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks", "visp_image_scale", "visp_gguf_validate",
     "visp_birefnet_image_extent", "visp_birefnet_compute_batch_device", "visp_birefnet_compute_batch_host",
     "visp_swin_load", "visp_swin_output_dims", "visp_swin_encode_batch_device", "visp_swin_encode_batch_host", "visp_swin_enable_captures",
-    "visp_swin_read_capture", "visp_swin_enable_timing", "visp_swin_read_timing",
+    "visp_swin_read_capture", "visp_swin_enable_timing", "visp_swin_read_timing", "visp_swin_set_mask_mode",
 ]
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
@@ -210,6 +210,7 @@ def init() -> ctypes.CDLL:
     lib.visp_swin_encode_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p), c_void_p]
     lib.visp_swin_encode_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
     lib.visp_swin_enable_captures.argtypes = [c_void_p, c_int32]
+    lib.visp_swin_set_mask_mode.argtypes = [c_void_p, c_int32]
     lib.visp_swin_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
     lib.visp_swin_enable_timing.argtypes = [c_void_p, c_int32]
     lib.visp_swin_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]

@@ -658,6 +658,10 @@ int32_t visp_swin_read_capture(visp_model* m, char const* name, float* host_out,
     });
 }
 
+int32_t visp_swin_set_mask_mode(visp_model* m, int32_t shifted_only) {
+    return handle_errors([&]() { as_swin(m).mask_shifted_only = shifted_only != 0; });
+}
+
 int32_t visp_swin_enable_timing(visp_model* m, int32_t enable) {
     return handle_errors([&]() { as_swin(m).timing = enable != 0; });
 }

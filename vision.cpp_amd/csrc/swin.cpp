@@ -55,6 +55,7 @@ void swin_load_into(swin_model& mdl, model_file const& file, backend_device cons
     swin_model* const model = &mdl;
     model->backend = &dev;
     model->params = swin_detect_params(file);
+    model->mask_shifted_only = getenv("VISP_SWIN_MASK_SHIFTED_ONLY") != nullptr && atoi(getenv("VISP_SWIN_MASK_SHIFTED_ONLY")) != 0;
     swin_params const& P = model->params;
     arena_builder ab;
     packer pk{file, ab, true, file.tensor_layout() != layout_cwhn, file.conv2d_weights()};
@@ -293,11 +294,12 @@ void swin_encode_pixels(swin_model& m, void const* in8_arg, int B, int w, int h,
         for (size_t bi = 0; bi < Wt.blocks[l].size(); ++bi) { // swin::block (swin.cpp:117-163)
             swin_block_weights const& b = Wt.blocks[l][bi];
             const int shift = bi % 2 == 0 ? 0 : ws / 2;
+            const bool masked = shift > 0 || !m.mask_shifted_only; // swin.cpp:226-237: the reference masks every block
             ex.mark("layernorm", 0, (double)(T + rows) * C * 2);
             VX(vx_swin_layernorm_f16(x, ex.fptr(b.norm1_w), ex.fptr(b.norm1_b), t1, rows, C, 1e-5f, ch, cw, ws, shift, 0, s));
             ex.gemm(b.qkv, t1, rows, C, t2, VX_EPI_F16, nullptr, "gemm_qkv");
             ex.mark("window_attention", 4.0 * rows * N * C, (double)rows * C * 8);
-            VX(vx_window_attention_masked_f16(t2, ex.wa + b.bias.off, t1, (int)(rows / N), N, L.n_heads, shift ? nwx : 0, shift ? nwy : 0, s));
+            VX(vx_window_attention_masked_f16(t2, ex.wa + b.bias.off, t1, (int)(rows / N), N, L.n_heads, masked ? nwx : 0, masked ? nwy : 0, s));
             // proj + window_reverse + roll(+shift) + crop + shortcut: window rows are scattered to their pixels by the GEMM epilogue
             // (vx_swin_window_reverse_add_f16 is the unfused form, kept for the kernel-level parity test)
             ex.gemm(b.proj, t1, rows, C, t3, VX_EPI_F16_ADD, x, "gemm_proj", ws, cw, ch, shift);

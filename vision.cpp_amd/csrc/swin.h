@@ -49,6 +49,12 @@ struct swin_model : model_base { // the encoder half of vision.h birefnet_model
     device_buffer weight_arena;
     device_buffer ws;
     bool timing = false, captures = false;
+    // Shift-mask semantics. The reference's swin::layer hands the layer's attn_mask to EVERY block (swin.cpp:226-237) and
+    // swin::block forwards it to window_attention unconditionally (:128-139), so the -inf edge mask of compute_attention_mask
+    // (:165-210) also acts in the UNSHIFTED blocks (the windows of the last row / column). That is what the reference computes,
+    // and the default here. Its torch twin (tests/test_birefnet.py:249-255, the original Swin) masks shifted blocks only:
+    // mask_shifted_only = true (visp_swin_set_mask_mode(m, 1) / VISP_SWIN_MASK_SHIFTED_ONLY=1 at load) selects that.
+    bool mask_shifted_only = false;
     std::vector<timing_entry> last_timing;
     std::map<std::string, capture_entry> capture_bufs;
     virtual ~swin_model();

@@ -151,7 +151,8 @@ class Model:
         check(self._api.visp_depthany_use_graph(self._handle, int(enable)))
 
     def set_schedule(self, schedule: int):
-        """0 = GEMM launches per op group (default); 1 = token-stationary block kernel per layer (embed dim 384 models)."""
+        """-1 = automatic (the default: the token-stationary block kernel where the model has its shape, embed dim 384 / mlp 1536 /
+        head dim 64, otherwise GEMM launches); 0 = GEMM launches per op group; 1 = block kernel per layer."""
         check(self._api.visp_depthany_set_schedule(self._handle, int(schedule)))
 
     def compute_batch(self, images: np.ndarray, return_raw: bool = False):
@@ -194,6 +195,11 @@ class Model:
 
 
     # ---- BiRefNet (family 1): batched extension
+    def swin_set_mask_mode(self, shifted_only: bool):
+        """False (default) = the reference as written: the layer's shift mask acts in every block (swin.cpp:128-139, 226-237);
+        True = shifted blocks only, as the reference's torch twin / the original Swin."""
+        check(self._api.visp_swin_set_mask_mode(self._handle, int(bool(shifted_only))))
+
     def birefnet_image_extent(self, w: int, h: int):
         ow, oh = c_int32(), c_int32()
         check(self._api.visp_birefnet_image_extent(self._handle, w, h, byref(ow), byref(oh)))
@@ -385,9 +391,9 @@ class DeviceBuffer:
 
 
 class SwinEncoder(Model):
-    """The SWIN encoder of a birefnet GGUF (reference swin_encode, src/visp/arch/swin.cpp:237-262, behind birefnet::encode): the
-    BiRefNet decoder is not built in this backend, so the family's Model.load / compute stay refused and the encoder has its
-    own handle (visp_swin_*). Outputs are the four normed stage maps, f32 [B, h_i, w_i, C_i]."""
+    """The SWIN encoder of a birefnet GGUF on its own (reference swin_encode, src/visp/arch/swin.cpp:237-262, behind
+    birefnet::encode); the whole BiRefNet (encoder + decoder) is Model.load(..., Arch.birefnet). Outputs are the four normed
+    stage maps, f32 [B, h_i, w_i, C_i]."""
 
     @classmethod
     def load(cls, path, device: Device):
