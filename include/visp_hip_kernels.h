@@ -248,10 +248,15 @@ VX_API int vx_sam_interpolate(const void* src, int src_f16, int sw, int sh, int 
 VX_API int vx_add_gelu_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
 
 /* ---- fused multi-head attention, head_dim 64 (nn.cpp:210-244, dino.cpp:59-74) ------------
- * q,k,v: f16 [B,H,T,64] (q pre-scaled by 1/sqrt(64)); out: f16 [B*T, H*64].
+ * q,k,v: f16 [B,H,T,64], q pre-scaled by VX_ATTN_Q_SCALE = log2(e) / sqrt(64): the kernel works in the exp2 domain and the
+ * producer of q (QKV epilogue / block kernel, their q_scale argument) folds the factor in; out: f16 [B*T, H*64].
  * softmax in f32, S never leaves registers; V is transposed on the fly by ds_read_b64_tr_b16. */
+#define VX_ATTN_Q_SCALE 0.18033688011112042f
 VX_API int vx_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int T,
                             void* stream);
+/* test hook: a lane's partial row sum above `limit` sends a key tile from the lagging-reference fast path to the full path
+ * (0 = always the full path; negative = restore the default 1024) */
+VX_API void vx_attention_set_fast_limit(float limit);
 
 /* ---- token-stationary DINOv2 block (kernels_block.hip; embed dim 384, mlp 1536, head dim 64) ------------------------------
  * One launch per layer replaces everything between two attentions of dino::layer (src/visp/arch/dino.cpp:48-90):

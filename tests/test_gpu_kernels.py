@@ -173,6 +173,9 @@ def test_conv3x3_implicit_gemm(cin, cout, stride, hw, mode):
     assert rel_err(got, want) < F16_TOL
 
 
+LOG2E = 1.4426950408889634
+
+
 @pytest.mark.parametrize("B,H,T", [(1, 1, 64), (2, 2, 65), (1, 3, 50), (1, 2, 257), (2, 6, 1370)])
 def test_attention(B, H, T):
     """fused MHSA, head_dim 64 (nn.cpp:210-244) vs the oracle's softmax(q k^T * scale) v."""
@@ -180,7 +183,7 @@ def test_attention(B, H, T):
     Cc = H * 64
     q, k, v = (_h(_rand(rng, B, T, Cc)) for _ in range(3))
     scale = 0.125
-    qs = _h(q * scale)  # the QKV epilogue stores q pre-scaled (exact: power of two)
+    qs = q * (scale * LOG2E)  # the QKV epilogue stores q pre-scaled by log2(e) / sqrt(64) (VX_ATTN_Q_SCALE): exp2-domain kernel
     qd = dev(qs.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float16))
     kd = dev(k.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float16))
     vd = dev(v.reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float16))
@@ -202,11 +205,70 @@ def test_attention_online_softmax_rescale_branch():
     k[0, 290] = q[0, 7] * 4.0  # key 290 dominates query 7 only
     k = _h(k)
     out = empty(T * 64 * 2)
-    L.vx_check(api().vx_attention_f16(dev(_h(q * 0.125).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr,
+    L.vx_check(api().vx_attention_f16(dev((q * (0.125 * LOG2E)).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr,
                                       dev(v.astype(np.float16)).ptr, out.ptr, B, H, T, None))
     sync()
     got = out.to_numpy(np.float16, (T, 64)).astype(np.float32)
     want = oracle.attention(q[0], k[0], v[0], 1, 0.125)
+    assert rel_err(got, want) < 5e-3
+
+
+def _attn(q, k, v, T):
+    out = empty(T * 64 * 2)
+    L.vx_check(api().vx_attention_f16(dev((q * (0.125 * LOG2E)).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr,
+                                      dev(v.astype(np.float16)).ptr, out.ptr, 1, 1, T, None))
+    sync()
+    return out.to_numpy(np.float16, (T, 64)).astype(np.float32)
+
+
+def test_attention_lagging_reference_fast_path_and_its_fallback():
+    """Round 3: tiles 1 .. n-2 exponentiate against the reference point the wave already has (no maximum, no subtract) and fall
+    back to the full path when a lane's partial row sum exceeds the limit (guide rule 26: force the branch, full-tensor
+    independent reference, threshold sweep).
+      * query 7: key 200 (tile 3 of 10) beats everything before it by ~40 in the exp2 domain -> the fallback MUST fire mid-stream
+        and rescale O and l of tiles 0-2;
+      * query 9: key 330 (tile 5) beats the earlier maximum by ~6 -> stays on the fast path with P up to ~2^6 (no rescale);
+      * query 11: key 70 (tile 1) by ~9.5 -> P up to ~2^9.5, just under the limit, or the fallback; either must be right.
+    Limits 0 (every tile on the full path) / default / 2^14 (the fast path where f16 can still hold P) must agree to rounding."""
+    rng = np.random.default_rng(17)
+    T = 640
+    q, k, v = (_h(_rand(rng, 1, T, 64)) for _ in range(3))
+    k[0, 200] = q[0, 7] * 4.0
+    k[0, 330] = q[0, 9] * (8.0 / float((q[0, 9] ** 2).sum() * 0.125))     # score 8 -> 11.5 in the exp2 domain
+    k[0, 70] = q[0, 11] * (10.5 / float((q[0, 11] ** 2).sum() * 0.125))   # score 10.5 -> 15.1
+    k = _h(k)
+    want = oracle.attention(q[0], k[0], v[0], 1, 0.125)
+    try:
+        got = {}
+        for limit in (0.0, -1.0, 16384.0):
+            api().vx_attention_set_fast_limit(limit)
+            got[limit] = _attn(q[0], k[0], v[0], T)
+            assert np.isfinite(got[limit]).all(), limit
+            assert rel_err(got[limit], want) < 5e-3, limit
+            for row in (7, 9, 11):
+                assert np.abs(got[limit][row] - want[row]).max() < 5e-3 * max(1.0, np.abs(want[row]).max()), (limit, row)
+        # same arithmetic up to the reference point: the three agree far inside the f16 output rounding
+        assert np.abs(got[0.0] - got[-1.0]).max() < 2e-3 * np.abs(want).max()
+        assert np.abs(got[16384.0] - got[-1.0]).max() < 2e-3 * np.abs(want).max()
+    finally:
+        api().vx_attention_set_fast_limit(-1.0)
+
+
+def test_attention_reference_point_follows_a_slowly_rising_maximum():
+    """Scores that climb by ~3 (exp2 domain) per 64-key tile: no single tile trips the limit at once, the lag accumulates until
+    one does; and a row whose scores keep FALLING after the first tile (P shrinks to f16 subnormals against the stale
+    reference, as in any online softmax anchored at the running maximum)."""
+    rng = np.random.default_rng(23)
+    T = 1370
+    q, k, v = (_h(_rand(rng, 1, T, 64) * 0.3) for _ in range(3))
+    ramp = np.arange(T, dtype=np.float32) / 64.0 * 3.0 / LOG2E      # natural-log units, added through one feature
+    q[0, :, 0] = 8.0
+    k[0, :, 0] = ramp / (8.0 * 0.125)
+    k[0, 700:, 0] = k[0, 699, 0] - (np.arange(T - 700, dtype=np.float32) / 64.0 * 2.0 / LOG2E)
+    q, k = _h(q), _h(k)
+    want = oracle.attention(q[0], k[0], v[0], 1, 0.125)
+    got = _attn(q[0], k[0], v[0], T)
+    assert np.isfinite(got).all()
     assert rel_err(got, want) < 5e-3
 
 
@@ -222,7 +284,7 @@ def test_attention_all_scores_far_below_zero():
     k[..., 1:] = _h(_rand(rng, 1, T, 63) * 0.3)
     v = _h(_rand(rng, 1, T, 64))
     out = empty(T * 64 * 2)
-    L.vx_check(api().vx_attention_f16(dev(_h(q * 0.125).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr,
+    L.vx_check(api().vx_attention_f16(dev((q * (0.125 * LOG2E)).astype(np.float16)).ptr, dev(k.astype(np.float16)).ptr,
                                       dev(v.astype(np.float16)).ptr, out.ptr, 1, 1, T, None))
     sync()
     got = out.to_numpy(np.float16, (1, T, 64)).astype(np.float32)

@@ -782,7 +782,9 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     // the row. Measured on the same device: the GEMMs get 0.36 ms faster per step (no strided f32 read-modify-write
     // epilogue) but the LayerNorms 0.42 ms slower (they now also write x); total traffic is the same 236 MB per
     // residual, so the read-modify-write epilogue stays the default.
-    const float q_scale = 1.0f / std::sqrt((float)D / (float)NH);
+    // attention() scales the scores by 1/sqrt(head_dim) (nn.cpp:232-233); the attention kernel works in the exp2 domain, so log2(e)
+    // rides along in the same factor (VX_ATTN_Q_SCALE for head_dim 64)
+    const float q_scale = 1.4426950408889634f / std::sqrt((float)D / (float)NH);
     // The encoder of images [b0, b0 + nb) on stream `strm`. Every activation buffer is image-major, so a sub-batch is a row
     // offset into the same workspace; VISP_SPLIT=n runs n sub-batches on parallel streams (captured as parallel branches of
     // the hipGraph) so that kernels with different bottlenecks -- HBM-bound LayerNorms, VALU-bound attention, MFMA/LDS-bound
