@@ -254,7 +254,8 @@ def main():
 
     # sanity: the timed output is a valid normalised depth batch
     o = out.cpu().numpy()
-    assert np.isfinite(o).all() and o.min() >= 0 and o.max() <= 1 + 1e-6, "invalid output"
+    ablated = bool(os.environ.get("VISP_ABLATE"))  # timing-only diagnostic builds of the step (results invalid by construction)
+    assert ablated or (np.isfinite(o).all() and o.min() >= 0 and o.max() <= 1 + 1e-6), "invalid output"
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -283,6 +284,8 @@ def main():
             "model_tflops": round(value * GFLOP_PER_IMAGE / 1e3, 2),
             "mfma_frac_whole_model": round(value * GFLOP_PER_IMAGE * 1e9 / (world * PEAK_MFMA_F16), 4),
         }
+        if ablated:
+            res["INVALID_ablation"] = os.environ["VISP_ABLATE"]
         if groups:
             dom = groups[0]
             per_launch_ms = dom["ms"] / max(dom["launches"], 1)

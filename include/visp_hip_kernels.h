@@ -163,7 +163,15 @@ typedef struct {
     int a_relu;
     const float* head_w; float head_bias, head_scale;
     void* stamps; /* diagnostics only: u64 [blocks][8] = cycles in {dma wait, barrier, dma issue + halo cursor, mfma loop, epilogue, tile setup}, steps, end clock; NULL in product */
+    /* round 3 -- ggml_interpolate(BILINEAR | ALIGN_CORNERS) fused into the consumer (depth-anything.cpp:36-38, 84-85; ml.cpp:782-788):
+     * bil_hs > 0: x is the LOW-resolution map [B, bil_hs, bil_ws, .] and the conv runs on its bilinear resize to H x W, interpolated by
+     *   the halo loader (source patch by LDS-DMA, packed-f16 weights); cout = 32, no up2 / a_relu / x_residual, H + W <= 2048 and a
+     *   scale that keeps an 18 x 34 halo inside a 12 x 21 source patch (about <= 0.575; vx_dconv_bilinear_supported).
+     * res2_hs > 0: res2 is [B, res2_hs, res2_ws, .] and is resized to H x W where the epilogue adds it (same arithmetic). */
+    int bil_hs, bil_ws;
+    int res2_hs, res2_ws;
 } vx_dconv_args;
+VX_API int vx_dconv_bilinear_supported(int cout, int H, int W, int hs, int ws);
 VX_API int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream);
 /* sets the kernels' dynamic-LDS attribute (call once per process before capturing launches into a hipGraph) */
 VX_API int vx_dconv_prepare(void);

@@ -120,7 +120,7 @@ def from_planes(p: np.ndarray) -> np.ndarray:
 
 
 def dconv(x_dev, n_planes, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=0, out=None, out_planes=None, out_plane0=0,
-          res1=None, s1=1.0, res2=None, s2=1.0, rgb=False, cin_pad=None, x_residual=False, nhwc=None, a_relu=False, head=None):
+          res1=None, s1=1.0, res2=None, s2=1.0, rgb=False, cin_pad=None, x_residual=False, nhwc=None, a_relu=False, head=None, bil=None):
     """Launches vx_dconv3x3_f16 on planar buffers (x_dev: n_planes planes of [B,H(/2),W(/2),32]); the output goes to
     planes out_plane0.. of `out` (out_planes planes of [B,H,W,32]). Returns all planes of the output buffer as
     [B,H,W,32*planes] f16, or f32 [B,H,W,3] for the rgb head. res1/res2: planar device buffers [cout/32][B,H,W,32]."""
@@ -149,6 +149,8 @@ def dconv(x_dev, n_planes, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=
         cx, co = nhwc
         a.x_pix, a.x_plane = cx, 32
         a.out_pix, a.out_plane, a.res1_pix, a.res1_plane, a.res2_pix, a.res2_plane = co, 32, co, 32, co, 32
+    if bil is not None:  # x_dev is the low-resolution map [B, hs, ws, cin]: bilinear (align_corners) resize in the halo loader
+        a.bil_hs, a.bil_ws = bil
     if head is not None:
         w3, b3, scale = head
         hw = dev(np.asarray(w3, np.float32))

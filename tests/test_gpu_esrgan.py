@@ -117,6 +117,45 @@ def test_dconv_nhwc_relu_forms(cin, cout, H, W):
         np.testing.assert_allclose(got, want, atol=3e-3, rtol=3e-3)
 
 
+@pytest.mark.parametrize("cin,hs,ws,H,W,B", [(64, 148, 148, 296, 296, 1), (32, 296, 296, 518, 518, 1), (32, 40, 60, 70, 105, 2), (64, 19, 37, 37, 74, 3),
+                                             (32, 100, 28, 175, 50, 2)])
+def test_dconv_bilinear_input(cin, hs, ws, H, W, B):
+    """Round 3: ggml_interpolate(BILINEAR | ALIGN_CORNERS) fused into the consumer conv (depth-anything.cpp:36-38 -> head.conv1,
+    :84-85 -> head.conv2; ml.cpp:782-788): the conv of the resized map, resized in the halo loader, against
+    conv(oracle.interpolate(x)) -- both head forms (f16 map out, fused depth head) and both tile shapes (widths with a
+    remainder <= 16 take the 32x16 strip), several batch images so that persistent blocks cross image boundaries."""
+    from tests import gpu_util as G
+    rng = np.random.default_rng(cin + hs + W)
+    assert G.api().vx_dconv_bilinear_supported(32, H, W, hs, ws) == 1
+    x = (rng.standard_normal((B, hs, ws, cin)) * 0.5).astype(np.float16)
+    w = (rng.standard_normal((32, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = (rng.standard_normal(32) * 0.1).astype(np.float32)
+    up = O.interpolate_nhwc(x.astype(np.float32), (H, W), "bilinear", True)
+    ref = _conv_ref(up, w, b)
+    xd = G.dev(x)
+    got = G.dconv(xd, 0, cin, B, H, W, w, b, nhwc=(cin, 32), bil=(hs, ws), out=G.empty(B * H * W * 32 * 2))
+    # the interpolation runs on packed f16 (4 products, 3 roundings per value) where the stand-alone kernel rounds once
+    np.testing.assert_allclose(got.astype(np.float32), ref, atol=5e-3, rtol=4e-3)
+    assert np.abs(got.astype(np.float32) - ref).mean() < 4e-4
+    w3, b3 = np.abs(rng.standard_normal(32) * 0.3).astype(np.float32), 0.05
+    got = G.dconv(xd, 0, cin, B, H, W, w, b, nhwc=(cin, 32), bil=(hs, ws), head=(w3, b3, 1.5))
+    want = np.maximum(np.maximum(ref, 0) @ w3 + b3, 0) * 1.5
+    np.testing.assert_allclose(got, want, atol=4e-3, rtol=3e-3)
+
+
+def test_dconv_bilinear_limits():
+    from tests import gpu_util as G
+    ok = G.api().vx_dconv_bilinear_supported
+    assert ok(32, 518, 518, 296, 296) == 1 and ok(32, 296, 296, 148, 148) == 1 and ok(32, 518, 700, 296, 400) == 1
+    assert ok(64, 296, 296, 148, 148) == 0      # Cout = 64 keeps the DMA halo
+    assert ok(32, 100, 100, 80, 80) == 0        # scale 0.8: the 18 x 34 halo does not fit a 12 x 21 source patch
+    assert ok(32, 1500, 1500, 750, 750) == 0    # H + W beyond the row / column table
+    x = G.dev(np.zeros((1, 80, 80, 32), np.float16))
+    w = np.zeros((32, 32, 3, 3), np.float32)
+    with pytest.raises(Exception, match="interpolating loader"):
+        G.dconv(x, 0, 32, 1, 100, 100, w, None, nhwc=(32, 32), bil=(80, 80), out=G.empty(100 * 100 * 32 * 2))
+
+
 @pytest.mark.parametrize("w,h,fmt", [(256, 256, O.RGB_U8), (300, 260, O.RGBA_U8), (100, 50, O.BGRA_U8), (64, 64, O.ARGB_U8)])
 def test_tiles_in_out(w, h, fmt):
     """vx_esrgan_tiles_in == image_u8_to_f32 per tile (clamped reads); vx_esrgan_tiles_out == tile_merge of all

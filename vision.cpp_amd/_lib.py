@@ -42,6 +42,7 @@ class DconvArgs(ctypes.Structure):  # == vx_dconv_args
         ("out", c_void_p), ("out_plane", c_int64), ("x_residual", c_int),
         ("x_pix", c_int64), ("out_pix", c_int64), ("res1_pix", c_int64), ("res2_pix", c_int64), ("a_relu", c_int),
         ("head_w", c_void_p), ("head_bias", c_float), ("head_scale", c_float), ("stamps", c_void_p),
+        ("bil_hs", c_int), ("bil_ws", c_int), ("res2_hs", c_int), ("res2_ws", c_int),
     ]
 
 
@@ -113,7 +114,7 @@ KERNEL_SYMBOLS = [
     "vx_attention_f16", "vx_attention_set_fast_limit",
     "vx_layernorm_f32_f16", "vx_layernorm_resid_supported", "vx_layernorm_resid_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
-    "vx_dconv3x3_f16", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
+    "vx_dconv3x3_f16", "vx_dconv_bilinear_supported", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
     "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_mbconv_dw_pw_supported", "vx_mbconv_pack_w3", "vx_mbconv_dw_pw_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
     "vx_bf_preprocess_half", "vx_bf_patches", "vx_bf_resize_f16", "vx_bf_deform_cols_f16", "vx_bf_mean_f16", "vx_bf_broadcast_f16", "vx_bf_mul_sigmoid_f16", "vx_bf_sigmoid_out_f32",
     "vx_swin_attention_pack_bias", "vx_window_attention_masked_f16", "vx_swin_layernorm_f16", "vx_swin_layernorm_strided_f16", "vx_swin_merge_layernorm_f16", "vx_swin_window_reverse_add_f16",
@@ -285,6 +286,7 @@ def init() -> ctypes.CDLL:
     lib.vx_window_reverse_add_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_add_gelu_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     lib.vx_dconv3x3_f16.argtypes = [POINTER(DconvArgs), c_void_p]
+    lib.vx_dconv_bilinear_supported.argtypes = [c_int, c_int, c_int, c_int, c_int]
     lib.vx_esrgan_tiles_in.argtypes = [c_void_p, c_int, c_int, c_int, c_int, POINTER(TileLayout), c_void_p, c_void_p]
     lib.vx_esrgan_tiles_out.argtypes = [c_void_p, c_int, POINTER(TileLayout), c_void_p, c_void_p, c_void_p]
     for name in KERNEL_SYMBOLS[1:]:

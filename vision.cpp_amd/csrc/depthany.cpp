@@ -631,6 +631,14 @@ struct exec_ctx {
         void* ev = nullptr;
         VX(vx_event_create(&ev));
         VX(vx_event_record(ev, stream));
+        static const bool detail = getenv("VISP_TIMING_DETAIL") != nullptr; // one row per launch (tools/dpt_launches.py)
+        if (detail) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "%s#%zu", name, marks.size());
+            marks.push_back({nm, ev});
+            acc.push_back({nm, 0, launches, flops, bytes});
+            return;
+        }
         marks.push_back({name, ev});
         acc.push_back({name, 0, launches, flops, bytes});
     }
@@ -689,8 +697,10 @@ struct exec_ctx {
     }
 
     // NHWC 3x3 (or kxk) convolution as implicit GEMM
+    // bil_hs > 0: x is the low-resolution map [B, bil_hs, bil_ws, Cin] and the conv runs on its bilinear (align_corners) resize to
+    // H x W, interpolated by the conv's halo loader (callers check bil_ok first)
     void conv(packed_gemm const& g, const void* x, int B, int H, int W, int Cin, int k, int stride, int pad, void* y, int ldo,
-              int epi, bool a_relu, bool relu, const void* res1, const void* res2, const char* group) {
+              int epi, bool a_relu, bool relu, const void* res1, const void* res2, const char* group, int bil_hs = 0, int bil_ws = 0) {
         int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
         long M = (long)B * OH * OW;
         vx_gemm_args a = base(g, M);
@@ -708,6 +718,7 @@ struct exec_ctx {
         mark(group, 1, 2.0 * M * g.n_real * g.k_real, (double)B * H * W * Cin * 2 + (double)M * g.n_real * 2 + (double)g.N * g.K * 2);
         if (dconv_ok(g, k, stride, pad, W, Cin, epi) && !relu) {
             vx_dconv_args d = dconv_base(g, x, B, H, W, Cin);
+            d.bil_hs = bil_hs; d.bil_ws = bil_ws;
             d.epi = VX_DC_F16;
             d.act = epi == VX_EPI_F16_RELU ? 2 : 0;
             d.a_relu = a_relu;
@@ -719,14 +730,23 @@ struct exec_ctx {
             VX(vx_dconv3x3_f16(&d, stream));
             return;
         }
+        if (bil_hs > 0) throw except("depthany: internal: bilinear input without the LDS-ring conv");
         gemm(a);
     }
-    // 3x3 / stride 1 / pad 1 convs on maps at least 64 wide go to the persistent LDS-ring kernel written for the ESRGAN
-    // row (1.4-1.9x the halo kernel on these shapes, tools/conv_compare.py); it reads and writes the NHWC maps in place
-    // through its pixel / plane strides
+    // may conv `g` (3x3 / 1 / 1 on an H x W map) take its input as the bilinear resize of an hs x ws map?
+    static bool bil_ok(packed_gemm const& g, int H, int W, int Cin, int epi, int hs, int ws) {
+        static const bool off = getenv("VISP_NO_BIL_FUSE") != nullptr;
+        return !off && dconv_ok(g, 3, 1, 1, W, Cin, epi) && vx_dconv_bilinear_supported(g.N, H, W, hs, ws);
+    }
+    // 3x3 / stride 1 / pad 1 convs go to the persistent LDS-ring kernel written for the ESRGAN row (1.4-1.9x the halo kernel on
+    // maps >= 64 wide, tools/conv_compare.py); it reads and writes the NHWC maps in place through its pixel / plane strides.
+    // Round 3: also on the 37^2 and 19^2 maps (its 16x32 tiles are half empty there, and still: neck conv 192->64 @37^2 50 -> 27 us,
+    // 384->64 @19^2 80 -> 40 us, the six small residual-unit convs 23 -> 17.5 us each at batch 32: the implicit-GEMM kernel runs one
+    // workgroup per CU with a single LDS stage on these grids and every k-step is an exposed L2 round trip; profiles/r03_dpt_launches.txt)
     static bool dconv_ok(packed_gemm const& g, int k, int stride, int pad, int W, int Cin, int epi) {
         static const bool off = getenv("VISP_NO_DCONV") != nullptr;
-        return !off && g.dw != SIZE_MAX && k == 3 && stride == 1 && pad == 1 && W >= 64 && round_up(Cin, 32) == g.d_cin &&
+        static const int min_w = getenv("VISP_DCONV_MINW") ? atoi(getenv("VISP_DCONV_MINW")) : 16;
+        return !off && g.dw != SIZE_MAX && k == 3 && stride == 1 && pad == 1 && W >= min_w && round_up(Cin, 32) == g.d_cin &&
                (epi == VX_EPI_F16 || epi == VX_EPI_F16_RELU || epi == VX_EPI_F16_ADD || epi == VX_EPI_HEAD_OUT);
     }
     vx_dconv_args dconv_base(packed_gemm const& g, const void* x, int B, int H, int W, int Cin) {
@@ -882,7 +902,8 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         int tap = 0;
         for (int i = 0; i < P.dino.n_layers; ++i) {
             c.mark("attention", 1, 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
-            VX(vx_attention_f16(qb, kb, vb, attb, B, NH, T, stream));
+            static const bool no_attn = getenv("VISP_ABLATE") && (atoi(getenv("VISP_ABLATE")) & 4); // timing-only ablation
+            if (!no_attn) VX(vx_attention_f16(qb, kb, vb, attb, B, NH, T, stream));
             // get_intermediate_layers (dino.cpp:100-107): every tap that names this layer (the first one is written by the kernel)
             void* first = nullptr;
             int tap0 = tap;
@@ -947,6 +968,9 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     }
     if (!use_block && tap != 4) throw except("depthany: expected 4 feature layers, found %d", tap);
 
+    // timing-only ablations (results invalid): what the step would cost without a stage -- bounds what fusing it away can buy
+    static const int ablate = getenv("VISP_ABLATE") ? atoi(getenv("VISP_ABLATE")) : 0; // 1 = no DPT, 2 = no bilinear launches, 4 = no attention
+    if (ablate & 1) return;
     // ---- dpt::neck reassemble (depth-anything.cpp:44-64)
     const int lh[4] = {4 * ph, 2 * ph, ph, (ph + 2 - 3) / 2 + 1};
     const int lw[4] = {4 * pw, 2 * pw, pw, (pw + 2 - 3) / 2 + 1};
@@ -1006,6 +1030,8 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     // ---- fusion stage (depth-anything.cpp:25-42, 71-77)
     void *t1 = c.buf("t1"), *t2 = c.buf("t2"), *t3 = c.buf("t3"), *up = c.buf("up"), *fused = c.buf("fused");
     const void* prev = nullptr; // output of the previous fusion layer (lives in `fused`)
+    const void* head_in = nullptr; // set when head.conv1 resizes the last stage's projection itself
+    int head_in_h = 0, head_in_w = 0;
     for (int i = 0; i < 4; ++i) {
         fusion_weights const& FW = Wt.fusion[i];
         const int j = 3 - i; // feature consumed at this stage
@@ -1035,8 +1061,14 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
             c.mark("fusion_proj", 1, 2.0 * B * h * w * F * F, (double)B * h * w * F * 4);
             c.gemm(a);
         }
+        // The last stage's resize (148^2 -> 296^2 at 518^2: 0.45 GB written and read back per 32 images) feeds head.conv1 only: that
+        // conv interpolates it in its halo loader instead (kernels_dconv.hip BIL). Captures keep the unfused form (fusion_3 is one).
+        if (i == 3 && !m.captures && exec_ctx::bil_ok(Wt.head1, oh, ow, F, VX_EPI_F16, h, w)) {
+            head_in = t1; head_in_h = h; head_in_w = w;
+            break;
+        }
         c.mark("bilinear", 1, 0, (double)B * (h * w + oh * ow) * F * 2);
-        VX(vx_bilinear_ac_f16(t1, fused, B, h, w, F, oh, ow, stream));
+        if (!(ablate & 2)) VX(vx_bilinear_ac_f16(t1, fused, B, h, w, F, oh, ow, stream));
         (void)up;
         prev = fused;
         if (m.captures) { std::string nm = "fusion_" + std::to_string(i); c.capture(nm.c_str(), fused, {B, oh, ow, F}, true); }
@@ -1044,10 +1076,16 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
 
     // ---- dpt::head (depth-anything.cpp:81-96)
     const int fh = 8 * ph, fw = 8 * pw;
-    c.conv(Wt.head1, fused, B, fh, fw, F, 3, 1, 1, c.buf("h1"), HC, VX_EPI_F16, false, false, nullptr, nullptr, "head_conv1");
+    if (head_in) c.conv(Wt.head1, head_in, B, fh, fw, F, 3, 1, 1, c.buf("h1"), HC, VX_EPI_F16, false, false, nullptr, nullptr, "head_conv1", head_in_h, head_in_w);
+    else c.conv(Wt.head1, fused, B, fh, fw, F, 3, 1, 1, c.buf("h1"), HC, VX_EPI_F16, false, false, nullptr, nullptr, "head_conv1");
     c.capture("head_conv1", c.buf("h1"), {B, fh, fw, HC}, true);
-    c.mark("bilinear", 1, 0, (double)B * ((double)fh * fw + (double)H * W) * HC * 2);
-    VX(vx_bilinear_ac_f16(c.buf("h1"), c.buf("hup"), B, fh, fw, HC, H, W, stream));
+    // head: interpolate to the image extent, then conv2 (depth-anything.cpp:84-87): conv2's loader resizes h1 itself where it can
+    // (0.55 GB written and read back per 32 images otherwise)
+    const bool head2_bil = !m.captures && Wt.head2.N == 32 && exec_ctx::bil_ok(Wt.head2, H, W, HC, VX_EPI_HEAD_OUT, fh, fw);
+    if (!head2_bil) {
+        c.mark("bilinear", 1, 0, (double)B * ((double)fh * fw + (double)H * W) * HC * 2);
+        if (!(ablate & 2)) VX(vx_bilinear_ac_f16(c.buf("h1"), c.buf("hup"), B, fh, fw, HC, H, W, stream));
+    }
     float* depth = raw_out_dev ? static_cast<float*>(raw_out_dev) + (size_t)b0 * H * W : static_cast<float*>(c.buf("depth"));
     if (Wt.head2.N == 32) {
         // conv2 (3x3 -> 32) + ReLU + conv3 (1x1 -> 1) + ReLU [* max_depth] in one kernel: the 32-channel
@@ -1063,7 +1101,8 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         a.head_scale = P.max_depth;
         c.mark("head_conv2+3", 1, 2.0 * B * H * W * 32 * (Wt.head2.k_real + 1), (double)B * H * W * (HC * 2 + 4));
         if (exec_ctx::dconv_ok(Wt.head2, 3, 1, 1, W, HC, VX_EPI_HEAD_OUT)) {
-            vx_dconv_args d = c.dconv_base(Wt.head2, c.buf("hup"), B, H, W, HC);
+            vx_dconv_args d = c.dconv_base(Wt.head2, head2_bil ? c.buf("h1") : c.buf("hup"), B, H, W, HC);
+            if (head2_bil) { d.bil_hs = fh; d.bil_ws = fw; }
             d.epi = VX_DC_HEAD_F32;
             d.head_w = c.fptr(Wt.head3_w); d.head_bias = Wt.head3_b; d.head_scale = P.max_depth;
             d.out = depth;

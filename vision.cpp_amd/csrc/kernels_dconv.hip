@@ -26,6 +26,7 @@
 //    ReLU) write f32 straight from the accumulators; AR = ReLU on the input fragments.
 #include "vx_common.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -40,6 +41,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int TRASH_BLOCKS = 1024;
 __device__ __attribute__((aligned(16))) unsigned char g_dconv_trash[TRASH_BLOCKS * 8 * 1024];
 
+constexpr int DCONV_TAB_MAX = 1280; // BIL: H + W entries (8 bytes each) of the row / column interpolation table
 constexpr int CK = 32;      // channels per chunk
 constexpr int PIXB = CK * 2; // bytes per pixel per chunk
 constexpr int NW = 8;       // waves per block
@@ -67,8 +69,24 @@ struct tile_grid {
 // depth-anything.cpp:15-23).
 // RES: number of weight slabs kept RESIDENT in LDS for the whole launch (all cin/32 chunks of the conv fit next to the
 // halo ring), 0 = slabs stream through a 2-stage ring. HSV: halo ring stages of this variant.
-template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2)>
+// max(x, 0) as ONE instruction: fmaxf() on an MFMA result costs a canonicalising v_max_f32 x, x, x first (IEEE mode), and the depth
+// head's epilogue is 32 of them per tile in a kernel bound by VALU issue
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
+// BIL: the input is a LOW-resolution map and the conv runs on its bilinear (align_corners) resize (the DPT head's two
+// `interpolate` calls, depth-anything.cpp:36-38 / 84-85 -> ml.cpp:782-788 ggml_interpolate): the resized map never exists. Per step
+// the loader DMAs the SOURCE patch under the halo (<= 12 x 21 pixels of the chunk's 32 channels, 16 KB) two steps ahead into a
+// 2-stage source ring, and the waves interpolate the NEXT step's 18 x 34 halo out of it into the other halo stage from inside the
+// current step's MFMA loop (4 ds_read_b128 + 16 v_pk_fma_f16 + 1 ds_write_b128 per pixel and 8 channels, five of those per lane
+// and step). Source row / column and weight of every output row / column come from a table built in LDS at kernel start.
+// ONE: Cin = 32, every tile is a single step: its accumulators need no initialisation, the first MFMA of each takes the bias tile as C.
+template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2), bool BIL = false, bool ONE = false>
 __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
+    static_assert(!ONE || COUT == 32, "single-step tiles: COUT = 32 only");
     constexpr int MT = 2;                       // M-tiles (32 pixels) per wave
     constexpr int HALO_PIX = 18 * 34;           // both tile shapes
     // a halo stage holds [pixel][64 B] (the chunk's 32 channels) with the four 16-byte groups XOR-swizzled by
@@ -85,8 +103,13 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     constexpr int HS = HSV;                     // halo stages
     constexpr int WSLOTS = RES ? RES : 2;       // slab slots: the streaming ring has 2
     static_assert(!RES || COUT == 32, "resident slabs are built for COUT = 32 (the COUT = 64 epilogue stages through slab space)");
-    constexpr int W_BASE = HS * HALO_BYTES;     // LDS: [halo 0 .. HS-1 | slab slots | bias]
+    static_assert(!BIL || (COUT == 32 && HSV == 2 && !RES && !AR), "the interpolating loader is built for COUT = 32 with two halo stages");
+    constexpr int SRC_PIX = 256, SRC_BYTES = SRC_PIX * PIXB, SJ = SRC_BYTES / 1024 / NW; // source patch: 16 KB = 2 DMA instructions per wave
+    constexpr int SRC_BASE = HS * HALO_BYTES;   // BIL: [halo 0 | halo 1 | src 0 | src 1 | slab 0 | slab 1 | bias | row/col table]
+    constexpr int W_BASE = HS * HALO_BYTES + (BIL ? 2 * SRC_BYTES : 0); // LDS: [halo 0 .. HS-1 | slab slots | bias]
     constexpr int BIAS_BASE = W_BASE + WSLOTS * W_BYTES;
+    constexpr int TAB_BASE = BIAS_BASE + ((COUT * 4 + 15) & ~15); // BIL: int [H + W], (source index << 16) | f16 weight
+    static_assert(!BIL || TAB_BASE + (DCONV_TAB_MAX + 4) * 8 <= 160 * 1024, "interpolation tables do not fit");
     constexpr int NCH16 = COUT / 8, PITCH = COUT * 2;
     static_assert(BIAS_BASE + COUT * 4 <= 160 * 1024, "LDS ring too large");
     static_assert(256 * PITCH <= HALO_BYTES && 256 * PITCH <= W_BYTES + (COUT == 32 ? HALO_BYTES : 0), "output staging does not fit a stage");
@@ -119,12 +142,40 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     if (tid < COUT) s_bias[tid] = p.bias ? p.bias[tid] : 0.0f;
 
     const int up = p.up2 ? 1 : 0;
-    const int Hs = H >> up, Ws = W >> up;
+    const int Hs = BIL ? p.bil_hs : H >> up, Ws = BIL ? p.bil_ws : W >> up;
     const int nch = p.cin / CK;
     const int nch_total_bytes = nch * 9 * COUT * PIXB;
     const long x_plane_bytes = p.x_plane * 2;
     const int x_pix = p.x_pix ? (int)p.x_pix : CK;           // elements between pixels (32 = planar, C = NHWC)
     const long out_pix = p.out_pix ? p.out_pix : CK, res1_pix = p.res1_pix ? p.res1_pix : CK, res2_pix = p.res2_pix ? p.res2_pix : CK;
+
+    // BIL: row / column tables of 8-byte entries. Entry i + 1 describes output row (column) i; entries 0 and H + 1 (W + 1) stand for
+    // the rows of the conv's zero padding just outside the map, so a halo pixel needs no range test:
+    //   .x: bit 31 outside the map | bit 30 the source has a next row (column) | bits 29:16 first source index
+    //   .y: packed f16 weights (1 - f) | f << 16 of the two source rows (columns); both 0 outside the map, so that the four
+    //       products of a pixel's row and column pairs are its bilinear weights and vanish in the padding
+    // Source coordinate = out / sf with sf = (out_extent - 1) / (in_extent - 1), as ggml computes it (and bilinear_ac_kernel).
+    uint2* const tab_y = reinterpret_cast<uint2*>(smem + TAB_BASE);
+    uint2* const tab_x = tab_y + H + 2;
+    if constexpr (BIL) {
+        const float sfy = (H > 1 && Hs > 1) ? (float)(H - 1) / (float)(Hs - 1) : (float)H / (float)Hs;
+        const float sfx = (W > 1 && Ws > 1) ? (float)(W - 1) / (float)(Ws - 1) : (float)W / (float)Ws;
+        for (int i = tid; i < H + W + 4; i += 512) {
+            const bool isx = i >= H + 2;
+            const int o = (isx ? i - (H + 2) : i) - 1, n_out = isx ? W : H, n_src = isx ? Ws : Hs;
+            uint2 e = {0x80000000u, 0u};
+            if (o >= 0 && o < n_out) {
+                const float sc = (float)o / (isx ? sfx : sfy);
+                int i0 = (int)floorf(sc);
+                i0 = max(0, min(i0, n_src - 1));
+                const float f = fminf(fmaxf(sc - (float)i0, 0.0f), 1.0f);
+                e.x = (i0 + 1 < n_src ? 0x40000000u : 0u) | (unsigned)i0 << 16;
+                e.y = (unsigned)__builtin_bit_cast(unsigned short, (f16)(1.0f - f)) | (unsigned)__builtin_bit_cast(unsigned short, (f16)f) << 16;
+            }
+            tab_y[i] = e;
+        }
+        __syncthreads(); // (no LDS-DMA in flight yet)
+    }
 
     // ---- tile geometry (wave-uniform) and per-lane halo sources
     struct geom { int b, y0, x0, tws; }; // tws = log2(tile width): 5 (16x32) or 4 (32x16)
@@ -155,7 +206,8 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             const int pix = L >> 2, phys = L & 3;
             const int hy = tws == 5 ? pix / 34 : pix / 18;
             const int hx = pix - hy * hw;
-            hpack[j] = (unsigned)hy | (unsigned)hx << 8 | (unsigned)(phys ^ ((pix >> 2) & 3)) << 16 | (pix < HALO_PIX ? 1u << 24 : 0u);
+            // (a slot past the halo's 612 pixels: not valid, and row 255 for the interpolating loader's table lookup)
+            hpack[j] = (unsigned)(pix < HALO_PIX ? hy : 255) | (unsigned)hx << 8 | (unsigned)(phys ^ ((pix >> 2) & 3)) << 16 | (pix < HALO_PIX ? 1u << 24 : 0u);
         }
     };
     __amdgpu_buffer_rsrc_t x_rsrc;
@@ -177,6 +229,103 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             hoff[j] = valid ? (unsigned)(e * 2) : OOB;
         }
     };
+    // ---- BIL: the source patch under a tile's halo. Patch pixel q = (lane-linear 16-byte slot) >> 2 is (q / PW, q % PW) of a
+    // 12 x 21 (16x32 tiles) or 21 x 12 (32x16 tiles) window whose origin is the source pixel of the halo's first in-map row / column.
+    unsigned spack[SJ]; // tile-shape part: patch row | patch col << 8 | 16-byte group << 16 | valid << 24
+    unsigned soff[SJ];  // byte offset of the lane's 16 bytes (chunk 0) inside the source image of the halo cursor's tile
+    auto patch_w = [](int tws) { return tws == 5 ? 21 : 12; };
+    auto setup_shape_patch = [&](int tws) {
+        const int pw = patch_w(tws);
+#pragma unroll
+        for (int j = 0; j < SJ; ++j) {
+            const int L = (wave + j * NW) * 64 + lane, q = L >> 2;
+            const int prow = q / pw;
+            spack[j] = (unsigned)prow | (unsigned)(q - prow * pw) << 8 | (unsigned)(L & 3) << 16 | (q < 252 ? 1u << 24 : 0u);
+        }
+    };
+    // origin of the patch of the tile at (y0, x0): wave-uniform table reads
+    auto patch_origin = [&](int y0, int x0, int& py0, int& px0) {
+        py0 = (__builtin_amdgcn_readfirstlane(tab_y[max(y0 - 1, 0) + 1].x) >> 16) & 0x3fff;
+        px0 = (__builtin_amdgcn_readfirstlane(tab_x[max(x0 - 1, 0) + 1].x) >> 16) & 0x3fff;
+    };
+    auto setup_patch = [&](const geom& g) {
+        const long img_bytes = (long)Hs * Ws * x_pix * 2;
+        const long span = x_pix > CK ? img_bytes : (nch - 1) * x_plane_bytes + img_bytes;
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + g.b * img_bytes, 0, (int)span, 0x00020000);
+        int py0, px0;
+        patch_origin(g.y0, g.x0, py0, px0);
+#pragma unroll
+        for (int j = 0; j < SJ; ++j) {
+            unsigned pk = spack[j];
+            asm volatile("" : "+v"(pk));
+            const int sy = py0 + (int)(pk & 0xff), sx = px0 + (int)((pk >> 8) & 0xff);
+            const bool valid = (pk >> 24) && sy < Hs && sx < Ws;
+            soff[j] = valid ? (unsigned)(((sy * Ws + sx) * x_pix + (int)(((pk >> 16) & 3) << 3)) * 2) : OOB;
+        }
+    };
+    auto issue_patch = [&](int c, int sstage) {
+#pragma unroll
+        for (int j = 0; j < SJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + SRC_BASE + sstage * SRC_BYTES + (wave + j * NW) * 1024), 16, soff[j],
+                                                     c * (int)x_plane_bytes, 0, 0);
+    };
+    // ---- BIL: interpolation of one tile's halo. Unit j of a lane is halo slot L = (wave + 8 j) * 64 + lane: pixel L >> 2, physical
+    // 16-byte group L & 3 (which holds channel group (L & 3) ^ ((pixel >> 2) & 3), as the DMA form stores it); its halo row / column
+    // and channel group are the tile-shape constants of hpack[] (setup_shape_src). Per tile and unit, branch-free:
+    //   ioff: byte offsets inside the patch of the top-left source pixel's group (bits 15:0) and of its right neighbour (31:16)
+    //   idy : byte distance to the row below (0 on the source's last row)
+    //   ifr : f16 column weight fx | f16 row weight fy << 16
+    // A pixel of the conv's zero padding (or a slot past the halo) reads the patch's last four pixels, 252 .. 255, which no patch
+    // uses and the DMA's range check zero-fills: the interpolation of zeros is the padding.
+    unsigned ioff[HJ], ifr[HJ];
+    unsigned short idy[HJ];
+    int i_shape = -1; // tile shape hpack[] was set up for
+    auto setup_interp = [&](const geom& g) {
+        if (g.tws != i_shape) {
+            i_shape = g.tws;
+            setup_shape_src(i_shape);
+        }
+        int py0, px0;
+        patch_origin(g.y0, g.x0, py0, px0);
+        const int pw = patch_w(g.tws), org = py0 * pw + px0;
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+            unsigned pk = hpack[j];
+            asm volatile("" : "+v"(pk));
+            // (an edge tile's halo runs past the map: every row / column beyond it is the "outside" entry H + 1 / W + 1; so is the
+            // row of a slot past the halo's 612 pixels, whose hpack row is 255)
+            const uint2 ty = tab_y[min(g.y0 + (int)(pk & 0xff), H + 1)], tx = tab_x[min(g.x0 + (int)((pk >> 8) & 0xff), W + 1)];
+            const bool outside = (int)(ty.x | tx.x) < 0;
+            const int sy = (ty.x >> 16) & 0x3fff, sx = (tx.x >> 16) & 0x3fff;
+            const unsigned lg16 = ((pk >> 16) & 3) * 16;
+            const unsigned o00 = (outside ? 252u * PIXB : (unsigned)((sy * pw + sx - org) * PIXB)) + lg16;
+            ioff[j] = o00 | (o00 + (outside ? 0u : ((tx.x >> 30) & 1) * PIXB)) << 16;
+            idy[j] = (unsigned short)(outside ? 0u : ((ty.x >> 30) & 1) * (unsigned)(pw * PIXB));
+            ifr[j] = (tx.y >> 16) | (ty.y & 0xffff0000u);
+        }
+    };
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    // v + f * (w - v) as v - f v + f w: two fused multiply-adds whose weights add up to one EXACTLY whatever the rounding of f (a
+    // weighted sum of four rounded f16 products does not: its weights sum to 1 +- 5e-4, a smooth bias on the resized map)
+    auto lerp2 = [](h2 v, h2 w, h2 f) { return f * w + (v - f * v); };
+    auto interp_unit = [&](int j, int sstage, int hstage) {
+        const unsigned char* const sp = smem + SRC_BASE + sstage * SRC_BYTES;
+        const unsigned o0 = ioff[j] & 0xffffu, o1 = ioff[j] >> 16, dy = idy[j];
+        const f16x8 a = *reinterpret_cast<const f16x8*>(sp + o0), b = *reinterpret_cast<const f16x8*>(sp + o1);
+        const f16x8 c = *reinterpret_cast<const f16x8*>(sp + o0 + dy), d = *reinterpret_cast<const f16x8*>(sp + o1 + dy);
+        const h2 fr = __builtin_bit_cast(h2, ifr[j]);
+        const h2 fx = __builtin_shufflevector(fr, fr, 0, 0), fy = __builtin_shufflevector(fr, fr, 1, 1);
+        f16x8 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const h2 aa = {a[2 * q], a[2 * q + 1]}, bb = {b[2 * q], b[2 * q + 1]}, cc = {c[2 * q], c[2 * q + 1]}, dd = {d[2 * q], d[2 * q + 1]};
+            const h2 r = lerp2(lerp2(aa, bb, fx), lerp2(cc, dd, fx), fy);
+            o[2 * q] = r[0];
+            o[2 * q + 1] = r[1];
+        }
+        *reinterpret_cast<f16x8*>(smem + hstage * HALO_BYTES + ((wave + j * NW) * 64 + lane) * 16) = o;
+    };
+
     // One LDS-DMA instruction costs its wave 60-180 issue cycles (measured: 8 of them in a row ~1050 cycles per step
     // with the MFMA pipe idle), so the ring is fed piece by piece from inside the MFMA loop: piece k of a step is
     // issued after the k-th fragment group's MFMAs. Slab pieces come first, then halo pieces (the counted vmcnt of
@@ -237,6 +386,20 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         for (int ks = 0; ks < 2; ++ks) w_addr[st][ks] = W_BASE + st * W_BYTES + r * PIXB + (((ks * 2 + h) ^ ((r >> 2) & 3)) << 4);
 
     f32x16 acc[MT][NI];
+    // COUT = 32: the bias lives in an accumulator-shaped register tile (element 4g + q of a lane = channel 8g + 4h + q) that a tile's
+    // accumulators start from, so no epilogue adds it; the fused depth head keeps conv3's weights the same way. These kernels are
+    // bound by VALU issue at Cin = 32 (36 MFMAs per tile): every per-tile instruction counts.
+    f32x16 bias_tile, headw_tile;
+    if constexpr (COUT == 32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bias_tile[4 * g + q] = p.bias ? p.bias[8 * g + 4 * h + q] : 0.0f;
+                if constexpr (EPI == VX_DC_HEAD_F32) headw_tile[4 * g + q] = p.head_w[8 * g + 4 * h + q];
+            }
+        }
+    }
 
     // fragment groups: one (tap column kx, k-step ks) = 3 weight fragments per N-tile + 4 pixel windows for 6 NI
     // MFMAs, prefetched one group ahead (register double buffer)
@@ -280,8 +443,12 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                     const int ky = u - mi;
                     if (ky < 0 || ky > 2) continue;
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][ky][ni], af[grp & 1][u], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NI; ++ni) {
+                        if (ONE && grp == 0 && ky == 0) // the tile's first MFMA of this accumulator (compile-time after unrolling)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][ky][ni], af[grp & 1][u], bias_tile, 0, 0, 0);
+                        else
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][ky][ni], af[grp & 1][u], acc[mi][ni], 0, 0, 0);
+                    }
                 }
             feed(2 * grp);
             feed(2 * grp + 1);
@@ -366,12 +533,18 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     // keeps ml & 7 (the wider form measured 1 % slower there)
     auto stage_swz = [](int ml) { return COUT == 32 ? ((ml ^ (ml >> 2)) & 3) : (ml & 7); };
     auto zero_acc = [&]() {
+        if constexpr (ONE) return;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < NI; ++ni) {
+                if constexpr (COUT == 32) {
+                    acc[mi][ni] = bias_tile;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+                    for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+                }
+            }
     };
 
     // ---- the block's stream of (tile, chunk) steps. Two cursors run over it: the compute cursor (cur, c) and the
@@ -382,26 +555,40 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
     int shape = cur.tws;
     setup_addr(shape);
     int src_shape = shape;
-    setup_shape_src(src_shape);
-    setup_src(cur);
+    if constexpr (BIL) {
+        setup_shape_patch(src_shape);
+        setup_patch(cur);
+    } else {
+        setup_shape_src(src_shape);
+        setup_src(cur);
+    }
     int h_t = t_cur, h_c = 0;
-    auto move_cursor = [&]() { // after the halo at the cursor has been issued
+    auto move_cursor = [&]() { // after the halo (BIL: the source patch) at the cursor has been issued
         if (++h_c == nch) {
             h_c = 0;
             h_t += t_step;
             if (h_t < t_end) {
                 const geom nx = locate(h_t);
-                if (nx.tws != src_shape) {
-                    src_shape = nx.tws;
-                    setup_shape_src(src_shape);
+                if constexpr (BIL) {
+                    if (nx.tws != src_shape) {
+                        src_shape = nx.tws;
+                        setup_shape_patch(src_shape);
+                    }
+                    setup_patch(nx);
+                } else {
+                    if (nx.tws != src_shape) {
+                        src_shape = nx.tws;
+                        setup_shape_src(src_shape);
+                    }
+                    setup_src(nx);
                 }
-                setup_src(nx);
             }
         }
     };
     auto advance_halo = [&](int hstage) -> bool { // prologue: issues the halo at the cursor, moves the cursor; false = stream ended
         if (h_t >= t_end) return false;
-        issue_halo(h_c, hstage);
+        if constexpr (BIL) issue_patch(h_c, hstage);
+        else issue_halo(h_c, hstage);
         move_cursor();
         return true;
     };
@@ -411,8 +598,21 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         issue_slab(0, 0);
     }
     bool prev_halo = false; // did the previous step issue a halo (younger than the slab this step waits for)?
+    if constexpr (BIL) {
+        // patches of steps 0 and 1 -> source stages 0 and 1; step 0's halo is interpolated here, every later one inside the step
+        // before it. (The step loop's first wait + barrier make it visible.)
+        advance_halo(0);
+        advance_halo(1);
+        setup_interp(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < HS - 1; ++k) prev_halo = advance_halo(k);
+        for (int j = 0; j < HJ; ++j) interp_unit(j, 0, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < HS - 1; ++k) prev_halo = advance_halo(k);
+    }
     if (HS == 2) prev_halo = false; // with two stages the only halo in flight is the one this step needs
     zero_acc();
     int c = 0; // chunk of the current tile
@@ -447,6 +647,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         }
         stores_in_flight = false;
         stamp(0); // waited for the step's DMA
+        if constexpr (BIL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's share of the step's interpolated halo is written
         // raw s_barrier: __syncthreads() carries a fence that drains vmcnt, i.e. the halo prefetched for later steps
         __builtin_amdgcn_s_barrier(); // the step's data is in LDS for everyone; everyone has left the previous step's stages
         asm volatile("" ::: "memory");
@@ -457,7 +658,22 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
         const bool do_halo = h_t < t_end;
         const int halo_c = h_c;
         constexpr int HNEXT = (HSt + HS - 1) % HS;
-        if constexpr (COUT == 32) {
+        if constexpr (BIL) {
+            // slab of the next step; source patch two steps ahead into source stage HSt (this step's patch, consumed by the
+            // interpolation during the previous step); the NEXT step's halo is interpolated from source stage HSt ^ 1 into halo stage
+            // HSt ^ 1 (free since the barrier) in the shadow of this step's MFMAs: unit j after fragment group j
+            if (do_slab) issue_slab(slab_c, WSt ^ 1);
+            if (do_halo) {
+                issue_patch(halo_c, HSt);
+                move_cursor();
+            }
+            const bool do_interp = !last_chunk || t_cur + t_step < t_end;
+            if (do_interp && last_chunk) setup_interp(locate(t_cur + t_step));
+            stamp(2);
+            compute(hs_c, ws_c, c, [&](int k) {
+                if (do_interp && (k & 1) && (k >> 1) < HJ) interp_unit(k >> 1, HSt ^ 1, HSt ^ 1);
+            });
+        } else if constexpr (COUT == 32) {
             // 36 MFMAs per step: the 8 DMA pieces go out in one burst before the loop (measured 2-3 % faster than
             // feeding them from inside it)
             if (do_slab) issue_slab(slab_c, WSt ^ 1);
@@ -496,10 +712,7 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = 8 * g + 4 * h + q;
-                        part += fmaxf(acc[mi][0][4 * g + q] + s_bias[n], 0.0f) * p.head_w[n];
-                    }
+                    for (int q = 0; q < 4; ++q) part += relu1(acc[mi][0][4 * g + q]) * headw_tile[4 * g + q];
                 part += __shfl_xor(part, 32, 64);
                 const int oy = cur.y0 + out_row(cur.tws, mi), ox = cur.x0 + out_col(cur.tws);
                 if (h == 0 && oy < H && ox < W)
@@ -515,9 +728,9 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
                     const int oy = cur.y0 + out_row(cur.tws, mi), ox = cur.x0 + out_col(cur.tws);
                     if (oy < H && ox < W) {
                         float* o = reinterpret_cast<float*>(p.out) + (((long)cur.b * H + oy) * W + ox) * 3;
-                        o[0] = acc[mi][0][0] + s_bias[0];
-                        o[1] = acc[mi][0][1] + s_bias[1];
-                        o[2] = acc[mi][0][2] + s_bias[2];
+                        o[0] = acc[mi][0][0]; // (bias: accumulator start)
+                        o[1] = acc[mi][0][1];
+                        o[2] = acc[mi][0][2];
                     }
                 }
             }
@@ -542,7 +755,8 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int nl = ni * 32 + 8 * g + 4 * h;
-                        const float4 bias = *reinterpret_cast<const float4*>(s_bias + nl);
+                        float4 bias = {0.f, 0.f, 0.f, 0.f}; // (COUT = 32: the accumulators started from the bias)
+                        if constexpr (COUT != 32) bias = *reinterpret_cast<const float4*>(s_bias + nl);
                         float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
                                       acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
 #pragma unroll
@@ -658,21 +872,23 @@ int dconv_grid_blocks() {
     return n_cu; // one 8-wave block per CU (its LDS ring takes the whole 160 KB)
 }
 
-template <int COUT, int RES, int HSV>
-constexpr int dconv_smem_bytes() { return HSV * (5 * NW * 1024) + (RES ? RES : 2) * 9 * COUT * PIXB + COUT * 4; }
+template <int COUT, int RES, int HSV, bool BIL = false>
+constexpr int dconv_smem_bytes() {
+    return HSV * (5 * NW * 1024) + (BIL ? 2 * 256 * PIXB : 0) + (RES ? RES : 2) * 9 * COUT * PIXB + (BIL ? ((COUT * 4 + 15) & ~15) + (DCONV_TAB_MAX + 4) * 8 : COUT * 4);
+}
 
-template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2)>
+template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2), bool BIL = false, bool ONE = false>
 int prepare_variant() { // > 64 KB of dynamic LDS needs the attribute; set once, outside any stream capture
-    static_assert(dconv_smem_bytes<COUT, RES, HSV>() <= 160 * 1024, "variant does not fit the LDS");
-    VX_CHECK(vx_ensure_dynamic_lds(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV>),
-                                   dconv_smem_bytes<COUT, RES, HSV>())); // per (kernel, device), not per process
+    static_assert(dconv_smem_bytes<COUT, RES, HSV, BIL>() <= 160 * 1024, "variant does not fit the LDS");
+    VX_CHECK(vx_ensure_dynamic_lds(reinterpret_cast<const void*>(&dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV, BIL, ONE>),
+                                   dconv_smem_bytes<COUT, RES, HSV, BIL>())); // per (kernel, device), not per process
     return 1;
 }
 
-template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2)>
+template <int COUT, int EPI, bool AR, bool STAMP, int RES = 0, int HSV = (COUT == 32 ? 3 : 2), bool BIL = false, bool ONE = false>
 int launch_variant(const vx_dconv_args& a, hipStream_t s) {
-    constexpr int smem = dconv_smem_bytes<COUT, RES, HSV>();
-    if (!prepare_variant<COUT, EPI, AR, STAMP, RES, HSV>()) return 0;
+    constexpr int smem = dconv_smem_bytes<COUT, RES, HSV, BIL>();
+    if (!prepare_variant<COUT, EPI, AR, STAMP, RES, HSV, BIL, ONE>()) return 0;
     const long tiles = (long)a.B * tile_grid(a.H, a.W).total();
     // Persistent blocks, one per CU at most. The number of ROUNDS (tiles per block) is what the launch takes; given the rounds, the
     // fewest blocks that still do it in that many leave the other CUs to concurrent launches (550 tiles: 184 blocks x 3 instead of
@@ -684,13 +900,19 @@ int launch_variant(const vx_dconv_args& a, hipStream_t s) {
         const long blocks_per_xcd = (per_xcd + rounds - 1) / rounds;
         blocks = (int)(8 * blocks_per_xcd);
     }
-    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV>), dim3(blocks), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((dconv3x3_kernel<COUT, EPI, AR, STAMP, RES, HSV, BIL, ONE>), dim3(blocks), dim3(512), smem, s, a);
     VX_LAUNCH_CHECK();
     return 1;
 }
 
 template <int COUT, int EPI>
 int launch_dconv(const vx_dconv_args& a, hipStream_t s) {
+    if constexpr (COUT == 32 && EPI == VX_DC_HEAD_F32) { // the depth head at Cin = 32 (one step per tile): see ONE
+        if (a.cin == 32) return a.bil_hs > 0 ? launch_variant<32, EPI, false, false, 0, 2, true, true>(a, s) : launch_variant<32, EPI, false, false, 0, 3, false, true>(a, s);
+    }
+    if constexpr (COUT == 32 && (EPI == VX_DC_F16 || EPI == VX_DC_HEAD_F32)) {
+        if (a.bil_hs > 0) return launch_variant<32, EPI, false, false, 0, 2, true>(a, s); // interpolating loader
+    }
     if constexpr (EPI == VX_DC_F16) {
         if (a.a_relu) return launch_variant<COUT, EPI, true, false>(a, s);
         if (a.stamps) return launch_variant<COUT, EPI, false, true>(a, s);
@@ -809,7 +1031,17 @@ extern "C" int vx_dconv_prepare(void) {
     return prepare_variant<32, VX_DC_F16, false, false>() && prepare_variant<32, VX_DC_F16, true, false>() &&
            prepare_variant<32, VX_DC_F16, false, false, 2, 3>() && prepare_variant<32, VX_DC_F16, false, false, 4, 2>() &&
            prepare_variant<64, VX_DC_F16, false, false>() && prepare_variant<64, VX_DC_F16, true, false>() &&
-           prepare_variant<32, VX_DC_RGB_F32, false, false>() && prepare_variant<32, VX_DC_HEAD_F32, false, false>();
+           prepare_variant<32, VX_DC_RGB_F32, false, false>() && prepare_variant<32, VX_DC_HEAD_F32, false, false>() &&
+           prepare_variant<32, VX_DC_F16, false, false, 0, 2, true>() && prepare_variant<32, VX_DC_HEAD_F32, false, false, 0, 2, true>() &&
+           prepare_variant<32, VX_DC_HEAD_F32, false, false, 0, 2, true, true>() && prepare_variant<32, VX_DC_HEAD_F32, false, false, 0, 3, false, true>();
+}
+
+// the interpolating loader's limits: an 18 x 34 (or 34 x 18) halo must map into a 12 x 21 (21 x 12) source patch
+extern "C" int vx_dconv_bilinear_supported(int cout, int H, int W, int hs, int ws) {
+    if (cout != 32 || H < 2 || W < 2 || hs < 2 || ws < 2 || hs > H || ws > W || H + W > DCONV_TAB_MAX) return 0;
+    const double ry = (double)(hs - 1) / (double)(H - 1), rx = (double)(ws - 1) / (double)(W - 1);
+    auto rows = [](double r, int n) { return (int)std::floor((n - 1) * r + 1.0) + 2; }; // source rows under n consecutive output rows, worst phase
+    return rows(ry, 18) <= 12 && rows(rx, 34) <= 21 && rows(ry, 34) <= 21 && rows(rx, 18) <= 12;
 }
 
 extern "C" int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream) {
@@ -818,10 +1050,13 @@ extern "C" int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream) {
     VX_REQUIRE(a.cin >= 32 && a.cin % 32 == 0, "vx_dconv3x3_f16: Cin %d must be a multiple of 32", a.cin);
     VX_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "vx_dconv3x3_f16: empty extent");
     VX_REQUIRE(!a.up2 || (a.H % 2 == 0 && a.W % 2 == 0), "vx_dconv3x3_f16: upsampled extent must be even");
+    VX_REQUIRE(a.bil_hs <= 0 || (!a.up2 && !a.a_relu && !a.x_residual && !a.stamps && vx_dconv_bilinear_supported(a.cout, a.H, a.W, a.bil_hs, a.bil_ws)),
+               "vx_dconv3x3_f16: bilinear input %dx%d -> %dx%d (cout %d) is outside the interpolating loader's limits", a.bil_ws, a.bil_hs, a.W, a.H, a.cout);
+    VX_REQUIRE(a.res2_hs <= 0, "vx_dconv3x3_f16: bilinear res2 is not built");
     VX_REQUIRE((reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(a.out) & 15) == 0, "vx_dconv3x3_f16: operands must be 16-byte aligned");
     {
-        const int64_t src_pixels = (int64_t)(a.H >> (a.up2 ? 1 : 0)) * (a.W >> (a.up2 ? 1 : 0));
+        const int64_t src_pixels = a.bil_hs > 0 ? (int64_t)a.bil_hs * a.bil_ws : (int64_t)(a.H >> (a.up2 ? 1 : 0)) * (a.W >> (a.up2 ? 1 : 0));
         const int64_t xp = a.x_pix ? a.x_pix : 32;
         VX_REQUIRE(xp >= 32 && xp % 8 == 0 && a.out_pix % 8 == 0 && a.res1_pix % 8 == 0 && a.res2_pix % 8 == 0, "vx_dconv3x3_f16: pixel strides must be multiples of 8 (input >= 32)");
         VX_REQUIRE(a.cin == 32 || (a.x_plane % 8 == 0 && (xp > 32 ? a.x_plane >= 32 : a.x_plane >= (int64_t)a.B * src_pixels * 32)), "vx_dconv3x3_f16: bad input plane stride");

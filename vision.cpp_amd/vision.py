@@ -188,8 +188,8 @@ class Model:
         check(self._family_fn("enable_timing")(self._handle, int(enable)))
 
     def read_timing(self):
-        arr, n = (lib.Timing * 64)(), c_int32()
-        check(self._family_fn("read_timing")(self._handle, arr, 64, byref(n)))
+        arr, n = (lib.Timing * 256)(), c_int32()
+        check(self._family_fn("read_timing")(self._handle, arr, 256, byref(n)))
         return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches, flops=arr[i].flops, bytes=arr[i].bytes)
                 for i in range(n.value)]
 
