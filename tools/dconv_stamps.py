@@ -15,7 +15,7 @@ from tests import gpu_util as G  # noqa: E402
 from visioncpp_amd import _lib as L  # noqa: E402
 
 
-def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3):
+def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3, nhwc=False, res=False):
     rng = np.random.default_rng(0)
     planes = max(cin // 32, 6)
     x = G.dev((rng.standard_normal((planes, B, H, W, 32)) * 0.5).astype(np.float16))
@@ -31,6 +31,11 @@ def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3):
     a.epi, a.act, a.s1, a.s2 = L.DC_F16, 1, 0.2, 1.0
     a.out, a.out_plane = out.ptr, B * H * W * 32
     a.x_residual = int(x_residual)
+    if nhwc:  # the DPT maps: NHWC through the pixel / plane strides, optional residual
+        a.x_pix, a.x_plane, a.out_pix, a.out_plane, a.res1_pix, a.res1_plane, a.res2_pix, a.res2_plane = cin, 32, cout, 32, cout, 32, cout, 32
+        a.act, a.s1 = 0, 1.0
+        if res:
+            a.res1 = x.ptr
     api = G.api()
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     api.vx_event_create(C.byref(ev0)); api.vx_event_create(C.byref(ev1))
@@ -57,5 +62,12 @@ def run(cin, cout, B=64, H=144, W=144, x_residual=False, reps=3):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dpt":  # the Depth-Anything tail at batch 32
+        run(64, 64, B=32, H=148, W=148, nhwc=True, res=True)
+        run(64, 64, B=32, H=148, W=148, nhwc=True)
+        run(64, 64, B=32, H=74, W=74, nhwc=True, res=True)
+        run(64, 32, B=32, H=296, W=296, nhwc=True)
+        run(32, 32, B=32, H=518, W=518, nhwc=True)
+        sys.exit(0)
     for cin, cout, xr in [(64, 32, False), (96, 32, False), (128, 32, False), (160, 32, False), (192, 64, True), (64, 64, False)]:
         run(cin, cout, x_residual=xr)

@@ -746,78 +746,103 @@ __global__ __launch_bounds__(512) void dconv3x3_kernel(const vx_dconv_args p) {
             unsigned char* st;
             if constexpr (COUT == 32) st = smem + done * HALO_BYTES + wave * 64 * PITCH;
             else st = (wave < 4 ? smem + done * HALO_BYTES : smem + W_BASE + WSt * W_BYTES) + (wave & 3) * 64 * PITCH;
-            const float slope = p.act == 1 ? 0.2f : (p.act == 2 ? 0.0f : 1.0f); // max(v, slope*v): LeakyReLU 0.2 / ReLU / identity
+            // The epilogue costs as many cycles as the tile's MFMA loops at Cin = 64 (in-kernel stamps, profiles/r03_dconv_stamps_dpt.txt:
+            // 7.6k of 20.8k per tile) and it is VALU issue: the activation is chosen by a wave-uniform branch (identity costs nothing,
+            // ReLU one instruction), residuals with unit scale are packed-f16 adds, and a row's pixel is tile base + a scalar.
+            auto stage_tile = [&](auto act_c) {
+                constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const int ml = mi * 32 + r; // row inside the wave's staging block
+                for (int mi = 0; mi < MT; ++mi) {
+                    const int ml = mi * 32 + r; // row inside the wave's staging block
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int nl = ni * 32 + 8 * g + 4 * h;
-                        float4 bias = {0.f, 0.f, 0.f, 0.f}; // (COUT = 32: the accumulators started from the bias)
-                        if constexpr (COUT != 32) bias = *reinterpret_cast<const float4*>(s_bias + nl);
-                        float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
-                                      acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
+                        for (int g = 0; g < 4; ++g) {
+                            const int nl = ni * 32 + 8 * g + 4 * h;
+                            float4 bias = {0.f, 0.f, 0.f, 0.f}; // (COUT = 32: the accumulators started from the bias)
+                            if constexpr (COUT != 32) bias = *reinterpret_cast<const float4*>(s_bias + nl);
+                            float v[4] = {acc[mi][ni][4 * g + 0] + bias.x, acc[mi][ni][4 * g + 1] + bias.y,
+                                          acc[mi][ni][4 * g + 2] + bias.z, acc[mi][ni][4 * g + 3] + bias.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], slope * v[j]);
-                        if (xres) {
+                            for (int j = 0; j < 4; ++j) {
+                                if constexpr (ACT == 2) v[j] = relu1(v[j]);
+                                else if constexpr (ACT == 1) v[j] = fmaxf(v[j], 0.2f * v[j]);
+                            }
+                            if (xres) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] *= p.s1;
+                                for (int j = 0; j < 4; ++j) v[j] *= p.s1;
+                            }
+                            f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                            const int c8 = nl >> 2;
+                            const int phys16 = (c8 >> 1) ^ stage_swz(ml);
+                            *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
                         }
-                        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                        const int c8 = nl >> 2;
-                        const int phys16 = (c8 >> 1) ^ stage_swz(ml);
-                        *reinterpret_cast<f16x4*>(st + ml * PITCH + phys16 * 16 + (c8 & 1) * 8) = o;
-                    }
-            }
+                }
+            };
+            if (p.act == 2) stage_tile(std::integral_constant<int, 2>{});
+            else if (p.act == 1) stage_tile(std::integral_constant<int, 1>{});
+            else stage_tile(std::integral_constant<int, 0>{});
             // drain in batches of NB row groups: residual loads of a batch are issued together (out-of-map pixels
-            // read a clamped, valid address and store to the trash page)
-            const f16* __restrict__ R1 = reinterpret_cast<const f16*>(p.res1);
-            const f16* __restrict__ R2 = reinterpret_cast<const f16*>(p.res2);
-            constexpr int ROWS_PER_IT = 64 / NCH16;
+            // read the tile's first pixel, a valid address, and store to the trash page)
+            const char* const R1 = reinterpret_cast<const char*>(p.res1);
+            const char* const R2 = reinterpret_cast<const char*>(p.res2);
+            constexpr int ROWS_PER_IT = 64 / NCH16, IT_PER_MT = 32 / ROWS_PER_IT;
             constexpr int NB = 4; // iterations whose loads are in flight together
-            const int j = lane % NCH16;
+            const int j = lane % NCH16, fr0 = lane / NCH16;
             const int jp = j >> 2, je = (j & 3) * 8; // plane of the lane's 8 channels, element offset inside the pixel
+            // staged row of iteration t: ml = t * ROWS_PER_IT + fr0, i.e. M-tile t / IT_PER_MT, pixel fr0 + ROWS_PER_IT * (t % IT_PER_MT) of it.
+            // 16x32 tiles: output (y0 + 2 wave + M-tile, x0 + pixel); 32x16 tiles: (y0 + 4 wave + M-tile + 2 (pixel >> 4), x0 + (pixel & 15)),
+            // where pixel >> 4 and the multiple-of-8 part of pixel & 15 only depend on t: pixel index = lane base + a per-t SCALAR.
+            const bool wide = cur.tws == 5;
+            const int oy_b = cur.y0 + (wide ? 2 * wave : 4 * wave), ox_b = cur.x0 + (wide ? fr0 : (fr0 & 15));
+            const int tile0 = (cur.b * H + cur.y0) * W + cur.x0;                 // always inside the map
+            const int base = (cur.b * H + oy_b) * W + ox_b;                     // (pixel indices fit 32 bits: checked by the host)
+            const long off1 = ((long)jp * p.res1_plane + je) * 2, off2 = ((long)jp * p.res2_plane + je) * 2, offo = ((long)jp * p.out_plane + je) * 2;
+            const bool unit = p.s1 == 1.0f && p.s2 == 1.0f;
+            const int rp1 = (int)res1_pix * 2, rp2 = (int)res2_pix * 2, rpo = (int)out_pix * 2; // byte strides between pixels
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-local hand-over of the staged rows: no block barrier
             const float s1 = p.s1, s2 = p.s2;
 #pragma unroll
             for (int ib = 0; ib < NCH16; ib += NB) {
-                long pixel[NB];
+                int pixel[NB];
                 bool ok[NB];
                 f16x8 ra[NB], rc[NB], v[NB];
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {
-                    const int fl = (ib + it) * ROWS_PER_IT + lane / NCH16, fm = fl >> 5, fr = fl & 31; // staged row -> (M-tile, pixel)
-                    const int oy = cur.y0 + (cur.tws == 5 ? 2 * wave + fm : 4 * wave + fm + 2 * (fr >> 4));
-                    const int ox = cur.x0 + (cur.tws == 5 ? fr : (fr & 15));
-                    ok[it] = oy < H && ox < W;
-                    pixel[it] = ((long)cur.b * H + min(oy, H - 1)) * W + min(ox, W - 1);
+                    const int t = ib + it, fm = t / IT_PER_MT, dfr = ROWS_PER_IT * (t % IT_PER_MT); // compile-time after unrolling
+                    const int dy = wide ? fm : fm + 2 * (dfr >> 4), dx = wide ? dfr : (dfr & 15);   // wave-uniform
+                    ok[it] = oy_b + dy < H && ox_b + dx < W;
+                    pixel[it] = ok[it] ? base + dy * W + dx : tile0;
                 }
                 if (R1) {
 #pragma unroll
-                    for (int it = 0; it < NB; ++it) ra[it] = *reinterpret_cast<const f16x8*>(R1 + jp * p.res1_plane + pixel[it] * res1_pix + je);
+                    for (int it = 0; it < NB; ++it) ra[it] = *reinterpret_cast<const f16x8*>(R1 + off1 + (long)pixel[it] * rp1);
                 }
                 if (R2) {
 #pragma unroll
-                    for (int it = 0; it < NB; ++it) rc[it] = *reinterpret_cast<const f16x8*>(R2 + jp * p.res2_plane + pixel[it] * res2_pix + je);
+                    for (int it = 0; it < NB; ++it) rc[it] = *reinterpret_cast<const f16x8*>(R2 + off2 + (long)pixel[it] * rp2);
                 }
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {
-                    const int ml = (ib + it) * ROWS_PER_IT + lane / NCH16;
+                    const int ml = (ib + it) * ROWS_PER_IT + fr0;
                     v[it] = *reinterpret_cast<const f16x8*>(st + ml * PITCH + (j ^ stage_swz(ml)) * 16);
                 }
 #pragma unroll
                 for (int it = 0; it < NB; ++it) {
-                    if (R1) {
+                    if (unit) { // the staged value is f16 already: a correctly rounded f16 add gives the same bits as the f32 form below
+                        if (R1) v[it] = v[it] + ra[it];
+                        if (R2) v[it] = v[it] + rc[it];
+                    } else {
+                        if (R1) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s1 + (float)ra[it][q]);
-                    }
-                    if (R2) {
+                            for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s1 + (float)ra[it][q]);
+                        }
+                        if (R2) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s2 + (float)rc[it][q]);
+                            for (int q = 0; q < 8; ++q) v[it][q] = (f16)((float)v[it][q] * s2 + (float)rc[it][q]);
+                        }
                     }
-                    f16* dst = ok[it] ? reinterpret_cast<f16*>(p.out) + jp * p.out_plane + pixel[it] * out_pix + je : trash;
+                    f16* dst = ok[it] ? reinterpret_cast<f16*>(reinterpret_cast<char*>(p.out) + offo + (long)pixel[it] * rpo) : trash;
                     *reinterpret_cast<f16x8*>(dst) = v[it];
                 }
             }
@@ -1049,6 +1074,8 @@ extern "C" int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream) {
     VX_REQUIRE(a.x && a.w && a.out, "vx_dconv3x3_f16: null operand");
     VX_REQUIRE(a.cin >= 32 && a.cin % 32 == 0, "vx_dconv3x3_f16: Cin %d must be a multiple of 32", a.cin);
     VX_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "vx_dconv3x3_f16: empty extent");
+    VX_REQUIRE((int64_t)a.B * a.H * a.W < (int64_t)0x7fffffff && a.out_pix < (1 << 20) && a.res1_pix < (1 << 20) && a.res2_pix < (1 << 20),
+               "vx_dconv3x3_f16: pixel indices must fit 32 bits; run fewer images per call");
     VX_REQUIRE(!a.up2 || (a.H % 2 == 0 && a.W % 2 == 0), "vx_dconv3x3_f16: upsampled extent must be even");
     VX_REQUIRE(a.bil_hs <= 0 || (!a.up2 && !a.a_relu && !a.x_residual && !a.stamps && vx_dconv_bilinear_supported(a.cout, a.H, a.W, a.bil_hs, a.bil_ws)),
                "vx_dconv3x3_f16: bilinear input %dx%d -> %dx%d (cout %d) is outside the interpolating loader's limits", a.bil_ws, a.bil_hs, a.W, a.H, a.cout);
