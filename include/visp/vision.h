@@ -4,12 +4,16 @@
 // the reference's high-level API -- scripts/pkg-check/main.cpp:22-44 is the model -- builds against this backend unchanged.
 // Header-only over the binary-stable C ABI (include/visp_c_api.h, lib/libvisioncpp.so): link with -lvisioncpp.
 //
-// Covered: backend_init / backend_device, image_view / image_data / image_alloc / image_clear / image_scale, and per family
-// *_load_model + *_compute for depth_anything, esrgan, birefnet and sam (sam_encode + sam_compute with a point or a box).
-// Not covered (this backend has no graph IR): the ml.h layer -- compute_graph, model_ref, tensor -- and
-// the *_process_input / *_predict graph pieces built on it; birefnet_* and migan_* (families not built).
+// Covered: backend_init / backend_device, image_view / image_data / image_alloc / image_clear / image_scale / image_u8_to_f32 /
+// image_normalize, per family *_load_model + *_compute for depth_anything, esrgan, birefnet and sam (sam_encode + sam_compute with a
+// point or a box), and the Depth-Anything pipeline pieces depthany_params / depthany_detect_params / depthany_image_extent /
+// depthany_process_input / depthany_process_output (vision.h:236-252).
+// Not covered (this backend has no graph IR): the ml.h layer -- compute_graph, model_ref, tensor, model_file --
+// and the *_predict(model_ref, tensor, ...) graph builders on it (so depthany_detect_params takes the loaded model instead of a
+// model_file); migan_* (family not built).
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <exception>
@@ -103,6 +107,21 @@ inline image_data image_scale(image_view const& img, i32x2 target) { // src/visp
     return detail::take(out, owner);
 }
 
+// image.cpp:215-255: dst = (src / 255 + offset) * scale per channel, any u8 format -> the float format `format`
+inline image_data image_u8_to_f32(image_view const& img, image_format format, std::array<float, 4> offset = {0, 0, 0, 0}, std::array<float, 4> scale = {1, 1, 1, 1}) {
+    visp_image_view in = detail::c_view(img), out{};
+    visp_image_data* owner = nullptr;
+    detail::check(visp_image_u8_to_f32(&in, int32_t(format), offset.data(), scale.data(), &out, &owner));
+    return detail::take(out, owner);
+}
+// image.cpp:537-582: min-max of an alpha_f32 image mapped to [min, max]
+inline image_data image_normalize(image_view const& img, float min = 0, float max = 1) {
+    visp_image_view in = detail::c_view(img), out{};
+    visp_image_data* owner = nullptr;
+    detail::check(visp_image_normalize(&in, min, max, &out, &owner));
+    return detail::take(out, owner);
+}
+
 //
 // backend (include/visp/ml.h:32-64)
 
@@ -167,6 +186,52 @@ inline image_data depthany_compute(depthany_model& model, image_view image) { //
     visp_image_data* owner = nullptr;
     detail::check(visp_depthany_compute_f32(model.handle, &in, &out, &owner));
     return detail::take(out, owner);
+}
+
+// --- Depth Anything pipeline (vision.h:236-252, arch/depth-anything.cpp:112-149). The reference reads the parameters from a
+// model_file; this backend has no GGUF surface in its public header, so they come from the loaded model.
+struct dino_params { int patch_size = 14, embed_dim = 384, n_layers = 12, n_heads = 6; }; // vision.h dino_params
+struct depthany_params {
+    int image_size = 518;
+    int image_multiple = 14;
+    i32x2 image_extent = {518, 518};
+    float max_depth = 1;
+    std::array<int, 4> feature_layers = {2, 5, 8, 11};
+    dino_params dino;
+};
+// round the short side up to a multiple of image_multiple (at least image_size), keep the aspect ratio, round both up (:112-117)
+inline i32x2 depthany_image_extent(i32x2 extent, depthany_params const& p) {
+    auto next_multiple = [](int x, int m) { return (x + m - 1) / m * m; };
+    const int min_side = extent[0] < extent[1] ? extent[0] : extent[1];
+    const int tgt = next_multiple(min_side, p.image_multiple) > p.image_size ? next_multiple(min_side, p.image_multiple) : p.image_size;
+    return i32x2(next_multiple(extent[0] * tgt / min_side, p.image_multiple), next_multiple(extent[1] * tgt / min_side, p.image_multiple));
+}
+inline depthany_params depthany_detect_params(depthany_model const& model, i32x2 input_extent = {}) { // (:119-128)
+    visp_depthany_info info{};
+    detail::check(visp_depthany_get_info(model.handle, &info));
+    depthany_params p;
+    p.image_size = info.image_size;
+    p.image_multiple = info.image_multiple;
+    p.max_depth = info.max_depth;
+    for (int i = 0; i < 4; ++i) p.feature_layers[size_t(i)] = info.feature_layers[i];
+    p.dino = dino_params{info.patch_size, info.embed_dim, info.n_layers, info.n_heads};
+    if (input_extent[0] > 0 && input_extent[1] > 0) p.image_extent = depthany_image_extent(input_extent, p);
+    return p;
+}
+// image_scale to the model extent where it differs, then (u8 / 255 - mean) / std -> rgb_f32 (:130-140)
+inline image_data depthany_process_input(image_view image, depthany_params const& p) {
+    image_data resized;
+    if (image.extent[0] != p.image_extent[0] || image.extent[1] != p.image_extent[1]) {
+        resized = image_scale(image, p.image_extent);
+        image = image_view(resized);
+    }
+    return image_u8_to_f32(image, image_format::rgb_f32, {-0.485f, -0.456f, -0.406f, 0.f}, {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f, 1.f});
+}
+// min-max normalise the raw depth at the model extent, scale to the caller's extent where it differs (:142-149)
+inline image_data depthany_process_output(std::span<float const> output_data, i32x2 target_extent, depthany_params const& p) {
+    image_data normalized = image_normalize(image_view(p.image_extent, image_format::alpha_f32, output_data.data()));
+    if (normalized.extent[0] != target_extent[0] || normalized.extent[1] != target_extent[1]) return image_scale(normalized, target_extent);
+    return normalized;
 }
 
 // ESRGAN (vision.h:284-304): any size, tiled, -> rgba_u8 at scale x the input extent (vision.cpp:220-253)

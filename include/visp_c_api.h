@@ -128,6 +128,9 @@ VISP_API int32_t visp_depthany_use_graph(visp_model* m, int32_t enable);
  * + one token-stationary block launch per layer (csrc/kernels_block.hip; embed dim 384 / mlp 1536 / head dim 64 only).
  * Results agree to f16 rounding. */
 VISP_API int32_t visp_depthany_set_schedule(visp_model* m, int32_t schedule);
+/* sub-batches of one step on parallel HIP streams (parallel branches of the step's hipGraph): 0 = automatic (3 from batch 24, 2
+ * from batch 8), 1 = none, up to 4. Results are bit-identical for every value (images are independent). */
+VISP_API int32_t visp_depthany_set_split(visp_model* m, int32_t n);
 
 /* Named intermediate tensors of the last compute, converted to f32 on the host (parity tests;
  * the reference's counterpart is the workbench capture, tests/workbench.cpp:754-760).
@@ -160,6 +163,13 @@ VISP_API int32_t visp_gguf_validate(char const* filepath, int32_t* out_n_tensors
  * any supported format; the result is owned by *out_data (visp_image_destroy) */
 VISP_API int32_t visp_image_scale(visp_image_view const* src, int32_t width, int32_t height, visp_image_view* out_image,
                                   visp_image_data** out_data);
+/* host-only image_u8_to_f32 of the reference (src/visp/image.cpp:215-255, image-impl.h:17-34): dst = (src / 255 + offset) * scale per
+ * channel, any u8 format -> the float format `format` (what *_process_input applies); result owned by *out_data */
+VISP_API int32_t visp_image_u8_to_f32(visp_image_view const* src, int32_t format, float const offset[4], float const scale[4],
+                                      visp_image_view* out_image, visp_image_data** out_data);
+/* host-only image_normalize of the reference (src/visp/image.cpp:537-582): min-max of an alpha_f32 image mapped to [min, max]
+ * (depthany_process_output); result owned by *out_data */
+VISP_API int32_t visp_image_normalize(visp_image_view const* src, float min, float max, visp_image_view* out_image, visp_image_data** out_data);
 VISP_API int32_t visp_esrgan_tile_layout(int32_t w, int32_t h, int32_t scale, int32_t out8[8]);
 /* img: u8 [B,h,w,channels(format)] (rgba/bgra/argb/rgb), out: rgba_u8 [B, h*scale, w*scale, 4]; device pointers;
  * stream = hipStream_t or NULL (NULL: the device's stream, synchronised before returning) */

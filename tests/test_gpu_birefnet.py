@@ -174,6 +174,30 @@ def test_birefnet_lite_configuration(device, tmp_path):
     assert np.abs(mask - want).max() < 3e-2 and np.abs(mask - want).mean() < 3e-3, np.abs(mask - want).max()
 
 
+def test_birefnet_lite_1024_batch_8(device, tmp_path):
+    """BASELINE.json configs[3] at its per-GPU share: BiRefNet-lite (swin_t backbone), 1024 x 1024, batch 8 (64 images over 8 GPUs).
+    Size-independent properties over the whole batch -- finite, a sigmoid's range, images independent of their batch position (bit
+    for bit: a duplicated image gives a duplicated mask, a single-image launch gives the same mask) -- and one image against the
+    oracle's birefnet_predict at full size (edge windows, window padding 256 -> 259 on the 1/4 map, all four decoder levels)."""
+    cfg = dataclasses.replace(synth.SWIN_T, image_size=1024)
+    sd = synth.birefnet_state_dict(cfg, 9)
+    model = vision.Model.load(synth.write_birefnet_gguf(tmp_path / "lite1024.gguf", cfg, sd=sd), device)
+    imgs = synth.images(8, 1024, 1024, seed=64)
+    imgs[5] = imgs[1]
+    masks = model.segment_batch(imgs)
+    assert masks.shape == (8, 1024, 1024) and np.isfinite(masks).all() and masks.min() >= 0.0 and masks.max() <= 1.0
+    assert masks.std() > 1e-4  # (not a constant image)
+    np.testing.assert_array_equal(masks[5], masks[1])
+    np.testing.assert_array_equal(model.segment_batch(imgs[2:3])[0], masks[2])
+    np.testing.assert_array_equal(model.segment_batch(imgs[::-1].copy())[::-1], masks)
+    tensors, conv_idx = synth.birefnet_gguf_tensors(sd)
+    om = oracle.Model(tensors, conv_idx)
+    P = oracle.swin_params(cfg.embed_dim, cfg.window_size, cfg.depths, cfg.n_heads)
+    want = oracle.birefnet_predict(om, P, _pre(imgs[2]))
+    d = np.abs(masks[2] - want)
+    assert d.max() < 3e-2 and d.mean() < 3e-3, (d.max(), d.mean())
+
+
 def test_reference_c_api_compute(mini):
     """visp_model_compute for family 1 = birefnet_compute (vision.cpp:108-132): a 300 x 200 bgra image is scaled to the model
     extent (256 x 256) with image_scale, segmented, scaled back and returned as alpha_u8."""

@@ -182,6 +182,19 @@ def test_batch_independence_and_determinism(small):
     np.testing.assert_array_equal(rev[::-1], a)
 
 
+def test_sub_batch_split_is_bit_identical(small):
+    """A step's batch runs as up to four sub-batches on parallel streams; every split gives the same bits."""
+    imgs = synth.images(9, 518, 518, seed=41)
+    small.set_split(1)
+    want = small.compute_batch(imgs)
+    try:
+        for n in (2, 3, 4, 0):
+            small.set_split(n)
+            np.testing.assert_array_equal(small.compute_batch(imgs), want, err_msg=f"split {n}")
+    finally:
+        small.set_split(0)
+
+
 def test_graph_replay_matches_direct_launches(small):
     imgs = synth.images(2, 518, 518, seed=5)
     want = small.compute_batch(imgs)
@@ -222,6 +235,20 @@ def test_reference_c_api_compute(small):
     want_wide = oracle.image_f32_to_u8(oracle.image_normalize(back)[..., None], oracle.ALPHA_F32, oracle.ALPHA_U8)[..., 0]  # c-api.cpp:72-77
     d = np.abs(res.astype(int) - want_wide.astype(int))
     assert d.max() <= 3 and d.mean() < 0.5, (d.max(), d.mean())
+    # rgba with a varying alpha channel: depthany_process_input scales the image in ITS format (stb resizes rgba alpha-weighted) and
+    # only then drops alpha (image_u8_to_f32 to rgb_f32, depth-anything.cpp:130-140) -- not the other way round
+    rng = np.random.default_rng(3)
+    alpha = (rng.random((480, 640, 1)) * 255).astype(np.uint8)
+    alpha[:, :320] = 255
+    rgba = np.concatenate([wide, alpha], axis=-1)
+    res_a = small.compute(rgba, vision.ImageFormat.rgba_u8)
+    scaled = oracle.image_scale(rgba, oracle.RGBA_U8, ew, eh)[..., :3]
+    want_a, _ = om.compute(params, np.ascontiguousarray(scaled))
+    back = oracle.image_scale(want_a, oracle.ALPHA_F32, 640, 480)
+    want_a8 = oracle.image_f32_to_u8(oracle.image_normalize(back)[..., None], oracle.ALPHA_F32, oracle.ALPHA_U8)[..., 0]
+    d = np.abs(res_a.astype(int) - want_a8.astype(int))
+    assert d.max() <= 3 and d.mean() < 0.5, (d.max(), d.mean())
+    assert np.abs(res_a.astype(int) - res.astype(int)).max() > 3  # (and it is not what the opaque image gives)
 
 
 def test_non_square_extent_vs_oracle(small):
@@ -301,6 +328,20 @@ def test_public_cpp_header_pkg_check(tmp_path):
     assert r.returncode == 0 and "pkg-check ok" in r.stdout, (r.stdout, r.stderr)
     r = subprocess.run([str(exe), str(tmp_path / "missing.gguf")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Failed to load GGUF model" in r.stderr
+
+
+def test_public_cpp_header_depthany_pipeline(tmp_path):
+    """depthany_params / depthany_detect_params / depthany_image_extent / depthany_process_input / depthany_process_output of the
+    public C++ header (reference include/visp/vision.h:236-252) over the C ABI's visp_depthany_get_info, visp_image_scale,
+    visp_image_u8_to_f32 and visp_image_normalize: tests/cpp/pipeline_check.cpp on the north-star configuration."""
+    import subprocess
+    from pathlib import Path
+
+    exe = Path(__file__).resolve().parents[1] / "vision.cpp_amd" / "lib" / "pipeline_check"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    path = synth.write_gguf(tmp_path / "small.gguf", synth.SMALL, seed=0)
+    r = subprocess.run([str(exe), str(path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "pipeline-check ok" in r.stdout, (r.stdout, r.stderr)
 
 
 def test_errors(small, device, tmp_path):

@@ -202,6 +202,27 @@ def test_swin_t_configuration(device, tmp_path):
         assert np.abs(outs[i][0] - want[i]).mean() < 3e-3 * np.abs(want[i]).max(), i
 
 
+def test_swin_t_1024_batch_8(device, tmp_path):
+    """The backbone of configs[3] at full size: swin_t, 1024 x 1024, batch 8 -- maps 256 / 128 / 64 / 32, window 7, so every stage
+    pads its windows and the edge windows carry the shift mask. Batch properties bit for bit, one image against the oracle."""
+    cfg = synth.SWIN_T
+    enc, om, P = _load(device, tmp_path, cfg, 2)
+    imgs = synth.images(8, 1024, 1024, seed=31)
+    imgs[6] = imgs[0]
+    outs = enc.encode_batch(imgs)
+    assert [o.shape for o in outs] == [(8, 256, 256, 96), (8, 128, 128, 192), (8, 64, 64, 384), (8, 32, 32, 768)]
+    for o in outs:
+        assert np.isfinite(o).all()
+        np.testing.assert_array_equal(o[6], o[0])
+    one = enc.encode_batch(imgs[3:4])
+    for i in range(4):
+        np.testing.assert_array_equal(one[i][0], outs[i][3])
+    want = oracle.swin_encode(om, P, _pre(imgs[3]))
+    for i in range(4):
+        assert rel_err(outs[i][3], want[i]) < 2e-2, i
+        assert np.abs(outs[i][3] - want[i]).mean() < 3e-3 * np.abs(want[i]).max(), i
+
+
 def test_swin_errors(device, tmp_path):
     cfg = synth.SWIN_MINI
     path = synth.write_swin_gguf(tmp_path / "m.gguf", cfg, seed=1)

@@ -260,6 +260,31 @@ def test_encoder_batch_16(sam):
     assert np.array_equal(m.sam_encode_batch(imgs[5:6])[0], got[5])
 
 
+def test_encoder_batch_128_properties(sam):
+    """BASELINE.json configs[4]'s per-GPU share (a 1k-image batch over 8 GPUs = 128 images of 1024 x 1024 per step, the bench's
+    batch): size-independent properties -- finite, duplicated images give duplicated embeddings, any image alone gives the same
+    bits as inside the batch -- and two images against the f32 oracle. (fp8 weights: not built, tests/test_fp8_decision.py.)"""
+    from visioncpp_amd import synth
+    m = sam["model"]
+    base = synth.images(16, 1024, 1024, seed=128)
+    imgs = np.concatenate([base] * 8)  # 128 images, 403 MB of u8
+    for k in range(1, 8):              # make the copies distinct images: a different constant offset per group (mod 256)
+        imgs[16 * k:16 * (k + 1)] += np.uint8(17 * k)
+    imgs[77] = imgs[5]
+    got = m.sam_encode_batch(imgs)
+    assert got.shape == (128, 64, 64, 256) and np.isfinite(got).all()
+    assert np.array_equal(got[77], got[5]) and not np.array_equal(got[21], got[5])
+    for i in (0, 100, 127):
+        assert np.array_equal(m.sam_encode_batch(imgs[i:i + 1])[0], got[i]), i
+    cfg = sam["cfg"]
+    params = O.tinyvit_params(cfg.img_size, cfg.layers())
+    for i in (64, 127):
+        x = (imgs[i].astype(np.float32) / np.float32(255.0) - MEAN) / STD
+        want = O.tinyvit_encode(sam["om"], params, x)
+        err = np.abs(got[i] - want.reshape(got[i].shape))
+        assert err.mean() < 6e-3 and err.max() < 0.1, (i, err.mean(), err.max())
+
+
 def test_sam_encode_pads_by_edge_replication(sam):
     """sam_process_input (mobile-sam.cpp:533-547): longest side already 1024 -> no resize, the square is filled with
     clamped source coordinates. Also exercises the bgra channel map."""

@@ -94,14 +94,14 @@ C_API_SYMBOLS = [
     "visp_depthany_get_info", "visp_depthany_image_extent", "visp_depthany_reserve",
     "visp_depthany_compute_batch_device", "visp_depthany_compute_batch_host", "visp_depthany_compute_f32", "visp_depthany_compute_sharded", "visp_depthany_use_graph", "visp_depthany_set_schedule",
     "visp_depthany_pipeline_create", "visp_depthany_pipeline_destroy", "visp_depthany_pipeline_input", "visp_depthany_pipeline_submit", "visp_depthany_pipeline_wait",
-    "visp_depthany_enable_captures", "visp_depthany_read_capture", "visp_depthany_enable_timing",
+    "visp_depthany_set_split", "visp_depthany_enable_captures", "visp_depthany_read_capture", "visp_depthany_enable_timing",
     "visp_depthany_read_timing",
     "visp_esrgan_get_info", "visp_esrgan_set_tile_group", "visp_esrgan_weights_arena", "visp_esrgan_weights_ready",
     "visp_esrgan_tile_layout", "visp_esrgan_compute_batch_device", "visp_esrgan_compute_batch_host",
     "visp_esrgan_generate_host", "visp_esrgan_enable_timing", "visp_esrgan_read_timing",
     "visp_sam_encode", "visp_sam_read_embedding", "visp_sam_encode_batch_device", "visp_sam_encode_batch_host",
     "visp_sam_weights_arena", "visp_sam_weights_ready", "visp_sam_enable_timing", "visp_sam_read_timing",
-    "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks", "visp_image_scale", "visp_gguf_validate",
+    "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks", "visp_image_scale", "visp_image_u8_to_f32", "visp_image_normalize", "visp_gguf_validate",
     "visp_birefnet_image_extent", "visp_birefnet_compute_batch_device", "visp_birefnet_compute_batch_host",
     "visp_swin_load", "visp_swin_output_dims", "visp_swin_encode_batch_device", "visp_swin_encode_batch_host", "visp_swin_enable_captures",
     "visp_swin_read_capture", "visp_swin_enable_timing", "visp_swin_read_timing", "visp_swin_set_mask_mode",
@@ -212,10 +212,13 @@ def init() -> ctypes.CDLL:
     lib.visp_swin_encode_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
     lib.visp_swin_enable_captures.argtypes = [c_void_p, c_int32]
     lib.visp_swin_set_mask_mode.argtypes = [c_void_p, c_int32]
+    lib.visp_depthany_set_split.argtypes = [c_void_p, c_int32]
     lib.visp_swin_read_capture.argtypes = [c_void_p, c_char_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]
     lib.visp_swin_enable_timing.argtypes = [c_void_p, c_int32]
     lib.visp_swin_read_timing.argtypes = [c_void_p, POINTER(Timing), c_int32, POINTER(c_int32)]
     lib.visp_image_scale.argtypes = [POINTER(ImageView), c_int32, c_int32, POINTER(ImageView), POINTER(c_void_p)]
+    lib.visp_image_u8_to_f32.argtypes = [POINTER(ImageView), c_int32, POINTER(c_float), POINTER(c_float), POINTER(ImageView), POINTER(c_void_p)]
+    lib.visp_image_normalize.argtypes = [POINTER(ImageView), c_float, c_float, POINTER(ImageView), POINTER(c_void_p)]
     for name in C_API_SYMBOLS[15:]:
         getattr(lib, name).restype = c_int32
     lib.visp_depthany_pipeline_destroy.restype = None

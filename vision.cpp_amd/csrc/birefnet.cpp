@@ -452,17 +452,21 @@ image_data birefnet_compute(birefnet_model& m, image_view image) { // vision.cpp
         throw except("birefnet: unsupported input image format [%d], expected an 8-bit colour image", int(image.format));
     const i32x2 res = birefnet_image_extent(image.extent, m.bparams);
     m.bparams.image_extent = res;
+    // birefnet_process_input (birefnet.cpp:262-266) happens in the caller's format -- for rgba / bgra / argb stb resizes alpha-weighted (premultiplied),
+    // so colours next to transparent pixels differ from a resize of the opaque rgb -- and the alpha channel is dropped afterwards
+    // (image_u8_to_f32 to rgb_f32 in the reference)
+    const i32x2 caller_extent = image.extent;
+    image_data resized;
+    if (image.extent != res) {
+        resized = image_scale(image, res);
+        image = view_of(resized);
+    }
     image_data rgb = image_to_rgb_u8(image);
     image_view rgb_view = view_of(rgb);
-    image_data resized;
-    if (image.extent != res) { // birefnet_process_input (birefnet.cpp:262-266)
-        resized = image_scale(rgb_view, res);
-        rgb_view = view_of(resized);
-    }
     image_data mask = image_alloc(res, image_format::alpha_f32);
     birefnet_compute_batch_host(m, static_cast<const uint8_t*>(rgb_view.data), 1, res[0], res[1], reinterpret_cast<float*>(mask.data.get()));
-    if (res != image.extent) { // birefnet_process_output (birefnet.cpp:272-281)
-        image_data scaled = image_scale(view_of(mask), image.extent);
+    if (res != caller_extent) { // birefnet_process_output (birefnet.cpp:272-281)
+        image_data scaled = image_scale(view_of(mask), caller_extent);
         return image_f32_to_u8(view_of(scaled), image_format::alpha_u8);
     }
     return image_f32_to_u8(view_of(mask), image_format::alpha_u8);

@@ -142,6 +142,26 @@ int32_t visp_image_scale(visp_image_view const* src, int32_t width, int32_t heig
     });
 }
 
+int32_t visp_image_u8_to_f32(visp_image_view const* src, int32_t format, float const offset[4], float const scale[4], visp_image_view* out_image,
+                             visp_image_data** out_data) {
+    return handle_errors([&]() {
+        if (!src || !src->data || !offset || !scale || !out_image || !out_data) throw except("visp_image_u8_to_f32: null argument");
+        if (src->format < 0 || src->format > int32_t(image_format::alpha_f32) || format < 0 || format > int32_t(image_format::alpha_f32))
+            throw except("Unsupported image format [%d]", src->format);
+        image_view v{i32x2{{src->width, src->height}}, src->stride, image_format(src->format), src->data};
+        return_image(image_u8_to_f32(v, image_format(format), offset, scale), out_image, out_data);
+    });
+}
+
+int32_t visp_image_normalize(visp_image_view const* src, float min, float max, visp_image_view* out_image, visp_image_data** out_data) {
+    return handle_errors([&]() {
+        if (!src || !src->data || !out_image || !out_data) throw except("visp_image_normalize: null argument");
+        if (src->format != int32_t(image_format::alpha_f32)) throw except("visp_image_normalize: expected an alpha_f32 image, got format %d", src->format);
+        image_view v{i32x2{{src->width, src->height}}, src->stride, image_format(src->format), src->data};
+        return_image(image_normalize(v, min, max), out_image, out_data);
+    });
+}
+
 int32_t visp_backend_load_all(char const*) { return 1; } // single built-in backend, nothing to load
 
 int32_t visp_device_init(int32_t type, visp_device** out_device) {
@@ -394,6 +414,18 @@ int32_t visp_depthany_set_schedule(visp_model* m, int32_t schedule) {
     });
 }
 
+int32_t visp_depthany_set_split(visp_model* m, int32_t n) {
+    return handle_errors([&]() {
+        depthany_model& dm = as_depthany(m);
+        if (n < 0 || n > 4) throw except("visp_depthany_set_split: %d sub-batches (0 = automatic, 1 = none, at most 4)", n);
+        dm.split = n;
+        if (dm.ws.graph_exec) { // the captured launch sequence has the other split
+            vx_graph_destroy(dm.ws.graph_exec);
+            dm.ws.graph_exec = nullptr;
+        }
+    });
+}
+
 int32_t visp_depthany_enable_captures(visp_model* m, int32_t enable) {
     return handle_errors([&]() { as_depthany(m).captures = enable != 0; });
 }
@@ -407,7 +439,8 @@ int32_t visp_depthany_read_capture(visp_model* m, char const* name, float* host_
 }
 
 int32_t visp_depthany_enable_timing(visp_model* m, int32_t enable) {
-    return handle_errors([&]() { as_depthany(m).timing = enable != 0; });
+    // 1 = the whole batch on one stream; 2 = the step's own launch shapes (sub-batches on parallel streams, every launch timed on its stream)
+    return handle_errors([&]() { as_depthany(m).timing = enable != 0; as_depthany(m).timing_split = enable == 2; });
 }
 
 int32_t visp_depthany_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n) {

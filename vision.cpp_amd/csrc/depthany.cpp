@@ -651,6 +651,7 @@ struct exec_ctx {
         std::map<std::string, timing_entry> by;
         std::vector<std::string> order;
         for (size_t i = 0; i + 1 < marks.size(); ++i) {
+            if (marks[i].first.rfind("__end", 0) == 0) continue; // the last launch of a sub-batch ends at its stream's end mark, recorded next
             float ms = 0;
             VX(vx_event_elapsed_ms(marks[i].second, marks[i + 1].second, &ms));
             auto it = by.find(marks[i].first);
@@ -809,6 +810,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     // offset into the same workspace; VISP_SPLIT=n runs n sub-batches on parallel streams (captured as parallel branches of
     // the hipGraph) so that kernels with different bottlenecks -- HBM-bound LayerNorms, VALU-bound attention, MFMA/LDS-bound
     // GEMMs -- of different sub-batches overlap.
+    bool in_split = false; // set while the sub-batches of a split step are being scheduled
     auto run_sub = [&](int b0, int nb, void* strm) {
     const int B = nb;
     const long M = (long)nb * T, MP = (long)nb * Pn;
@@ -981,7 +983,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     // Measured (3 interleaved A/B rounds, batch 32): forking is 1-3 % SLOWER than the single stream (8.08-8.30 vs
     // 8.00 ms per step), so it stays opt-in (VISP_FORK_NECK=1) as a documented negative result.
     static const bool fork_enabled = getenv("VISP_FORK_NECK") != nullptr;
-    const bool fork = !m.timing && !m.captures && fork_enabled;
+    const bool fork = !m.timing && !m.captures && fork_enabled && !in_split; // (the sub-batch split uses the same streams and events)
     if (fork) {
         VX(vx_event_record(m.fork_event, stream));
         for (int j = 0; j < 3; ++j) VX(vx_stream_wait_event(m.aux_stream[j], m.fork_event));
@@ -1124,17 +1126,19 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     {
         // measured at batch 32 (profiles/r02_split_streams.txt): 7.70 / 7.24 / 7.21 / 7.33 ms per step for 1 / 2 / 3 / 4 sub-batches (GEMM schedule)
         static const int split_env = getenv("VISP_SPLIT") ? atoi(getenv("VISP_SPLIT")) : 0;
-        const int want = split_env > 0 ? split_env : (B >= 24 ? 3 : (B >= 8 ? 2 : 1));
-        const int n_split = (!m.timing && !m.captures && want > 1 && want <= 4 && B >= 2 * want) ? want : 1;
+        const int want = m.split > 0 ? m.split : (split_env > 0 ? split_env : (B >= 24 ? 3 : (B >= 8 ? 2 : 1)));
+        const int n_split = ((!m.timing || m.timing_split) && !m.captures && want > 1 && want <= 4 && B >= 2 * want) ? want : 1;
         if (n_split == 1) {
             run_sub(0, B, stream);
         } else {
+            in_split = true;
             VX(vx_event_record(m.fork_event, stream));
             for (int j = 0; j < n_split; ++j) {
                 const int b0 = (int)((long)B * j / n_split), b1 = (int)((long)B * (j + 1) / n_split);
                 void* strm = j == 0 ? stream : m.aux_stream[j - 1];
                 if (j > 0) VX(vx_stream_wait_event(strm, m.fork_event));
                 run_sub(b0, b1 - b0, strm);
+                if (m.timing) c.mark("__end", 0, 0, 0); // (c.stream is this sub-batch's stream)
                 if (j > 0) {
                     VX(vx_event_record(m.join_event[j - 1], strm));
                     VX(vx_stream_wait_event(stream, m.join_event[j - 1]));
@@ -1267,6 +1271,13 @@ int depthany_pipeline_submit(depthany_pipeline& p, uint8_t const* rgb) {
     const size_t e = (size_t)(p.n_submitted++ % (long)p.exec.size()); // consecutive batches alternate executors
     depthany_model& em = *p.exec[e];
     em.use_graph = m.use_graph;
+    if (em.schedule != m.schedule) { // visp_depthany_set_schedule on the model after the pipeline was made: the executors follow it,
+        em.schedule = m.schedule;    // and a launch sequence captured for the other schedule is dropped
+        if (em.ws.graph_exec) {
+            vx_graph_destroy(em.ws.graph_exec);
+            em.ws.graph_exec = nullptr;
+        }
+    }
     if (em.ws.B != p.batch || em.ws.W != p.w || em.ws.H != p.h) depthany_reserve(em, p.batch, p.w, p.h);
     if (rgb && rgb != s.pin_in) memcpy(s.pin_in, rgb, p.in_bytes);
     void* cs = p.compute_stream[e];
@@ -1299,17 +1310,21 @@ image_data depthany_compute(depthany_model& m, image_view image) {
         throw except("depthany: unsupported input image format [%d], expected an 8-bit colour image", int(image.format));
     i32x2 res = depthany_image_extent(image.extent, m.params);
     m.params.image_extent = res;
+    // depthany_process_input: image_scale to the model extent happens in the caller's format -- for rgba / bgra / argb stb resizes alpha-weighted (premultiplied),
+    // so colours next to transparent pixels differ from a resize of the opaque rgb -- and the alpha channel is dropped afterwards
+    // (image_u8_to_f32 to rgb_f32 in the reference)
+    const i32x2 caller_extent = image.extent;
+    image_data resized;
+    if (image.extent != res) {
+        resized = image_scale(image, res);
+        image = view_of(resized);
+    }
     image_data rgb = image_to_rgb_u8(image);
     image_view rgb_view = view_of(rgb);
-    image_data resized;
-    if (image.extent != res) { // depthany_process_input: image_scale to the model extent
-        resized = image_scale(rgb_view, res);
-        rgb_view = view_of(resized);
-    }
     image_data out = image_alloc(res, image_format::alpha_f32);
     depthany_compute_batch_host(m, static_cast<const uint8_t*>(rgb_view.data), 1, res[0], res[1],
                                 reinterpret_cast<float*>(out.data.get()), nullptr);
-    if (res != image.extent) return image_scale(view_of(out), image.extent); // depthany_process_output
+    if (res != caller_extent) return image_scale(view_of(out), caller_extent); // depthany_process_output
     return out;
 }
 

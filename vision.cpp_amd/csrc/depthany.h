@@ -118,6 +118,8 @@ struct depthany_model : model_base { // vision.h:339-347 counterpart
     bool weights_uploaded = false;
     depthany_workspace ws;
     bool use_graph = false, captures = false, timing = false;
+    int split = 0; // sub-batches of a step on parallel streams: 0 = automatic (3 from batch 24, 2 from batch 8; $VISP_SPLIT overrides), 1 = none, 2..4
+    bool timing_split = false; // with timing: keep the step's sub-batch split (launches timed per stream while the other streams run)
     int schedule = -1; // encoder schedule: -1 auto (block kernel where the model has its shape), 0 GEMM launches, 1 block kernel
     std::map<std::string, capture_entry> capture_bufs;
     std::vector<timing_entry> last_timing;

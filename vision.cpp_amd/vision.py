@@ -155,6 +155,10 @@ class Model:
         head dim 64, otherwise GEMM launches); 0 = GEMM launches per op group; 1 = block kernel per layer."""
         check(self._api.visp_depthany_set_schedule(self._handle, int(schedule)))
 
+    def set_split(self, n: int):
+        """Sub-batches of one step on parallel streams: 0 = automatic, 1 = none, up to 4 (bit-identical results)."""
+        check(self._api.visp_depthany_set_split(self._handle, int(n)))
+
     def compute_batch(self, images: np.ndarray, return_raw: bool = False):
         """images: uint8 [B, h, w, 3] on the host -> float32 [B, h, w] in [0, 1]."""
         imgs = np.ascontiguousarray(images, dtype=np.uint8)
