@@ -314,3 +314,76 @@ def test_gguf_tensor_infos_are_validated(tmp_path):
     trunc = tmp_path / "trunc.gguf"
     trunc.write_bytes(bytes(raw[:-8]))
     assert api.visp_gguf_validate(str(trunc).encode(), None) == 0 and b"out of bounds" in api.visp_get_last_error()
+
+
+def test_image_scale_upsample_against_an_independent_f64_evaluation():
+    """The enlarging branch of image_scale -- what every input that is not at the model extent takes (640 x 480 -> 700 x 518) -- has no
+    vector in the reference's tests (tests/test-image.cpp:186-203 is a 2:1 Mitchell reduction). stb_image_resize v0.9x, which
+    the reference fetches, enlarges with Catmull-Rom: written out here from the library's published definition in float64 and
+    numpy, independently of csrc/image_resize.cpp and of oracle.image_scale:
+      * output pixel i has its centre at (i + 0.5) / scale in source coordinates; source pixels n with centre n + 0.5 inside the
+        +-2 support contribute k(distance), first = floor(lower + 0.5), last = floor(upper - 0.5), coefficients scaled to sum 1;
+      * k(x) = 1 - x^2 (2.5 - 1.5 x) for x < 1, 2 - x (4 + x (0.5 x - 2.5)) for x < 2;  * reads beyond the image clamp to the edge;
+      * u8 colour is filtered in linear light (sRGB decode / encode), alpha and float images as they are; alpha-weighted when the
+        format has an alpha channel.
+    u8 results may differ by one level where the float pipeline's rounding and stb's table-based sRGB encoder land on the other
+    side of a boundary; f32 images must agree to float rounding."""
+    import numpy as np
+
+    from visioncpp_amd import vision
+
+    def kern(x):
+        x = np.abs(x)
+        return np.where(x < 1, 1 - x * x * (2.5 - 1.5 * x), np.where(x < 2, 2 - x * (4 + x * (0.5 * x - 2.5)), 0.0))
+
+    def weights(n_in, n_out):
+        scale = n_out / n_in
+        Wm = np.zeros((n_out, n_in))
+        for i in range(n_out):
+            c = (i + 0.5) / scale
+            lo, hi = (i + 0.5 - 2 * scale) / scale, (i + 0.5 + 2 * scale) / scale
+            first, last = int(np.floor(lo + 0.5)), int(np.floor(hi - 0.5))
+            ns = np.arange(first, last + 1)
+            k = kern(c - (ns + 0.5))
+            k = k / k.sum()
+            for n, kv in zip(ns, k):
+                Wm[i, min(max(n, 0), n_in - 1)] += kv  # edge clamp
+        return Wm
+
+    def resize(a, oh, ow):  # a [h, w, c] float64
+        return np.einsum("yh,hwc->ywc", weights(a.shape[0], oh), np.einsum("xw,hwc->hxc", weights(a.shape[1], ow), a))
+
+    def to_linear(u):
+        c = u / 255.0
+        return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+    def to_srgb(l):
+        l = np.clip(l, 0.0, 1.0)
+        return np.where(l <= 0.0031308, l * 12.92, 1.055 * l ** (1 / 2.4) - 0.055) * 255.0
+
+    rng = np.random.default_rng(42)
+    F = vision.ImageFormat
+    for (h, w, oh, ow) in ((48, 64, 52, 70), (9, 7, 31, 40), (30, 20, 33, 23)):  # (an axis at scale exactly 1 takes stb's reducing filter)
+        # smooth content (a resize of noise mostly measures the encoder's boundaries), full range
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([127 + 120 * np.sin(xx / 3.1 + c) * np.cos(yy / 4.3 - c) for c in range(3)], -1)
+        rgb = np.clip(base + rng.normal(0, 6, base.shape), 0, 255).astype(np.uint8)
+        got = vision.image_scale(rgb, ow, oh, F.rgb_u8).astype(np.int32)
+        want = to_srgb(resize(to_linear(rgb.astype(np.float64)), oh, ow))
+        d = np.abs(got - np.rint(want))
+        assert d.max() <= 1 and d.mean() < 0.03, (h, w, d.max(), d.mean())
+        # float images: no colour space, plain filter
+        f = rng.random((h, w, 3)).astype(np.float32)
+        gotf = vision.image_scale(f, ow, oh, F.rgb_f32)
+        assert np.abs(gotf - resize(f.astype(np.float64), oh, ow)).max() < 2e-5
+        # rgba: colour premultiplied by alpha in linear light, filtered, divided back; alpha itself linear
+        al = np.clip(128 + 100 * np.sin(xx / 5.0) + rng.normal(0, 5, (h, w)), 1, 255).astype(np.uint8)
+        rgba = np.concatenate([rgb, al[..., None]], -1)
+        gota = vision.image_scale(rgba, ow, oh, F.rgba_u8).astype(np.int32)
+        a_lin = al.astype(np.float64)[..., None] / 255.0
+        pm = resize(to_linear(rgb.astype(np.float64)) * a_lin, oh, ow)
+        a_out = resize(a_lin, oh, ow)
+        col = to_srgb(pm / np.maximum(a_out, 1e-12))
+        da = np.abs(gota[..., 3] - np.rint(np.clip(a_out[..., 0], 0, 1) * 255.0))
+        dc = np.abs(gota[..., :3] - np.rint(col))[a_out[..., 0] > 0.05]
+        assert da.max() <= 1 and dc.max() <= 2 and dc.mean() < 0.06, (da.max(), dc.max(), dc.mean())

@@ -151,6 +151,84 @@ def test_block_vs_oracle(block_fn, M, T, mlp, tap, qkv):
             assert rel_err(got, want[name]) < 4e-3, name
 
 
+def _run_block(block_fn, w, x0, att, T, q_scale=0.125, eps=1e-6):
+    M = x0.shape[0]
+    d_mlp, d_qkv, v_mlp, v_qkv, v_tap = pack(w, block_fn)
+    xd, attd = dev(x0), dev(att.astype(np.float16))
+    cap, feat = empty(M * D * 4), empty(M * D * 2)
+    q, k, v = (empty(M * D * 2) for _ in range(3))
+    a = L.DinoBlockArgs()
+    a.x, a.M, a.T, a.H, a.q_scale, a.eps = xd.ptr, M, T, H, q_scale, eps
+    a.att, a.w_mlp, a.vec_mlp, a.cap_x1 = attd.ptr, d_mlp.ptr, v_mlp.ptr, cap.ptr
+    a.feat, a.vec_tap = feat.ptr, v_tap.ptr
+    a.q, a.k, a.v, a.w_qkv, a.vec_qkv = q.ptr, k.ptr, v.ptr, d_qkv.ptr, v_qkv.ptr
+    L.vx_check(block_fn(C.byref(a), None))
+    sync()
+    B = M // T
+    return dict(x=xd.to_numpy(np.float32, (M, D)), x1=cap.to_numpy(np.float32, (M, D)), feat=feat.to_numpy(np.float16, (M, D)).astype(np.float32),
+                q=q.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32), k=k.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32),
+                v=v.to_numpy(np.float16, (B, H, T, 64)).astype(np.float32))
+
+
+def test_block_layerscale_spread(block_fn):
+    """Trained DINOv2 LayerScale vectors span orders of magnitude (init 1e-5 .. 1; the synthetic files use 0.1 +- 0.01). The 16-token
+    form folds lambda into f16-rounded weights (Wo' = f16(f16(Wo) lambda1), W2' likewise, csrc/depthany.cpp), so channels with a tiny
+    lambda sit in f16's subnormal range and channels with a large one scale their rounding error up: lambda log-uniform in
+    [1e-5, 4] per channel plus outliers at 1e-7, 8 and exactly 0, against the f32 oracle with the bounds of test_block_vs_oracle
+    (errors relative to the largest magnitude of the tensor: a channel's folded rounding error is 2^-11 of ITS contribution)."""
+    rng = np.random.default_rng(99)
+    M, T = 384, 64
+    w = make_weights(31)
+    for name in ("lam1", "lam2"):
+        lam = np.exp(rng.uniform(np.log(1e-5), np.log(4.0), D)).astype(np.float32)
+        lam[[3, 77, 200]] = [1e-7, 8.0, 0.0]
+        lam[rng.integers(0, D, 20)] *= -1.0  # (signs occur in trained vectors too)
+        w[name] = lam
+    x0 = (rng.standard_normal((M, D)) * 1.5).astype(np.float32)
+    att = _h(rng.standard_normal((M, D)).astype(np.float32))
+    want = reference(w, x0, att, 1e-6, True, True, True, T, 0.125)
+    got = _run_block(block_fn, w, x0, att, T)
+    for n in got:
+        assert np.isfinite(got[n]).all(), n
+    assert rel_err(got["x1"], want["x1"]) < 1e-3 and rel_err(got["x"], want["x"]) < 1e-3
+    # per channel too: a channel with a small lambda must not inherit the error scale of the large ones. Its folded weights are f16
+    # subnormals (W lambda ~ 5e-6 at lambda = 1e-4: about 1 % precision each, NOT flushed by the MFMA), so its branch contribution
+    # (~3e-4) carries ~2 % error = 7e-6 absolute on a residual stream of magnitude ~5: floor 2e-5, two orders below the 2^-11
+    # operand rounding of the ordinary channels' contributions
+    err = np.abs(got["x"] - want["x"]).max(axis=0)
+    scale = np.abs(want["x"] - x0).max(axis=0)
+    bad = np.nonzero(~(err < 4e-3 * scale + 2e-5))[0]
+    assert bad.size == 0, [(int(c), float(err[c]), float(scale[c]), float(w['lam1'][c]), float(w['lam2'][c])) for c in bad[:8]]
+    assert rel_err(got["feat"], want["feat"]) < 2e-3
+    for n in "qkv":
+        assert rel_err(got[n], want[n]) < 4e-3, n
+
+
+def test_block_large_hidden_preactivations(block_fn):
+    """The 16-token form evaluates GELU on packed f16 (v_pk_*_f16, v_exp_f16, v_rcp_f16): x^2 overflows f16 beyond |x| = 255 and x
+    itself beyond 65504. Hidden units whose pre-activation sits at +-300, at -7e4 (f16: -inf before the clamp; gelu = 0) and rows
+    of moderately large values must come out as the f32 oracle's GELU rounded to f16. (+7e4 is +inf in any f16 hidden map, here as in
+    the GEMM schedule's f16 store: not representable, not tested.)"""
+    rng = np.random.default_rng(7)
+    M, T = 256, 64
+    w = make_weights(41)
+    big = {5: 300.0, 6: -300.0, 700: -7.0e4, 701: 260.0, 1535: -1000.0, 1000: 250.0}
+    for j, v in big.items():
+        w["b1"][j] = v
+    w["w1"][[5, 6, 700, 701, 1535]] *= 0.0  # these units' pre-activation is their bias exactly
+    w["w1"][100:140] *= 40.0                # and forty units swing through +-100 with the input
+    x0 = (rng.standard_normal((M, D)) * 1.5).astype(np.float32)
+    att = _h(rng.standard_normal((M, D)).astype(np.float32))
+    want = reference(w, x0, att, 1e-6, True, True, True, T, 0.125)
+    got = _run_block(block_fn, w, x0, att, T)
+    for n in got:
+        assert np.isfinite(got[n]).all(), n
+    assert rel_err(got["x"], want["x"]) < 1.5e-3
+    assert rel_err(got["feat"], want["feat"]) < 3e-3
+    for n in "qkv":
+        assert rel_err(got[n], want[n]) < 5e-3, n
+
+
 def test_block_rows_are_independent(block_fn):
     """A row's results do not depend on which workgroup / wave / lane processes it: the same rows placed at another
     offset of a larger problem give bit-identical outputs (the property the batch sharding relies on)."""

@@ -349,24 +349,28 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         };
         // GELU spread over the step, on PACKED f16 pairs (v_pk_mul / v_pk_fma / v_pk_add, v_exp_f16, v_rcp_f16): the result is an f16
         // MFMA operand anyway, and the wave's issue slots are what the MLP loop runs out of. Pair q = elements 2q, 2q+1 in slots
-        // 12q .. 12q+9. (GELU_F32: the f32 form, 6 slots per element, kept for A/B builds.)
+        // 12q .. 12q+10. (GELU_F32: the f32 form, 6 slots per element, kept for A/B builds.)
 #ifndef VISP_BLOCK16_GELU_F32
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2 gp[4], ga[4], ge[4];
-        const h2 hc1 = {(f16)c1, (f16)c1}, hc3 = {(f16)c3, (f16)c3}, one = {(f16)1.0f, (f16)1.0f};
+        const h2 hc1 = {(f16)c1, (f16)c1}, hc3 = {(f16)c3, (f16)c3}, one = {(f16)1.0f, (f16)1.0f}, lowest = {(f16)-65504.0f, (f16)-65504.0f};
         auto gelu_side = [&](auto ic) __attribute__((always_inline)) {
             constexpr int i = CI(ic), q = i / 12, op = i % 12;
             if constexpr (q < 4 && !(DBG & 32)) {
                 if constexpr (op == 0) { const h2 v = {(f16)hc[q >> 1][2 * (q & 1)], (f16)hc[q >> 1][2 * (q & 1) + 1]}; gp[q] = v; }
-                if constexpr (op == 1) ga[q] = gp[q] * gp[q];
-                if constexpr (op == 2) ga[q] = ga[q] * hc3 + hc1;
-                if constexpr (op == 3) ga[q] = ga[q] * gp[q];
-                if constexpr (op == 4) ge[q][0] = __builtin_exp2f16(ga[q][0]);
-                if constexpr (op == 5) ge[q][1] = __builtin_exp2f16(ga[q][1]);
-                if constexpr (op == 6) ge[q] = ge[q] + one;
-                if constexpr (op == 7) ge[q][0] = __builtin_amdgcn_rcph(ge[q][0]);
-                if constexpr (op == 8) ge[q][1] = __builtin_amdgcn_rcph(ge[q][1]);
-                if constexpr (op == 9) { const h2 y = gp[q] * ge[q]; hbn[2 * q] = y[0]; hbn[2 * q + 1] = y[1]; }
+                // Range: |x| > 255 makes x^2 = inf, which still ends right (x > 0: exp2(-inf) = 0 -> y = x; x < 0: rcp(inf) = 0 -> y = -0).
+                // x < -65504 would convert to -inf and give -inf * 0 = NaN where gelu is 0: clamp the low side (one packed op).
+                // x > 65504 is +inf in any f16 hidden map, here as in the GEMM schedule's f16 store.
+                if constexpr (op == 1) gp[q] = __builtin_elementwise_max(gp[q], lowest);
+                if constexpr (op == 2) ga[q] = gp[q] * gp[q];
+                if constexpr (op == 3) ga[q] = ga[q] * hc3 + hc1;
+                if constexpr (op == 4) ga[q] = ga[q] * gp[q];
+                if constexpr (op == 5) ge[q][0] = __builtin_exp2f16(ga[q][0]);
+                if constexpr (op == 6) ge[q][1] = __builtin_exp2f16(ga[q][1]);
+                if constexpr (op == 7) ge[q] = ge[q] + one;
+                if constexpr (op == 8) ge[q][0] = __builtin_amdgcn_rcph(ge[q][0]);
+                if constexpr (op == 9) ge[q][1] = __builtin_amdgcn_rcph(ge[q][1]);
+                if constexpr (op == 10) { const h2 y = gp[q] * ge[q]; hbn[2 * q] = y[0]; hbn[2 * q + 1] = y[1]; }
             }
         };
 #else
