@@ -310,6 +310,18 @@ def test_sharded_entry_two_models_two_threads(small, device, tmp_path):
     handles = (C.c_void_p * 2)(small._handle, second._handle)
     L.check(L.get_lib().visp_depthany_compute_sharded(handles, 2, imgs.ctypes.data, 5, 518, 518, out.ctypes.data))  # shards 3 + 2
     np.testing.assert_array_equal(out, want)
+    # larger shards go through each model's overlapped host pipeline in chunks of 32 (pinned staging, three streams, hipGraph replay):
+    # 90 images -> shards of 45 = one full chunk + a partial one run as a full step; same bits as the blocking entry
+    base = synth.images(10, 518, 518, seed=34)
+    many = np.concatenate([base] * 9)
+    for k in range(1, 9):
+        many[10 * k:10 * (k + 1)] += np.uint8(29 * k)  # distinct images
+    out_many = np.empty((90, 518, 518), np.float32)
+    L.check(L.get_lib().visp_depthany_compute_sharded(handles, 2, many.ctypes.data, 90, 518, 518, out_many.ctypes.data))
+    for lo in (0, 30, 60):
+        np.testing.assert_array_equal(out_many[lo:lo + 30], small.compute_batch(many[lo:lo + 30]))
+    L.check(L.get_lib().visp_depthany_compute_sharded(handles, 2, imgs.ctypes.data, 5, 518, 518, out.ctypes.data))  # and small shards after it
+    np.testing.assert_array_equal(out, want)
     same = (C.c_void_p * 2)(small._handle, small._handle)
     with pytest.raises(L.Error, match="passed twice"):
         L.check(L.get_lib().visp_depthany_compute_sharded(same, 2, imgs.ctypes.data, 5, 518, 518, out.ctypes.data))

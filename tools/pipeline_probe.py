@@ -27,6 +27,7 @@ dev = vision.Device.init(vision.Backend.gpu)
 model = vision.Model.load(path, dev, vision.Arch.depth_anything)
 imgs = synth.images(4, W, H, seed=1)
 imgs = np.concatenate([imgs] * 8)[:B]
+print("HIP runtime mapped in this process:", sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln or "libhsa-runtime" in ln}), flush=True)
 model.use_graph(True)
 if "--torch" in sys.argv:  # as bench.py: torch owns the buffers and the stream the graph is captured on
     src = torch.from_numpy(imgs).cuda()
@@ -58,6 +59,13 @@ for slots in (3,):
             tickets.append(pipe.submit(None))
         while tickets:
             pipe.wait(tickets.pop(0), copy=False)
+        if not in_place:  # the host copy alone: pageable numpy batch -> pinned slot
+            v = pipe.input_view()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                v[...] = imgs
+            dt = (time.perf_counter() - t0) / 10
+            print(f"host copy into the pinned slot: {dt * 1e3:.3f} ms per batch = {imgs.nbytes / dt / 1e9:.1f} GB/s", flush=True)
         n = 40
         t0 = time.perf_counter()
         for i in range(n):

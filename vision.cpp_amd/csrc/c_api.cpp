@@ -333,7 +333,8 @@ int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* rgb, int3
 
 // Multi-GPU without Python: one model per device (each loaded on its own visp_hip_device_init(i) device), one host thread per
 // model, contiguous image shards whose sizes differ by at most one (the partitioning of vision.cpp_amd/dist.py::shard_range),
-// no data-path collective -- images are independent units (image_normalize is per image, reference image.cpp:537-576).
+// no data-path collective -- images are independent units (image_normalize is per image, reference image.cpp:537-576). Each shard
+// goes through its model's overlapped host pipeline in chunks of 32 (pinned staging, H2D / forward / D2H on three streams).
 int32_t visp_depthany_compute_sharded(visp_model* const* models, int32_t n_models, uint8_t const* rgb, int32_t batch, int32_t w, int32_t h,
                                       float* out) {
     return handle_errors([&]() {
@@ -353,7 +354,7 @@ int32_t visp_depthany_compute_sharded(visp_model* const* models, int32_t n_model
             if (count == 0) continue;
             threads.emplace_back([&, i, begin, count]() {
                 try {
-                    depthany_compute_batch_host(*ms[(size_t)i], rgb + (size_t)begin * h * w * 3, count, w, h, out + (size_t)begin * h * w, nullptr);
+                    depthany_compute_shard_host(*ms[(size_t)i], rgb + (size_t)begin * h * w * 3, count, w, h, out + (size_t)begin * h * w);
                 } catch (std::exception const& e) {
                     errors[(size_t)i] = e.what();
                 } catch (...) {

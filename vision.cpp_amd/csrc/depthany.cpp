@@ -444,6 +444,8 @@ void depthany_weights_ready(depthany_model& m) {
 }
 
 depthany_model::~depthany_model() {
+    delete shard_pipeline; // (its executor 0 is this model: only the slots, streams and clones go)
+    shard_pipeline = nullptr;
     if (ws.graph_exec) vx_graph_destroy(ws.graph_exec);
     for (void* s : aux_stream) vx_stream_destroy(s);
     vx_event_destroy(fork_event);
@@ -1302,6 +1304,54 @@ float const* depthany_pipeline_wait(depthany_pipeline& p, int ticket) {
     VX(vx_event_sync(s.downloaded));
     s.busy = false;
     return static_cast<float const*>(s.pin_out);
+}
+
+// One shard of visp_depthany_compute_sharded on this model: pageable host images in, pageable results out, through the overlapped
+// pipeline in chunks of the tuned step (32 images; pinned staging, H2D / forward / D2H of consecutive chunks on three streams,
+// hipGraph replay) instead of one blocking pageable round trip. A last partial chunk runs as a full one (the pinned slot's other
+// images are whatever it held: images are independent) -- no second workspace shape, no graph re-capture. Bit-identical to
+// depthany_compute_batch_host.
+void depthany_compute_shard_host(depthany_model& m, uint8_t const* rgb, int count, int w, int h, float* out) {
+    constexpr int chunk = 32;
+    if (count < chunk / 2) { // small shards: nothing to overlap, and a 32-image step for a few images wastes the device
+        depthany_compute_batch_host(m, rgb, count, w, h, out, nullptr);
+        return;
+    }
+    if (!m.shard_pipeline || m.shard_pipeline->w != w || m.shard_pipeline->h != h) {
+        delete m.shard_pipeline;
+        m.shard_pipeline = nullptr;
+        m.shard_pipeline = depthany_pipeline_create(m, chunk, w, h, 3);
+    }
+    depthany_pipeline& p = *m.shard_pipeline;
+    const size_t px = (size_t)w * h;
+    const int n_chunks = (count + chunk - 1) / chunk;
+    const bool graph = m.use_graph;
+    m.use_graph = true;
+    std::vector<std::pair<int, int>> flight; // (ticket, chunk index)
+    auto retire = [&]() {
+        const auto [ticket, k] = flight.front();
+        flight.erase(flight.begin());
+        float const* res = depthany_pipeline_wait(p, ticket);
+        const int n = std::min(chunk, count - k * chunk);
+        memcpy(out + (size_t)k * chunk * px, res, (size_t)n * px * 4);
+    };
+    try {
+        for (int k = 0; k < n_chunks; ++k) {
+            if ((int)flight.size() == p.n_slots) retire();
+            const int n = std::min(chunk, count - k * chunk);
+            uint8_t* pin = depthany_pipeline_input(p);
+            memcpy(pin, rgb + (size_t)k * chunk * px * 3, (size_t)n * px * 3);
+            flight.push_back({depthany_pipeline_submit(p, nullptr), k});
+        }
+        while (!flight.empty()) retire();
+    } catch (...) {
+        m.use_graph = graph;
+        for (auto& f : flight) { // leave no slot busy behind an error
+            try { depthany_pipeline_wait(p, f.first); } catch (...) {}
+        }
+        throw;
+    }
+    m.use_graph = graph;
 }
 
 // reference src/visp/vision.cpp:147-167

@@ -108,6 +108,7 @@ struct model_base {
     explicit model_base(int32_t f) : family(f) {}
 };
 
+struct depthany_pipeline;
 struct depthany_model : model_base { // vision.h:339-347 counterpart
     depthany_model() : model_base(family_depth_anything) {}
     backend_device const* backend = nullptr;
@@ -120,6 +121,7 @@ struct depthany_model : model_base { // vision.h:339-347 counterpart
     bool use_graph = false, captures = false, timing = false;
     int split = 0; // sub-batches of a step on parallel streams: 0 = automatic (3 from batch 24, 2 from batch 8; $VISP_SPLIT overrides), 1 = none, 2..4
     bool timing_split = false; // with timing: keep the step's sub-batch split (launches timed per stream while the other streams run)
+    depthany_pipeline* shard_pipeline = nullptr; // visp_depthany_compute_sharded's overlapped host pipeline for this model (owned, lazily made)
     int schedule = -1; // encoder schedule: -1 auto (block kernel where the model has its shape), 0 GEMM launches, 1 block kernel
     std::map<std::string, capture_entry> capture_bufs;
     std::vector<timing_entry> last_timing;
@@ -176,6 +178,10 @@ uint8_t* depthany_pipeline_input(depthany_pipeline&);
 int depthany_pipeline_submit(depthany_pipeline&, uint8_t const* rgb_or_null); // returns the ticket (= slot index)
 // blocks until that batch is back in pinned host memory; returns it (valid until the slot is submitted again)
 float const* depthany_pipeline_wait(depthany_pipeline&, int ticket);
+
+// one shard of the multi-device entry: pageable host buffers through the overlapped pipeline in chunks of 32 (bit-identical to
+// depthany_compute_batch_host)
+void depthany_compute_shard_host(depthany_model&, uint8_t const* rgb, int count, int w, int h, float* out);
 
 // reference API: any extent, any u8 colour format, batch 1 (vision.cpp:147-167) -> alpha_f32 at the input extent
 image_data depthany_compute(depthany_model&, image_view image);
