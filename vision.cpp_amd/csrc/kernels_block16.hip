@@ -52,6 +52,10 @@ constexpr int V_TOTAL = 6528;
 #ifndef VISP_BLOCK16_DEFER_MLP
 #define VISP_BLOCK16_DEFER_MLP 0
 #endif
+#ifndef VISP_BLOCK16_LN_FENCE
+#define VISP_BLOCK16_LN_FENCE 1
+#endif
+constexpr int LN_FENCE = VISP_BLOCK16_LN_FENCE; // scheduling fence after every LN_FENCE k-blocks of a LayerNorm's fragment pass (0 = none)
 constexpr int PF = VISP_BLOCK16_PF;   // fragment window per stream (A/B builds: tools/block16_diag.sh)
 constexpr int DG = VISP_BLOCK16_DEFER; // groups of a step that run after the next pair's boundary (0: every step opens with its own boundary)
 static_assert(PF % 2 == 0 && FR % PF == 0 && PF - 2 * DG >= 2, "the window must hold the deferred groups and the next step's first group");
@@ -267,11 +271,18 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     };
     // normalised row as B fragments: element j of k-block kb = feature 32 kb + 16 (j >> 2) + 4g + (j & 3) = register j & 3 of tile 2 kb + (j >> 2)
     auto ln_to_frags = [&](const float* gamma, const float* beta) __attribute__((always_inline)) {
+        // The vectors' LDS addresses are known long before the statistics are: left alone, hipcc issues all 48 float4 reads ahead of the
+        // variance pass, runs out of registers and SPILLS THE VALUES IT JUST READ (11 + 12 16-byte scratch stores per launch and lane,
+        // 73 MB of scratch writes per launch at batch 32, profiles/r02_pmc). The pointers are therefore made to depend on rstd
+        // (an empty asm the optimiser cannot see through), again every LN_FENCE k-blocks: the reads stay next to their use.
+        int lo = 4 * g; // (an offset, not a pointer: a pointer that went through the asm would come back generic -> flat loads)
+        if constexpr (LN_FENCE) asm volatile("" : "+v"(lo) : "v"(rstd));
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                const f32x4 gm = vec4(gamma, 2 * kb + t2), bt = vec4(beta, 2 * kb + t2);
+                const float4 gq = *reinterpret_cast<const float4*>(gamma + lo + 16 * (2 * kb + t2)), bq = *reinterpret_cast<const float4*>(beta + lo + 16 * (2 * kb + t2));
+                const float gm[4] = {gq.x, gq.y, gq.z, gq.w}, bt[4] = {bq.x, bq.y, bq.z, bq.w};
                 // as x * (rstd g) + (b - mean rstd g): written as (x - mean) * rstd * g + b, hipcc keeps the 96 differences of the
                 // variance pass alive for this loop (common subexpression) and spills 56 registers around it
 #pragma unroll
@@ -280,6 +291,10 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
                     xb[kb][4 * t2 + j] = (f16)fmaf(acc[2 * kb + t2][j], a, fmaf(-mean, a, bt[j]));
                 }
             }
+            if constexpr (LN_FENCE) {
+                if (kb % LN_FENCE == LN_FENCE - 1 && kb + 1 < KB) asm volatile("" : "+v"(lo) : "v"(xb[kb])); // (the whole fragment: with one element the other seven are sunk past the fence)
+            }
+        }
     };
 
     if constexpr (MLP) {
