@@ -313,7 +313,7 @@ def main():
                                    "avg_launch_ms": round(per_launch_ms, 4), "launches_per_step": dom["launches"]}
             # HBM traffic and MFMA-busy % per launch of that kernel from the PMC passes (rocprofv3 --pmc, one counter set per
             # pass, on tools/bench_block.py --pmc = the same launch shapes; units and corrections in tools/pmc_summary.py)
-            pmc = ROOT / "profiles" / ("r02_pmc" if (ROOT / "profiles" / "r02_pmc" / "traffic.json").exists() else "r01_pmc") / "traffic.json"
+            pmc = next((q for q in (ROOT / "profiles" / d / "traffic.json" for d in ("r03_pmc", "r02_pmc", "r01_pmc")) if q.exists()), ROOT / "profiles" / "none")
             if pmc.exists():
                 ks = json.loads(pmc.read_text())["kernels"]
                 # one entry per launch shape ("block@343wg"): this object describes the unsplit batch-32 launch (the timing pass runs
