@@ -31,6 +31,9 @@
 
 namespace {
 
+#ifndef VISP_ATTN_SEQ
+#define VISP_ATTN_SEQ 1 // A/B builds: 0 lets hipcc overlap the two 32-key blocks of a tile (profiles/r03_attention_ab_fastpath.txt)
+#endif
 constexpr int HD = 64;        // head dim
 constexpr int KV_TILE = 64;   // keys per tile
 constexpr int Q_PER_WAVE = 32;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
             f32x16 s = qk(sk, kb, k0, masked);
 #pragma unroll
             for (int e = 0; e < 16; ++e) pf[2 * kb + (e >> 3)][e & 7] = (f16)__builtin_amdgcn_exp2f(s[e]);
-            __builtin_amdgcn_sched_barrier(0); // keep the blocks in sequence: the register budget is 128 (4 waves per SIMD)
+            if (VISP_ATTN_SEQ) __builtin_amdgcn_sched_barrier(0); // keep the blocks in sequence: the register budget is 128 (4 waves per SIMD)
         }
         f32x16 rs = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
