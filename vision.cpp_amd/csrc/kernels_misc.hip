@@ -108,11 +108,25 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
 }
 
 // ---- pre-processing + patch im2col (reference depth-anything.cpp:130-140, image.cpp:215-226,
-// image-impl.h:23-27, nn.cpp:166-180). One thread writes 8 consecutive k of one patch row.
+// image-impl.h:23-27, nn.cpp:166-180). One thread writes 8 consecutive k of one patch row. The value of an element depends on its byte
+// and its channel only, so the reference's arithmetic -- (u / 255 - mean) * (1 / std), an IEEE division per element -- is evaluated
+// once per (channel, byte) into a 768-entry f16 table in LDS and the kernel is byte loads + table reads (round 3: it was bound by
+// vector issue -- the division sequence and two integer divisions by the runtime patch size per element -- at 1.4 TB/s; PS = 14 is a
+// compile-time constant for the DINOv2 models, 0 = any patch size).
+template <int PS>
 __global__ __launch_bounds__(256) void preprocess_patches_kernel(const uint8_t* __restrict__ rgb, f16* __restrict__ patches,
-                                                                  int H, int W, int ps, int Kp, float m0, float m1,
+                                                                  int H, int W, int ps_rt, int Kp, float m0, float m1,
                                                                   float m2, float s0, float s1, float s2) {
+    __shared__ f16 lut[3 * 256];
+    for (int i = threadIdx.x; i < 768; i += 256) {
+        const int c = i >> 8;
+        const float u = (float)(i & 255);
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), inv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        lut[i] = (f16)((u / 255.0f - mean) * inv);
+    }
+    __syncthreads();
     // grid: (ceil(P*chunks / 256), B); thread = 8 consecutive k of one patch row, 32-bit index math
+    const int ps = PS ? PS : ps_rt;
     const int chunks = Kp >> 3;
     const int pw = W / ps, ph = H / ps;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -121,21 +135,18 @@ __global__ __launch_bounds__(256) void preprocess_patches_kernel(const uint8_t* 
     const int py = prow / pw, px = prow - py * pw;
     const int b = blockIdx.y;
     const int kreal = ps * ps * 3;
-    const uint8_t* img = rgb + (long)b * H * W * 3;
+    const uint8_t* img = rgb + (long)b * H * W * 3 + ((long)py * ps * W + px * ps) * 3;
     f16x8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = ch * 8 + j;
-        float v = 0.0f;
+        f16 v = (f16)0.0f;
         if (k < kreal) {
-            const int kk = k / 3, c = k - kk * 3;
-            const int ky = kk / ps, kx = kk - ky * ps;
-            const float u = (float)img[((py * ps + ky) * W + px * ps + kx) * 3 + c];
-            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
-            const float inv = c == 0 ? s0 : (c == 1 ? s1 : s2);
-            v = (u / 255.0f - mean) * inv;
+            const int ky = k / (ps * 3), r = k - ky * (ps * 3); // r = kx * 3 + c: contiguous bytes of one image row
+            const int c = r % 3;
+            v = lut[c * 256 + img[ky * W * 3 + r]];
         }
-        out[j] = (f16)v;
+        out[j] = v;
     }
     *reinterpret_cast<f16x8*>(patches + ((long)b * pw * ph + prow) * Kp + ch * 8) = out;
 }
@@ -317,9 +328,12 @@ int vx_preprocess_patches(const uint8_t* rgb, void* patches, int B, int H, int W
     VX_REQUIRE(H % ps == 0 && W % ps == 0, "vx_preprocess_patches: %dx%d not a multiple of patch size %d", W, H, ps);
     VX_REQUIRE(Kp % 8 == 0 && Kp >= ps * ps * 3, "vx_preprocess_patches: bad Kp=%d", Kp);
     const int per_image = (H / ps) * (W / ps) * (Kp / 8);
-    hipLaunchKernelGGL(preprocess_patches_kernel, dim3((per_image + 255) / 256, B), dim3(256), 0, as_stream(stream), rgb,
-                       reinterpret_cast<f16*>(patches), H, W, ps, Kp, mean[0], mean[1], mean[2], inv_std[0], inv_std[1],
-                       inv_std[2]);
+    if (ps == 14)
+        hipLaunchKernelGGL(preprocess_patches_kernel<14>, dim3((per_image + 255) / 256, B), dim3(256), 0, as_stream(stream), rgb,
+                           reinterpret_cast<f16*>(patches), H, W, ps, Kp, mean[0], mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    else
+        hipLaunchKernelGGL(preprocess_patches_kernel<0>, dim3((per_image + 255) / 256, B), dim3(256), 0, as_stream(stream), rgb,
+                           reinterpret_cast<f16*>(patches), H, W, ps, Kp, mean[0], mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
     VX_LAUNCH_CHECK();
     return 1;
 }
