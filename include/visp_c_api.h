@@ -235,6 +235,55 @@ VISP_API int32_t visp_swin_read_capture(visp_model* m, char const* name, float* 
 VISP_API int32_t visp_swin_enable_timing(visp_model* m, int32_t enable);
 VISP_API int32_t visp_swin_read_timing(visp_model* m, visp_timing* out, int32_t cap, int32_t* n);
 
+/* ---- graph layer: the executor boundary the reference's arch code is written against -----------------------------------------------------------
+ * replaces include/visp/ml.h:154-256 (compute_graph, compute_graph_init / _allocate, compute, model_ref::weights / find, compute_graph_input /
+ * _output, transfer_to_backend / transfer_from_backend) and the builders of src/visp/nn.h + ml.cpp:746-788, which the reference implements on
+ * ggml (ggml_new_tensor / ggml_mul_mat / ggml_add / ... / ggml_gallocr / ggml_backend_graph_compute). A tensor handle is an index into its
+ * graph (>= 0); shapes are ggml's ne order (ne[0] contiguous). include/visp/ml.h is the C++ face of these entries (model_ref, tensor, the
+ * nn.h builder names). One generic entry adds a node: `op` is a visp_graph_op, `src` the operand handles, `iparams` / `fparams` its integer
+ * and float arguments (listed per op below). dev == NULL makes a planning-only graph: build, fold constants, lower and plan the arena, no
+ * device work (visp_graph_describe shows the launch list). */
+typedef struct visp_graph visp_graph;
+enum visp_graph_op {
+    VISP_OP_LINEAR = 2,            /* src x, w [K,N], (b)                                  nn.cpp:6-12 */
+    VISP_OP_LAYER_NORM = 3,        /* src x, w, b; f0 eps                                  nn.cpp:14-19 */
+    VISP_OP_GELU = 4, VISP_OP_RELU = 5,
+    VISP_OP_SCALE = 6,             /* f0 factor */
+    VISP_OP_ADD = 7, VISP_OP_MUL = 8, /* second operand broadcast over trailing dimensions */
+    VISP_OP_CONV_2D = 9,           /* src x [C,W,H,N], w [Cin,kw,kh,Cout], (b); i0 stride, i1 pad        nn.cpp:72-100 */
+    VISP_OP_CONV_TRANSPOSE_2D = 10,/* src x, w [kw,kh,Cout,Cin], (b); i0 stride (== kernel)               nn.cpp:117-129 */
+    VISP_OP_INTERPOLATE = 11,      /* i0 w, i1 h, i2 mode: 1 bilinear, 2 bicubic, | 256 align_corners     ml.cpp:782-788 */
+    VISP_OP_ATTENTION = 12,        /* src q, k, v [head_dim, heads, tokens, batch]; f0 scale               nn.cpp:210-244 */
+    VISP_OP_CONCAT = 13,           /* src a, b; i0 dim                                                      ml.cpp:770-780 */
+    VISP_OP_SLICE = 14,            /* i[3d], i[3d+1], i[3d+2] = begin, end, step of dimension d            ml.cpp:746-768 */
+    VISP_OP_RESHAPE = 15,          /* i0..i3 ne */
+    VISP_OP_REPEAT = 16,           /* i0..i3 ne */
+    VISP_OP_PATCH_EMBED = 17,      /* src x f32 [C,W,H,N], w, (b); i0 patch size                           nn.cpp:166-180 */
+    VISP_OP_CONT = 18
+};
+VISP_API int32_t visp_graph_create(visp_device const* dev, visp_graph** out);
+VISP_API void visp_graph_destroy(visp_graph* g);
+/* every f16 / f32 tensor of the file becomes a weight; conv kernels listed in <arch>.conv2d_weights are presented as [Cin,kw,kh,Cout] */
+VISP_API int32_t visp_graph_load_weights(visp_graph* g, char const* gguf_path);
+VISP_API int32_t visp_graph_add_weight(visp_graph* g, char const* name, int32_t dtype, int64_t const ne[4], float const* data, int32_t* out);
+VISP_API int32_t visp_graph_find_weight(visp_graph const* g, char const* name, int32_t* out); /* *out = -1 when absent (model_ref::find) */
+VISP_API int32_t visp_graph_input(visp_graph* g, int32_t dtype /* 0 f32, 1 f16 */, int64_t const ne[4], char const* name, int32_t* out);
+VISP_API int32_t visp_graph_op(visp_graph* g, int32_t op, int32_t const* src, int32_t n_src, int64_t const* iparams, int32_t n_iparams,
+                               float const* fparams, int32_t n_fparams, int32_t* out);
+VISP_API int32_t visp_graph_set_name(visp_graph* g, int32_t tensor, char const* name);
+VISP_API int32_t visp_graph_get_tensor(visp_graph const* g, char const* name, int32_t* out); /* ggml_get_tensor; -1 when absent */
+VISP_API int32_t visp_graph_output(visp_graph* g, int32_t tensor, char const* name);
+VISP_API int32_t visp_graph_tensor_info(visp_graph const* g, int32_t tensor, int32_t* dtype, int64_t ne[4], int32_t* is_constant);
+/* constants (weights and everything folded from them): their f32 values */
+VISP_API int32_t visp_graph_read_constant(visp_graph const* g, int32_t tensor, float* out, int64_t capacity);
+VISP_API int32_t visp_graph_allocate(visp_graph* g);  /* lower to launches, pack weights, plan + allocate the arena */
+VISP_API int32_t visp_graph_use_hip_graph(visp_graph* g, int32_t enable); /* replay the launch list as one hipGraph from the second compute on */
+VISP_API int32_t visp_graph_compute(visp_graph* g);   /* blocking (ml.cpp:559-562) */
+VISP_API int32_t visp_graph_tensor_set(visp_graph* g, int32_t tensor, void const* data, size_t n_bytes);
+VISP_API int32_t visp_graph_tensor_get(visp_graph* g, int32_t tensor, void* data, size_t n_bytes, int32_t as_f32);
+/* one line per launch, then "launches=.. arena_bytes=.. unshared_bytes=.. constant_bytes=.."; returns the length needed */
+VISP_API int32_t visp_graph_describe(visp_graph const* g, char* out, int64_t capacity, int64_t* needed);
+
 #ifdef __cplusplus
 }
 #endif

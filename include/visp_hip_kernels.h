@@ -339,6 +339,21 @@ VX_API int vx_minmax_normalize(const float* depth, float* out, float* minmax, in
 /* alpha_f32 -> alpha_u8: uint8(clamp(v,0,1)*255) (image-impl.h:36-38) */
 VX_API int vx_f32_to_u8(const float* src, uint8_t* dst, int64_t n, void* stream);
 
+/* ---- graph executor glue (csrc/graph.cpp, kernels_graph.hip): the stand-alone forms of the ops the reference's arch code emits between
+ * its matrix products (ml.cpp:746-788 slice / concat, ggml_add / ggml_mul broadcasts, ggml_gelu / relu / scale, ggml_cont of a permute) */
+/* dst[i . dst_stride] = scale * src[i . src_stride], i over ne (element strides, 0 = broadcast a source dimension) */
+VX_API int vx_copy_strided_f16(const void* src, void* dst, const int64_t ne[4], const int64_t src_stride[4], const int64_t dst_stride[4], float scale,
+                               void* stream);
+/* y[i] = a[i] (op) b[i mod b_period]; op 0 add, 1 mul; each operand f16 or f32 */
+VX_API int vx_binary_rows(int op, const void* a, int a_f32, const void* b, int b_f32, int64_t b_period, void* y, int y_f32, int64_t n, void* stream);
+/* op 0 tanh-GELU (ggml_gelu), 1 ReLU, 2 x * s; f16 */
+VX_API int vx_unary_f16(int op, const void* x, void* y, int64_t n, float s, void* stream);
+VX_API int vx_convert(const void* x, int x_f32, void* y, int y_f32, int64_t n, void* stream);
+/* patch_embed's im2col (nn.cpp:166-180) on the f32 image tensor [B,H,W,C]: rows (b,py,px), k = (ky,kx,c), zero padded to Kp, f16 */
+/* 1x1 convolution to one channel: out f32 [M] = scale * act(sum_c x[m,c] w[c] + bias), x f16 [M][C] (depth-anything.cpp:91-95) */
+VX_API int vx_conv1x1_to1_f32(const void* x, const float* w, float bias, int relu, float scale, float* out, int64_t M, int C, void* stream);
+VX_API int vx_im2col_patches_f32(const float* x, void* patches, int B, int H, int W, int C, int ps, int Kp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

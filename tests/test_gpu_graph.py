@@ -1,0 +1,315 @@
+"""-m gpu: the graph executor (csrc/graph.cpp behind `visp_graph_*`) on the device. Every node kind against a
+plain PyTorch fp32 evaluation of the same op on the same f16-rounded operands (the reference pins its ops the same way:
+tests/test_primitives.py:20-184), then Depth-Anything-V2 built through the layer the way the reference's arch code builds it
+(vision.cpp_amd/graph.py::depthany_predict) against the CPU oracle (MAE < 1e-3, the north star's tolerance) and against the
+hand-scheduled step of csrc/depthany.cpp."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle
+from visioncpp_amd import _lib as L
+from visioncpp_amd import graph as G
+from visioncpp_amd import synth, vision
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    return vision.Device.init(vision.Backend.gpu)
+
+
+def h(a):  # round to f16 like every activation / matrix weight of the executor
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def rel(got, want):
+    want = np.asarray(want, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - want).max() / max(float(np.abs(want).max()), 1e-30))
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def run(g, feeds, outs):
+    g.allocate()
+    for k, v in feeds.items():
+        g.set(k, v)
+    g.compute()
+    return [g.get(o) for o in outs]
+
+
+def test_linear_layer_norm_gelu_mul_add(device):
+    """One pre-LN MLP block (dino.cpp:48-56, 80-87): layer_norm -> linear + gelu (fused) -> linear -> layer scale -> residual."""
+    rng = np.random.default_rng(1)
+    C, Hd, T, B = 128, 512, 70, 3
+    x = h(rng.standard_normal((B, T, C)))
+    w = {"norm.weight": 1 + 0.1 * rng.standard_normal(C), "norm.bias": 0.1 * rng.standard_normal(C), "fc1.weight": h(0.05 * rng.standard_normal((Hd, C))),
+         "fc1.bias": 0.05 * rng.standard_normal(Hd), "fc2.weight": h(0.05 * rng.standard_normal((C, Hd))), "fc2.bias": 0.05 * rng.standard_normal(C),
+         "ls.lambda1": 0.3 + 0.1 * rng.standard_normal(C)}
+    g = G.Graph(device)
+    for k, v in w.items():
+        g.add_weight(k, v, G.F16 if v.ndim == 2 else G.F32)
+    m = G.ModelRef(g)
+    xi = g.input((C, T, B), G.F16)
+    ln = G.layer_norm(m["norm"], xi, 1e-6)
+    hid = G.gelu(m, G.linear(m["fc1"], ln))
+    y = G.add(m, xi, G.mul(m, G.linear(m["fc2"], hid), m["ls"].weights("lambda1")))
+    g.output(ln, "ln"); g.output(y, "y")
+    got_ln, got_y = run(g, {xi: x}, [ln, y])
+    tw = {k: t(v) for k, v in w.items()}
+    ref_ln = F.layer_norm(t(x), (C,), tw["norm.weight"], tw["norm.bias"], 1e-6)
+    assert rel(got_ln, ref_ln.numpy()) < 2e-3
+    ref_h = F.gelu(F.linear(t(h(ref_ln.numpy())), tw["fc1.weight"], tw["fc1.bias"]), approximate="tanh")
+    ref_y = t(x) + F.linear(t(h(ref_h.numpy())), tw["fc2.weight"], tw["fc2.bias"]) * tw["ls.lambda1"]
+    assert rel(got_y, ref_y.numpy()) < 3e-3
+    assert g.describe().splitlines()[1].startswith("gemm[gelu]")
+
+
+@pytest.mark.parametrize("T,B,heads", [(50, 2, 2), (257, 1, 6), (1370, 1, 6)])
+def test_attention_node(device, T, B, heads):
+    """split heads (reshape views) -> attention -> output linear (nn.cpp:210-244, dino.cpp:59-74) vs torch softmax(QK^T / 8) V."""
+    rng = np.random.default_rng(T)
+    C = heads * 64
+    x = h(rng.standard_normal((B, T, C)))
+    ws = {n: h(rng.standard_normal((C, C)) / math.sqrt(C)) for n in ("query", "key", "value", "dense")}
+    bs = {n: 0.1 * rng.standard_normal(C) for n in ws}
+    g = G.Graph(device)
+    for n in ws:
+        g.add_weight(f"{n}.weight", ws[n]); g.add_weight(f"{n}.bias", bs[n], G.F32)
+    m = G.ModelRef(g)
+    xi = g.input((C, T, B), G.F16)
+    q, k, v = (G.reshape(m, G.linear(m[n], xi), 64, heads, T, B) for n in ("query", "key", "value"))
+    y = g.output(G.attention(m, q, k, v, None, 1 / 8, m["dense"]), "y")
+    (got,) = run(g, {xi: x}, [y])
+    tq, tk, tv = (t(h(F.linear(t(x), t(ws[n]), t(bs[n])).numpy())).reshape(B, T, heads, 64).transpose(1, 2) for n in ("query", "key", "value"))
+    att = torch.softmax(tq @ tk.transpose(-1, -2) / 8, -1) @ tv
+    ref = F.linear(t(h(att.transpose(1, 2).reshape(B, T, C).numpy())), t(ws["dense"]), t(bs["dense"]))
+    assert rel(got, ref.numpy()) < 4e-3
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W", [(64, 64, 3, 1, 1, 19, 23), (48, 64, 3, 1, 1, 30, 26), (96, 96, 3, 2, 1, 37, 37), (64, 32, 3, 1, 1, 100, 120),
+                                                         (384, 48, 1, 1, 0, 12, 9), (32, 32, 3, 1, 1, 112, 98), (64, 8, 5, 1, 2, 21, 17)])
+def test_conv_2d_node(device, cin, cout, k, stride, pad, H, W):
+    """CWHN conv_2d (nn.cpp:72-100) in every form the lowering picks: 1x1 as a plain product, implicit GEMM (any kernel / stride / a Cin whose
+    9-tap rows are not a multiple of the 64-wide k tile), the halo-in-LDS 3x3 kernel from 96 px wide -- vs torch conv2d."""
+    rng = np.random.default_rng(cin + cout + k)
+    B = 2
+    x = h(rng.standard_normal((B, H, W, cin)))
+    w = h(rng.standard_normal((cout, k, k, cin)) / math.sqrt(k * k * cin))  # OHWI
+    b = 0.1 * rng.standard_normal(cout)
+    g = G.Graph(device)
+    g.add_weight("c.weight", w); g.add_weight("c.bias", b, G.F32)
+    m = G.ModelRef(g)
+    xi = g.input((cin, W, H, B), G.F16)
+    y = g.output(G.conv_2d(m["c"], xi, stride, pad), "y")
+    (got,) = run(g, {xi: x}, [y])
+    ref = F.conv2d(t(x).permute(0, 3, 1, 2), t(w).permute(0, 3, 1, 2), t(b), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    assert got.shape == tuple(ref.shape)
+    assert rel(got, ref.numpy()) < 2e-3
+
+
+def test_residual_conv_unit_fuses_and_matches(device):
+    """dpt::residual_conv (depth-anything.cpp:15-23) = two launches: conv[relu-in][relu], conv[+res]; plus feature_fusion's outer add,
+    bilinear align_corners resize and 1x1 projection (depth-anything.cpp:25-42)."""
+    rng = np.random.default_rng(5)
+    C, H, W, B = 64, 37, 37, 2
+    x0, x1 = h(rng.standard_normal((B, H, W, C))), h(rng.standard_normal((B, H, W, C)))
+    names = ["residual_layer1.convolution1", "residual_layer1.convolution2", "residual_layer2.convolution1", "residual_layer2.convolution2"]
+    w = {n: h(rng.standard_normal((C, 3, 3, C)) / math.sqrt(9 * C)) for n in names}
+    b = {n: 0.1 * rng.standard_normal(C) for n in names}
+    wp, bp = h(rng.standard_normal((C, 1, 1, C)) / 8), 0.1 * rng.standard_normal(C)
+    g = G.Graph(device)
+    for n in names:
+        g.add_weight(f"f.{n}.weight", w[n]); g.add_weight(f"f.{n}.bias", b[n], G.F32)
+    g.add_weight("f.projection.weight", wp); g.add_weight("f.projection.bias", bp, G.F32)
+    m = G.ModelRef(g)
+    a, c = g.input((C, W, H, B), G.F16, "x0"), g.input((C, W, H, B), G.F16, "x1")
+    y = g.output(G.dpt_feature_fusion(m["f"], a, c, (74, 74)), "y")
+    (got,) = run(g, {a: x0, c: x1}, [y])
+    d = g.describe()
+    assert d.count("[relu-in][relu]") == 2 and d.count("[+res]") == 2 and "bilinear_ac 37x37 -> 74x74 C=64" in d
+
+    def conv(v, n):
+        return F.conv2d(v, t(w[n]).permute(0, 3, 1, 2), t(b[n]), padding=1)
+
+    def rcu(v, p):
+        o = t(h(torch.relu(conv(torch.relu(v), f"{p}.convolution1")).numpy()))
+        return t(h((v + conv(o, f"{p}.convolution2")).numpy()))
+
+    v0, v1 = t(x0).permute(0, 3, 1, 2), t(x1).permute(0, 3, 1, 2)
+    r = rcu(t(h((v0 + rcu(v1, "residual_layer1")).numpy())), "residual_layer2")
+    up = t(h(F.interpolate(r, size=(74, 74), mode="bilinear", align_corners=True).numpy()))
+    ref = F.conv2d(up, t(wp).permute(0, 3, 1, 2), t(bp)).permute(0, 2, 3, 1)
+    assert rel(got, ref.numpy()) < 4e-3
+
+
+@pytest.mark.parametrize("cin,cout,s", [(48, 48, 4), (96, 96, 2), (64, 16, 2)])
+def test_conv_transpose_2d_node(device, cin, cout, s):
+    """kernel == stride transposed conv (nn.cpp:117-129) as a product + pixel shuffle; Cin = 48 / 96 take the zero-padded row copy."""
+    rng = np.random.default_rng(cin + s)
+    B, H, W = 2, 9, 11
+    x = h(rng.standard_normal((B, H, W, cin)))
+    w = h(rng.standard_normal((cin, cout, s, s)) / math.sqrt(cin))  # torch layout = ggml ne [kw, kh, Cout, Cin]
+    b = 0.1 * rng.standard_normal(cout)
+    g = G.Graph(device)
+    g.add_weight("t.weight", w); g.add_weight("t.bias", b, G.F32)
+    xi = g.input((cin, W, H, B), G.F16)
+    y = g.output(G.conv_transpose_2d(G.ModelRef(g)["t"], xi, s), "y")
+    (got,) = run(g, {xi: x}, [y])
+    ref = F.conv_transpose2d(t(x).permute(0, 3, 1, 2), t(w), t(b), stride=s).permute(0, 2, 3, 1)
+    assert rel(got, ref.numpy()) < 2e-3
+    assert ("pad_rows" in g.describe()) == (cin % 64 != 0)
+
+
+def test_slice_concat_repeat_patch_embed(device):
+    """dino::prepare_tokens (dino.cpp:32-46): patch_embed on the f32 image tensor, cls token repeated over the batch and concatenated
+    in front, position embeddings added; then the neck's cls-token slice (depth-anything.cpp:50-51)."""
+    rng = np.random.default_rng(9)
+    D, ps, pw, ph, B = 64, 14, 4, 4, 3
+    img = rng.standard_normal((B, ph * ps, pw * ps, 3)).astype(np.float32)
+    w = h(rng.standard_normal((D, ps, ps, 3)) / math.sqrt(ps * ps * 3))
+    b = 0.1 * rng.standard_normal(D)
+    cls = rng.standard_normal((1, 1, D)).astype(np.float32)
+    pos = rng.standard_normal((1, 1 + pw * ph, D)).astype(np.float32)
+    g = G.Graph(device)
+    g.add_weight("e.patch_embeddings.projection.weight", w); g.add_weight("e.patch_embeddings.projection.bias", b, G.F32)
+    g.add_weight("e.cls_token", cls, G.F32); g.add_weight("e.position_embeddings", pos, G.F32)
+    m = G.ModelRef(g)
+    xi = g.input((3, pw * ps, ph * ps, B), G.F32, "image")
+    tok = G.dino_prepare_tokens(m["e"], xi, ps)
+    sl = G.slice_(m, tok, G.SLICE_ALL, (1, tok.ne[1]))
+    every_other = G.slice_(m, tok, (8, 40, 1), (0, tok.ne[1], 2))  # begin / end / step on two dimensions: the generic strided copy
+    g.output(tok, "tok"); g.output(sl, "sl"); g.output(every_other, "eo")
+    got_tok, got_sl, got_eo = run(g, {xi: img}, [tok, sl, every_other])
+    pe = F.conv2d(t(h(img)).permute(0, 3, 1, 2), t(w).permute(0, 3, 1, 2), t(b), stride=ps).permute(0, 2, 3, 1).reshape(B, pw * ph, D)
+    ref = torch.cat([t(h(cls)).expand(B, 1, D), t(h(pe.numpy()))], 1) + t(pos)
+    assert got_tok.shape == (1, B, 1 + pw * ph, D)
+    assert rel(got_tok[0], ref.numpy()) < 2e-3
+    np.testing.assert_array_equal(got_sl[0], got_tok[0][:, 1:])
+    np.testing.assert_array_equal(got_eo[0], got_tok[0][:, 0::2, 8:40])
+
+
+def test_one_channel_head_relu_scale(device):
+    """head.conv3 (1x1, 32 -> 1) + ReLU + max_depth scale (depth-anything.cpp:91-95): one f32 launch."""
+    rng = np.random.default_rng(3)
+    C, H, W, B = 32, 20, 30, 2
+    x = h(rng.standard_normal((B, H, W, C)))
+    w, b = h(rng.standard_normal((1, 1, 1, C)) / 4), np.array([0.2], np.float32)
+    g = G.Graph(device)
+    g.add_weight("conv3.weight", w); g.add_weight("conv3.bias", b, G.F32)
+    m = G.ModelRef(g)
+    xi = g.input((C, W, H, B), G.F16)
+    y = g.output(G.scale(m, G.relu(m, G.conv_2d(m["conv3"], xi)), 20.0), "depth")
+    (got,) = run(g, {xi: x}, [y])
+    assert y.dtype == G.F32 and g.summary()["launches"] == 1
+    ref = 20.0 * torch.relu((t(x) * t(w).reshape(C)).sum(-1) + 0.2)
+    np.testing.assert_allclose(got[..., 0], ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def _oracle(cfg, seed):
+    sd = synth.state_dict(cfg, seed)
+    tensors, conv2d = synth.gguf_tensors(sd)
+    om = oracle.Model(tensors, conv2d, "whcn")
+    params = oracle.make_params(cfg.patch_size, cfg.embed_dim, cfg.n_layers, cfg.n_heads, cfg.image_size, 14, cfg.feature_layers, 1.0, oracle.GELU_GGML_F16_LUT)
+    return om, params
+
+
+def _pre(img):
+    return oracle.image_u8_to_f32(img, oracle.RGB_U8, oracle.RGB_F32, (-0.485, -0.456, -0.406, 0), (1 / 0.229, 1 / 0.224, 1 / 0.225, 1))
+
+
+def _norm(d):
+    lo, hi = d.min(), d.max()
+    return (d - lo) / (hi - lo)
+
+
+@pytest.mark.parametrize("layout", ["whcn", "cwhn"])
+def test_depth_anything_through_the_graph_layer(device, tmp_path, layout):
+    """The whole model built node by node (graph.py::depthany_predict = the structure of dino.cpp + depth-anything.cpp) from a GGUF of
+    either tensor layout, against the CPU oracle at every tapped boundary and at the output (MAE < 1e-3 on the normalised depth), and
+    against the hand-scheduled step. 700 x 518: the position embeddings are bicubic-resized (folded on the host)."""
+    cfg = synth.SMALL
+    path = synth.write_gguf(tmp_path / f"small_{layout}.gguf", cfg, seed=0, layout=layout)
+    W, H, B = 700, 518, 2
+    imgs = synth.images(B, W, H, seed=3)
+    g = G.Graph(device)
+    g.load_weights(path)
+    m = G.ModelRef(g)
+    xi = g.input((3, W, H, B), G.F32, "image")
+    out = G.depthany_predict(m, xi, cfg.n_layers, cfg.n_heads)
+    taps = [g.output(g.get_tensor(f"dino_layer_{i}"), f"dino_layer_{i}") for i in cfg.feature_layers]
+    fused = g.output(g.get_tensor("neck.fusion_stage.layers.3"), "fusion_3")
+    g.allocate()
+    g.set(xi, np.stack([_pre(im) for im in imgs]))
+    g.compute()
+    depth = g.get(out)[..., 0]
+    assert depth.shape == (B, H, W) and np.isfinite(depth).all()
+
+    om, params = _oracle(cfg, 0)
+    names = [f"dino_layer_{i}" for i in cfg.feature_layers] + ["fusion_3"]
+    for b in range(B):
+        caps = {n: 1 << 25 for n in names}
+        want, cap = om.predict(params, _pre(imgs[b]), caps)
+        for n, tn in zip(names, taps + [fused]):
+            got = g.get(tn)
+            got = got[0, b] if n.startswith("dino") else got[b]
+            assert rel(got.reshape(-1), cap[n].reshape(-1)) < (2e-2 if n.startswith("dino") else 3e-2), n
+        mae = float(np.abs(_norm(depth[b]) - _norm(want.reshape(H, W))).mean())
+        print(f"{layout} image {b}: graph executor vs oracle MAE {mae:.2e}")
+        assert mae < 1e-3
+
+    model = vision.Model.load(path, device)
+    static = model.compute_batch(imgs)
+    for b in range(B):
+        assert float(np.abs(_norm(depth[b]) - static[b]).mean()) < 5e-4
+
+
+def test_hip_graph_replay_is_bit_identical(device, tmp_path):
+    """compute() eagerly, then the same launch list replayed as one hipGraph: identical bits, and new input data is picked up."""
+    cfg = synth.MINI
+    path = synth.write_gguf(tmp_path / "mini.gguf", cfg, seed=4)
+    g = G.Graph(device)
+    g.load_weights(path)
+    xi = g.input((3, 112, 112, 2), G.F32, "image")
+    out = G.depthany_predict(G.ModelRef(g), xi, cfg.n_layers, cfg.n_heads, feature_layers=cfg.feature_layers)
+    g.allocate()
+    g.use_hip_graph(True)
+    a, b2 = (np.stack([_pre(im) for im in synth.images(2, 112, 112, seed=s)]) for s in (1, 2))
+    g.set(xi, a); g.compute(); first = g.get(out)       # eager + capture
+    g.compute(); again = g.get(out)                     # replay
+    np.testing.assert_array_equal(first, again)
+    g.set(xi, b2); g.compute(); other = g.get(out)
+    assert np.abs(other - first).max() > 0
+    om, params = _oracle(cfg, 4)
+    want, _ = om.predict(params, a[0], {})
+    assert float(np.abs(_norm(first[0, ..., 0]) - _norm(want.reshape(112, 112))).mean()) < 1e-3
+
+
+def test_intermediates_are_not_readable_and_errors_surface(device):
+    g = G.Graph(device)
+    g.add_weight("fc.weight", np.eye(64, dtype=np.float32))
+    m = G.ModelRef(g)
+    x = g.input((64, 8), G.F16)
+    mid = G.linear(m["fc"], x)
+    y = g.output(G.linear(m["fc"], G.relu(m, mid)), "y")
+    g.allocate()
+    g.set(x, np.ones((8, 64)))
+    g.compute()
+    np.testing.assert_array_equal(g.get(y), np.ones((1, 1, 8, 64)))
+    with pytest.raises(L.Error, match="recycled"):
+        g.get(mid)  # not marked as an output: its buffer may have been reused (compute_graph_output is how the reference keeps one)
+    with pytest.raises(ValueError):
+        g.set(x, np.ones((4, 64)))
+    g2 = G.Graph(device)
+    g2.add_weight("q.weight", np.zeros((96, 96), np.float32))
+    x2 = g2.input((96, 10, 1), G.F16)
+    q = G.reshape(G.ModelRef(g2), G.linear(G.ModelRef(g2)["q"], x2), 32, 3, 10, 1)
+    g2.output(g2.op(G.OP_ATTENTION, [q, q, q], fparams=[0.1]), "o")
+    with pytest.raises(L.Error, match="head_dim 64"):
+        g2.allocate()

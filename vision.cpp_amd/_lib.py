@@ -105,6 +105,9 @@ C_API_SYMBOLS = [
     "visp_birefnet_image_extent", "visp_birefnet_compute_batch_device", "visp_birefnet_compute_batch_host",
     "visp_swin_load", "visp_swin_output_dims", "visp_swin_encode_batch_device", "visp_swin_encode_batch_host", "visp_swin_enable_captures",
     "visp_swin_read_capture", "visp_swin_enable_timing", "visp_swin_read_timing", "visp_swin_set_mask_mode",
+    "visp_graph_create", "visp_graph_destroy", "visp_graph_load_weights", "visp_graph_add_weight", "visp_graph_find_weight", "visp_graph_input",
+    "visp_graph_op", "visp_graph_set_name", "visp_graph_get_tensor", "visp_graph_output", "visp_graph_tensor_info", "visp_graph_read_constant",
+    "visp_graph_allocate", "visp_graph_use_hip_graph", "visp_graph_compute", "visp_graph_tensor_set", "visp_graph_tensor_get", "visp_graph_describe",
 ]
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
@@ -118,6 +121,7 @@ KERNEL_SYMBOLS = [
     "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_mbconv_dw_pw_supported", "vx_mbconv_pack_w3", "vx_mbconv_dw_pw_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
     "vx_bf_preprocess_half", "vx_bf_patches", "vx_bf_resize_f16", "vx_bf_deform_cols_f16", "vx_bf_mean_f16", "vx_bf_broadcast_f16", "vx_bf_mul_sigmoid_f16", "vx_bf_sigmoid_out_f32",
     "vx_swin_attention_pack_bias", "vx_window_attention_masked_f16", "vx_swin_layernorm_f16", "vx_swin_layernorm_strided_f16", "vx_swin_merge_layernorm_f16", "vx_swin_window_reverse_add_f16",
+    "vx_copy_strided_f16", "vx_binary_rows", "vx_unary_f16", "vx_convert", "vx_im2col_patches_f32", "vx_conv1x1_to1_f32",
     "vx_dino_block_supported", "vx_dino_block_mlp_bytes", "vx_dino_block_qkv_bytes", "vx_dino_block_pack_mlp", "vx_dino_block_pack_qkv", "vx_dino_block_f16", "vx_dino_block16_pack_mlp", "vx_dino_block16_pack_qkv", "vx_dino_block16_f16",
 ]
 
@@ -219,9 +223,28 @@ def init() -> ctypes.CDLL:
     lib.visp_image_scale.argtypes = [POINTER(ImageView), c_int32, c_int32, POINTER(ImageView), POINTER(c_void_p)]
     lib.visp_image_u8_to_f32.argtypes = [POINTER(ImageView), c_int32, POINTER(c_float), POINTER(c_float), POINTER(ImageView), POINTER(c_void_p)]
     lib.visp_image_normalize.argtypes = [POINTER(ImageView), c_float, c_float, POINTER(ImageView), POINTER(c_void_p)]
+    lib.visp_graph_create.argtypes = [c_void_p, POINTER(c_void_p)]
+    lib.visp_graph_destroy.argtypes = [c_void_p]
+    lib.visp_graph_load_weights.argtypes = [c_void_p, c_char_p]
+    lib.visp_graph_add_weight.argtypes = [c_void_p, c_char_p, c_int32, POINTER(c_int64), c_void_p, POINTER(c_int32)]
+    lib.visp_graph_find_weight.argtypes = [c_void_p, c_char_p, POINTER(c_int32)]
+    lib.visp_graph_input.argtypes = [c_void_p, c_int32, POINTER(c_int64), c_char_p, POINTER(c_int32)]
+    lib.visp_graph_op.argtypes = [c_void_p, c_int32, POINTER(c_int32), c_int32, POINTER(c_int64), c_int32, POINTER(c_float), c_int32, POINTER(c_int32)]
+    lib.visp_graph_set_name.argtypes = [c_void_p, c_int32, c_char_p]
+    lib.visp_graph_get_tensor.argtypes = [c_void_p, c_char_p, POINTER(c_int32)]
+    lib.visp_graph_output.argtypes = [c_void_p, c_int32, c_char_p]
+    lib.visp_graph_tensor_info.argtypes = [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int64), POINTER(c_int32)]
+    lib.visp_graph_read_constant.argtypes = [c_void_p, c_int32, c_void_p, c_int64]
+    lib.visp_graph_allocate.argtypes = [c_void_p]
+    lib.visp_graph_use_hip_graph.argtypes = [c_void_p, c_int32]
+    lib.visp_graph_compute.argtypes = [c_void_p]
+    lib.visp_graph_tensor_set.argtypes = [c_void_p, c_int32, c_void_p, c_size_t]
+    lib.visp_graph_tensor_get.argtypes = [c_void_p, c_int32, c_void_p, c_size_t, c_int32]
+    lib.visp_graph_describe.argtypes = [c_void_p, c_char_p, c_int64, POINTER(c_int64)]
     for name in C_API_SYMBOLS[15:]:
         getattr(lib, name).restype = c_int32
     lib.visp_depthany_pipeline_destroy.restype = None
+    lib.visp_graph_destroy.restype = None
 
     lib.vx_last_error.restype = c_char_p
     lib.vx_device_info.argtypes = [c_int, c_char_p, c_int, c_char_p, c_int, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_int)]

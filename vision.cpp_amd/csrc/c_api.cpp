@@ -18,12 +18,14 @@
 #include "tinyvit.h"
 #include "swin.h"
 #include "birefnet.h"
+#include "graph.h"
 #include "visp_util.h"
 
 using namespace visp;
 
 struct visp_image_data : image_data {};
 struct visp_device : backend_device {};
+struct visp_graph : graph {};
 // visp_model stays opaque: handles are depthany_model* (any_model in the reference, c-api.cpp:193)
 
 namespace {
@@ -713,6 +715,96 @@ int32_t visp_swin_read_timing(visp_model* m, visp_timing* out, int32_t cap, int3
             ++count;
         }
         *n = count;
+    });
+}
+
+// ---- graph layer (graph.h) ----
+
+int32_t visp_graph_create(visp_device const* dev, visp_graph** out) {
+    return handle_errors([&]() {
+        if (!out) throw except("visp_graph_create: null out pointer");
+        *out = static_cast<visp_graph*>(graph_create(dev));
+    });
+}
+void visp_graph_destroy(visp_graph* g) { delete static_cast<graph*>(g); }
+
+static graph& as_graph(visp_graph* g) {
+    if (!g) throw except("graph handle is null");
+    return *g;
+}
+static graph const& as_cgraph(visp_graph const* g) {
+    if (!g) throw except("graph handle is null");
+    return *g;
+}
+
+int32_t visp_graph_load_weights(visp_graph* g, char const* gguf_path) {
+    return handle_errors([&]() { graph_load_weights(as_graph(g), gguf_path); });
+}
+int32_t visp_graph_add_weight(visp_graph* g, char const* name, int32_t dtype, int64_t const ne[4], float const* data, int32_t* out) {
+    return handle_errors([&]() {
+        const int t = graph_add_weight(as_graph(g), name, dtype, ne, data);
+        if (out) *out = t;
+    });
+}
+int32_t visp_graph_find_weight(visp_graph const* g, char const* name, int32_t* out) {
+    return handle_errors([&]() { *out = graph_find_weight(as_cgraph(g), name); });
+}
+int32_t visp_graph_input(visp_graph* g, int32_t dtype, int64_t const ne[4], char const* name, int32_t* out) {
+    return handle_errors([&]() { *out = graph_input(as_graph(g), dtype, ne, name); });
+}
+int32_t visp_graph_op(visp_graph* g, int32_t op, int32_t const* src, int32_t n_src, int64_t const* iparams, int32_t n_iparams, float const* fparams,
+                      int32_t n_fparams, int32_t* out) {
+    return handle_errors([&]() { *out = graph_add(as_graph(g), op, src, n_src, iparams, n_iparams, fparams, n_fparams); });
+}
+int32_t visp_graph_set_name(visp_graph* g, int32_t tensor, char const* name) {
+    return handle_errors([&]() { graph_set_name(as_graph(g), tensor, name); });
+}
+int32_t visp_graph_get_tensor(visp_graph const* g, char const* name, int32_t* out) {
+    return handle_errors([&]() { *out = graph_get_tensor(as_cgraph(g), name); });
+}
+int32_t visp_graph_output(visp_graph* g, int32_t tensor, char const* name) {
+    return handle_errors([&]() { graph_output(as_graph(g), tensor, name); });
+}
+int32_t visp_graph_tensor_info(visp_graph const* g, int32_t tensor, int32_t* dtype, int64_t ne[4], int32_t* is_constant) {
+    return handle_errors([&]() {
+        graph const& gr = as_cgraph(g);
+        if (tensor < 0 || tensor >= (int)gr.nodes.size()) throw except("visp_graph_tensor_info: tensor handle %d is not part of this graph", tensor);
+        graph_node const& n = gr.nodes[tensor];
+        if (dtype) *dtype = n.dtype;
+        if (ne) for (int i = 0; i < 4; ++i) ne[i] = n.ne[i];
+        if (is_constant) *is_constant = n.constant;
+    });
+}
+int32_t visp_graph_read_constant(visp_graph const* g, int32_t tensor, float* out, int64_t capacity) {
+    return handle_errors([&]() {
+        graph const& gr = as_cgraph(g);
+        if (tensor < 0 || tensor >= (int)gr.nodes.size()) throw except("visp_graph_read_constant: tensor handle %d is not part of this graph", tensor);
+        graph_node const& n = gr.nodes[tensor];
+        if (!n.constant) throw except("visp_graph_read_constant: tensor %d is not a constant", tensor);
+        if (capacity < n.n_elements()) throw except("visp_graph_read_constant: capacity %lld < %lld elements", (long long)capacity, (long long)n.n_elements());
+        memcpy(out, n.host.data(), (size_t)n.n_elements() * 4);
+    });
+}
+int32_t visp_graph_allocate(visp_graph* g) {
+    return handle_errors([&]() { graph_allocate(as_graph(g)); });
+}
+int32_t visp_graph_use_hip_graph(visp_graph* g, int32_t enable) {
+    return handle_errors([&]() { as_graph(g).use_hip_graph = enable != 0; });
+}
+int32_t visp_graph_compute(visp_graph* g) {
+    return handle_errors([&]() { graph_compute(as_graph(g)); });
+}
+int32_t visp_graph_tensor_set(visp_graph* g, int32_t tensor, void const* data, size_t n_bytes) {
+    return handle_errors([&]() { graph_tensor_set(as_graph(g), tensor, data, n_bytes); });
+}
+int32_t visp_graph_tensor_get(visp_graph* g, int32_t tensor, void* data, size_t n_bytes, int32_t as_f32) {
+    return handle_errors([&]() { graph_tensor_get(as_graph(g), tensor, data, n_bytes, as_f32 != 0); });
+}
+int32_t visp_graph_describe(visp_graph const* g, char* out, int64_t capacity, int64_t* needed) {
+    return handle_errors([&]() {
+        std::string s = graph_describe(as_cgraph(g));
+        if (needed) *needed = (int64_t)s.size() + 1;
+        if (out && capacity > 0) snprintf(out, (size_t)capacity, "%s", s.c_str());
     });
 }
 
