@@ -241,9 +241,9 @@ VISP_API int32_t visp_swin_read_timing(visp_model* m, visp_timing* out, int32_t 
  * ggml (ggml_new_tensor / ggml_mul_mat / ggml_add / ... / ggml_gallocr / ggml_backend_graph_compute). A tensor handle is an index into its
  * graph (>= 0); shapes are ggml's ne order (ne[0] contiguous). include/visp/ml.h is the C++ face of these entries (model_ref, tensor, the
  * nn.h builder names). One generic entry adds a node: `op` is a visp_graph_op, `src` the operand handles, `iparams` / `fparams` its integer
- * and float arguments (listed per op below). dev == NULL makes a planning-only graph: build, fold constants, lower and plan the arena, no
- * device work (visp_graph_describe shows the launch list). */
+ * and float arguments (listed per op below). */
 typedef struct visp_graph visp_graph;
+typedef struct visp_weights visp_weights; /* model_weights (ml.h:126-149): tensors by name + their packed device images, shared by the graphs over them */
 enum visp_graph_op {
     VISP_OP_LINEAR = 2,            /* src x, w [K,N], (b)                                  nn.cpp:6-12 */
     VISP_OP_LAYER_NORM = 3,        /* src x, w, b; f0 eps                                  nn.cpp:14-19 */
@@ -261,22 +261,30 @@ enum visp_graph_op {
     VISP_OP_PATCH_EMBED = 17,      /* src x f32 [C,W,H,N], w, (b); i0 patch size                           nn.cpp:166-180 */
     VISP_OP_CONT = 18
 };
-VISP_API int32_t visp_graph_create(visp_device const* dev, visp_graph** out);
+/* every f16 / f32 tensor of the file becomes a weight (model_load + model_transfer, ml.cpp:206-217, 449-516); conv kernels listed in
+ * <arch>.conv2d_weights of a whcn file are presented as [Cin,kw,kh,Cout]. Device images are made when a graph that uses a tensor is
+ * allocated, once per (tensor, role), and are reused by later graphs over the same weights. */
+VISP_API int32_t visp_weights_load(char const* gguf_path, visp_weights** out);
+VISP_API int32_t visp_weights_create(visp_weights** out);
+VISP_API int32_t visp_weights_add(visp_weights* w, char const* name, int32_t dtype, int64_t const ne[4], float const* data);
+VISP_API void visp_weights_destroy(visp_weights* w); /* graphs over the weights keep them alive */
+/* compute_graph_init (ml.cpp:531-543). weights == NULL: the graph starts with an empty store of its own (visp_graph_add_weight) */
+VISP_API int32_t visp_graph_create(visp_weights* weights, visp_graph** out);
 VISP_API void visp_graph_destroy(visp_graph* g);
-/* every f16 / f32 tensor of the file becomes a weight; conv kernels listed in <arch>.conv2d_weights are presented as [Cin,kw,kh,Cout] */
-VISP_API int32_t visp_graph_load_weights(visp_graph* g, char const* gguf_path);
 VISP_API int32_t visp_graph_add_weight(visp_graph* g, char const* name, int32_t dtype, int64_t const ne[4], float const* data, int32_t* out);
-VISP_API int32_t visp_graph_find_weight(visp_graph const* g, char const* name, int32_t* out); /* *out = -1 when absent (model_ref::find) */
+VISP_API int32_t visp_graph_find_weight(visp_graph* g, char const* name, int32_t* out); /* *out = -1 when absent (model_ref::find) */
 VISP_API int32_t visp_graph_input(visp_graph* g, int32_t dtype /* 0 f32, 1 f16 */, int64_t const ne[4], char const* name, int32_t* out);
 VISP_API int32_t visp_graph_op(visp_graph* g, int32_t op, int32_t const* src, int32_t n_src, int64_t const* iparams, int32_t n_iparams,
                                float const* fparams, int32_t n_fparams, int32_t* out);
 VISP_API int32_t visp_graph_set_name(visp_graph* g, int32_t tensor, char const* name);
-VISP_API int32_t visp_graph_get_tensor(visp_graph const* g, char const* name, int32_t* out); /* ggml_get_tensor; -1 when absent */
+VISP_API int32_t visp_graph_get_tensor(visp_graph* g, char const* name, int32_t* out); /* ggml_get_tensor; -1 when absent */
 VISP_API int32_t visp_graph_output(visp_graph* g, int32_t tensor, char const* name);
 VISP_API int32_t visp_graph_tensor_info(visp_graph const* g, int32_t tensor, int32_t* dtype, int64_t ne[4], int32_t* is_constant);
 /* constants (weights and everything folded from them): their f32 values */
 VISP_API int32_t visp_graph_read_constant(visp_graph const* g, int32_t tensor, float* out, int64_t capacity);
-VISP_API int32_t visp_graph_allocate(visp_graph* g);  /* lower to launches, pack weights, plan + allocate the arena */
+/* compute_graph_allocate (ml.cpp:545-552): lower to launches, pack the weights the graph uses, plan + allocate the arena on `dev`.
+ * dev == NULL: lower and plan only -- no device work (visp_graph_describe shows the launch list and the arena size) */
+VISP_API int32_t visp_graph_allocate(visp_graph* g, visp_device const* dev);
 VISP_API int32_t visp_graph_use_hip_graph(visp_graph* g, int32_t enable); /* replay the launch list as one hipGraph from the second compute on */
 VISP_API int32_t visp_graph_compute(visp_graph* g);   /* blocking (ml.cpp:559-562) */
 VISP_API int32_t visp_graph_tensor_set(visp_graph* g, int32_t tensor, void const* data, size_t n_bytes);

@@ -238,8 +238,7 @@ def test_depth_anything_through_the_graph_layer(device, tmp_path, layout):
     path = synth.write_gguf(tmp_path / f"small_{layout}.gguf", cfg, seed=0, layout=layout)
     W, H, B = 700, 518, 2
     imgs = synth.images(B, W, H, seed=3)
-    g = G.Graph(device)
-    g.load_weights(path)
+    g = G.Graph(device, G.Weights(path))
     m = G.ModelRef(g)
     xi = g.input((3, W, H, B), G.F32, "image")
     out = G.depthany_predict(m, xi, cfg.n_layers, cfg.n_heads)
@@ -274,8 +273,7 @@ def test_hip_graph_replay_is_bit_identical(device, tmp_path):
     """compute() eagerly, then the same launch list replayed as one hipGraph: identical bits, and new input data is picked up."""
     cfg = synth.MINI
     path = synth.write_gguf(tmp_path / "mini.gguf", cfg, seed=4)
-    g = G.Graph(device)
-    g.load_weights(path)
+    g = G.Graph(device, G.Weights(path))
     xi = g.input((3, 112, 112, 2), G.F32, "image")
     out = G.depthany_predict(G.ModelRef(g), xi, cfg.n_layers, cfg.n_heads, feature_layers=cfg.feature_layers)
     g.allocate()
@@ -313,3 +311,44 @@ def test_intermediates_are_not_readable_and_errors_surface(device):
     g2.output(g2.op(G.OP_ATTENTION, [q, q, q], fparams=[0.1]), "o")
     with pytest.raises(L.Error, match="head_dim 64"):
         g2.allocate()
+
+
+@pytest.mark.parametrize("w,h", [(518, 518), (640, 480)])
+def test_cpp_graph_layer_runs_the_reference_call_sequence(tmp_path, w, h):
+    """tests/cpp/graph_check.cpp: include/visp/ml.h + nn.h + arch/depth-anything.h used the way the reference's depthany_compute uses its
+    graph layer (vision.cpp:137-167) -- model_load_weights, compute_graph_init, model_ref, compute_graph_input, depthany_predict,
+    compute_graph_allocate, transfer_to_backend, compute, transfer_from_backend -- against the hand-scheduled depthany_compute.
+    640 x 480 goes through image_scale to 700 x 518 and back (non-square grid: resized position embeddings)."""
+    import subprocess
+    from pathlib import Path
+
+    exe = Path(__file__).resolve().parents[1] / "vision.cpp_amd" / "lib" / "graph_check"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    path = synth.write_gguf(tmp_path / "small.gguf", synth.SMALL, seed=0)
+    r = subprocess.run([str(exe), str(path), str(w), str(h)], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "graph_check ok" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_graphs_over_one_model_share_the_device_weights(device, tmp_path):
+    """The reference rebuilds its graph when the input extent changes (vision.cpp:150-158) over the same model_weights. Here the second
+    graph over a Weights object uploads nothing for the weights (only its own folded constants) and both graphs stay usable."""
+    cfg = synth.MINI
+    path = synth.write_gguf(tmp_path / "mini.gguf", cfg, seed=4)
+    w = G.Weights(path)
+    outs, graphs = [], []
+    for (W, H) in [(112, 112), (168, 112)]:
+        g = G.Graph(device, w)
+        xi = g.input((3, W, H, 1), G.F32, "image")
+        out = G.depthany_predict(G.ModelRef(g), xi, cfg.n_layers, cfg.n_heads, feature_layers=cfg.feature_layers)
+        g.allocate()
+        graphs.append((g, xi, out, W, H))
+    first, second = graphs[0][0].summary()["constant_bytes"], graphs[1][0].summary()["constant_bytes"]
+    assert first > 3_000_000 and second < first // 10, (first, second)  # the resized position embeddings are the second graph's own
+    om, params = _oracle(cfg, 4)
+    for g, xi, out, W, H in graphs:
+        img = _pre(synth.images(1, W, H, seed=W)[0])
+        g.set(xi, img[None])
+        g.compute()
+        want, _ = om.predict(params, img, {})
+        assert float(np.abs(_norm(g.get(out)[0, ..., 0]) - _norm(want.reshape(H, W))).mean()) < 1e-3

@@ -88,8 +88,7 @@ def test_constants_fold_on_the_host_like_the_oracle_computes_them():
 @pytest.fixture(scope="module")
 def planned(tmp_path_factory):
     path = synth.write_gguf(tmp_path_factory.mktemp("g") / "small.gguf", synth.SMALL, seed=0)
-    g = _g()
-    g.load_weights(path)
+    g = G.Graph(None, G.Weights(path))
     img = g.input((3, 518, 518, 2), G.F32, "image")
     out = G.depthany_predict(G.ModelRef(g), img, 12, 6)
     g.allocate()

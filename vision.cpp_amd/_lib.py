@@ -105,7 +105,8 @@ C_API_SYMBOLS = [
     "visp_birefnet_image_extent", "visp_birefnet_compute_batch_device", "visp_birefnet_compute_batch_host",
     "visp_swin_load", "visp_swin_output_dims", "visp_swin_encode_batch_device", "visp_swin_encode_batch_host", "visp_swin_enable_captures",
     "visp_swin_read_capture", "visp_swin_enable_timing", "visp_swin_read_timing", "visp_swin_set_mask_mode",
-    "visp_graph_create", "visp_graph_destroy", "visp_graph_load_weights", "visp_graph_add_weight", "visp_graph_find_weight", "visp_graph_input",
+    "visp_weights_load", "visp_weights_create", "visp_weights_add", "visp_weights_destroy",
+    "visp_graph_create", "visp_graph_destroy", "visp_graph_add_weight", "visp_graph_find_weight", "visp_graph_input",
     "visp_graph_op", "visp_graph_set_name", "visp_graph_get_tensor", "visp_graph_output", "visp_graph_tensor_info", "visp_graph_read_constant",
     "visp_graph_allocate", "visp_graph_use_hip_graph", "visp_graph_compute", "visp_graph_tensor_set", "visp_graph_tensor_get", "visp_graph_describe",
 ]
@@ -225,7 +226,10 @@ def init() -> ctypes.CDLL:
     lib.visp_image_normalize.argtypes = [POINTER(ImageView), c_float, c_float, POINTER(ImageView), POINTER(c_void_p)]
     lib.visp_graph_create.argtypes = [c_void_p, POINTER(c_void_p)]
     lib.visp_graph_destroy.argtypes = [c_void_p]
-    lib.visp_graph_load_weights.argtypes = [c_void_p, c_char_p]
+    lib.visp_weights_load.argtypes = [c_char_p, POINTER(c_void_p)]
+    lib.visp_weights_create.argtypes = [POINTER(c_void_p)]
+    lib.visp_weights_add.argtypes = [c_void_p, c_char_p, c_int32, POINTER(c_int64), c_void_p]
+    lib.visp_weights_destroy.argtypes = [c_void_p]
     lib.visp_graph_add_weight.argtypes = [c_void_p, c_char_p, c_int32, POINTER(c_int64), c_void_p, POINTER(c_int32)]
     lib.visp_graph_find_weight.argtypes = [c_void_p, c_char_p, POINTER(c_int32)]
     lib.visp_graph_input.argtypes = [c_void_p, c_int32, POINTER(c_int64), c_char_p, POINTER(c_int32)]
@@ -235,7 +239,7 @@ def init() -> ctypes.CDLL:
     lib.visp_graph_output.argtypes = [c_void_p, c_int32, c_char_p]
     lib.visp_graph_tensor_info.argtypes = [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int64), POINTER(c_int32)]
     lib.visp_graph_read_constant.argtypes = [c_void_p, c_int32, c_void_p, c_int64]
-    lib.visp_graph_allocate.argtypes = [c_void_p]
+    lib.visp_graph_allocate.argtypes = [c_void_p, c_void_p]
     lib.visp_graph_use_hip_graph.argtypes = [c_void_p, c_int32]
     lib.visp_graph_compute.argtypes = [c_void_p]
     lib.visp_graph_tensor_set.argtypes = [c_void_p, c_int32, c_void_p, c_size_t]
@@ -245,6 +249,7 @@ def init() -> ctypes.CDLL:
         getattr(lib, name).restype = c_int32
     lib.visp_depthany_pipeline_destroy.restype = None
     lib.visp_graph_destroy.restype = None
+    lib.visp_weights_destroy.restype = None
 
     lib.vx_last_error.restype = c_char_p
     lib.vx_device_info.argtypes = [c_int, c_char_p, c_int, c_char_p, c_int, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_int)]

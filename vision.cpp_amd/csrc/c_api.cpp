@@ -26,6 +26,7 @@ using namespace visp;
 struct visp_image_data : image_data {};
 struct visp_device : backend_device {};
 struct visp_graph : graph {};
+struct visp_weights { std::shared_ptr<weight_store> store; };
 // visp_model stays opaque: handles are depthany_model* (any_model in the reference, c-api.cpp:193)
 
 namespace {
@@ -720,10 +721,30 @@ int32_t visp_swin_read_timing(visp_model* m, visp_timing* out, int32_t cap, int3
 
 // ---- graph layer (graph.h) ----
 
-int32_t visp_graph_create(visp_device const* dev, visp_graph** out) {
+int32_t visp_weights_load(char const* gguf_path, visp_weights** out) {
+    return handle_errors([&]() {
+        if (!out) throw except("visp_weights_load: null out pointer");
+        *out = new visp_weights{weights_load(gguf_path)};
+    });
+}
+int32_t visp_weights_create(visp_weights** out) {
+    return handle_errors([&]() {
+        if (!out) throw except("visp_weights_create: null out pointer");
+        *out = new visp_weights{weights_create()};
+    });
+}
+int32_t visp_weights_add(visp_weights* w, char const* name, int32_t dtype, int64_t const ne[4], float const* data) {
+    return handle_errors([&]() {
+        if (!w) throw except("weights handle is null");
+        weights_add(*w->store, name, dtype, ne, data);
+    });
+}
+void visp_weights_destroy(visp_weights* w) { delete w; }
+
+int32_t visp_graph_create(visp_weights* weights, visp_graph** out) {
     return handle_errors([&]() {
         if (!out) throw except("visp_graph_create: null out pointer");
-        *out = static_cast<visp_graph*>(graph_create(dev));
+        *out = static_cast<visp_graph*>(graph_create(weights ? weights->store : nullptr));
     });
 }
 void visp_graph_destroy(visp_graph* g) { delete static_cast<graph*>(g); }
@@ -737,17 +758,14 @@ static graph const& as_cgraph(visp_graph const* g) {
     return *g;
 }
 
-int32_t visp_graph_load_weights(visp_graph* g, char const* gguf_path) {
-    return handle_errors([&]() { graph_load_weights(as_graph(g), gguf_path); });
-}
 int32_t visp_graph_add_weight(visp_graph* g, char const* name, int32_t dtype, int64_t const ne[4], float const* data, int32_t* out) {
     return handle_errors([&]() {
         const int t = graph_add_weight(as_graph(g), name, dtype, ne, data);
         if (out) *out = t;
     });
 }
-int32_t visp_graph_find_weight(visp_graph const* g, char const* name, int32_t* out) {
-    return handle_errors([&]() { *out = graph_find_weight(as_cgraph(g), name); });
+int32_t visp_graph_find_weight(visp_graph* g, char const* name, int32_t* out) {
+    return handle_errors([&]() { *out = graph_find_weight(as_graph(g), name); });
 }
 int32_t visp_graph_input(visp_graph* g, int32_t dtype, int64_t const ne[4], char const* name, int32_t* out) {
     return handle_errors([&]() { *out = graph_input(as_graph(g), dtype, ne, name); });
@@ -759,8 +777,8 @@ int32_t visp_graph_op(visp_graph* g, int32_t op, int32_t const* src, int32_t n_s
 int32_t visp_graph_set_name(visp_graph* g, int32_t tensor, char const* name) {
     return handle_errors([&]() { graph_set_name(as_graph(g), tensor, name); });
 }
-int32_t visp_graph_get_tensor(visp_graph const* g, char const* name, int32_t* out) {
-    return handle_errors([&]() { *out = graph_get_tensor(as_cgraph(g), name); });
+int32_t visp_graph_get_tensor(visp_graph* g, char const* name, int32_t* out) {
+    return handle_errors([&]() { *out = graph_get_tensor(as_graph(g), name); });
 }
 int32_t visp_graph_output(visp_graph* g, int32_t tensor, char const* name) {
     return handle_errors([&]() { graph_output(as_graph(g), tensor, name); });
@@ -782,11 +800,11 @@ int32_t visp_graph_read_constant(visp_graph const* g, int32_t tensor, float* out
         graph_node const& n = gr.nodes[tensor];
         if (!n.constant) throw except("visp_graph_read_constant: tensor %d is not a constant", tensor);
         if (capacity < n.n_elements()) throw except("visp_graph_read_constant: capacity %lld < %lld elements", (long long)capacity, (long long)n.n_elements());
-        memcpy(out, n.host.data(), (size_t)n.n_elements() * 4);
+        memcpy(out, n.values(), (size_t)n.n_elements() * 4);
     });
 }
-int32_t visp_graph_allocate(visp_graph* g) {
-    return handle_errors([&]() { graph_allocate(as_graph(g)); });
+int32_t visp_graph_allocate(visp_graph* g, visp_device const* dev) {
+    return handle_errors([&]() { graph_allocate(as_graph(g), dev); });
 }
 int32_t visp_graph_use_hip_graph(visp_graph* g, int32_t enable) {
     return handle_errors([&]() { as_graph(g).use_hip_graph = enable != 0; });

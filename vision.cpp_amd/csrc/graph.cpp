@@ -124,18 +124,18 @@ void fold_constant(graph& g, graph_node& n) {
     float* out = n.host.data();
     switch (n.op) {
         case gop_reshape:
-        case gop_cont: n.host = src(0).host; break;
+        case gop_cont: n.host.assign(src(0).values(), src(0).values() + total); break;
         case gop_scale:
-            for (int64_t i = 0; i < total; ++i) out[i] = src(0).host[i] * n.fp[0];
+            for (int64_t i = 0; i < total; ++i) out[i] = src(0).values()[i] * n.fp[0];
             break;
         case gop_add:
         case gop_mul: {
             const int64_t period = src(1).n_elements();
-            const float *a = src(0).host.data(), *b = src(1).host.data();
+            const float *a = src(0).values(), *b = src(1).values();
             for (int64_t i = 0; i < total; ++i) out[i] = n.op == gop_add ? a[i] + b[i % period] : a[i] * b[i % period];
         } break;
         case gop_slice: {
-            host_view v{src(0).host.data(), src(0).ne};
+            host_view v{src(0).values(), src(0).ne};
             int64_t o = 0;
             for (int64_t i3 = 0; i3 < n.ne[3]; ++i3)
                 for (int64_t i2 = 0; i2 < n.ne[2]; ++i2)
@@ -144,7 +144,7 @@ void fold_constant(graph& g, graph_node& n) {
                             out[o++] = v.at(n.ip[0] + i0 * n.ip[2], n.ip[3] + i1 * n.ip[5], n.ip[6] + i2 * n.ip[8], n.ip[9] + i3 * n.ip[11]);
         } break;
         case gop_repeat: {
-            host_view v{src(0).host.data(), src(0).ne};
+            host_view v{src(0).values(), src(0).ne};
             int64_t o = 0;
             for (int64_t i3 = 0; i3 < n.ne[3]; ++i3)
                 for (int64_t i2 = 0; i2 < n.ne[2]; ++i2)
@@ -153,7 +153,7 @@ void fold_constant(graph& g, graph_node& n) {
         } break;
         case gop_concat: {
             const int dim = (int)n.ip[0];
-            host_view a{src(0).host.data(), src(0).ne}, b{src(1).host.data(), src(1).ne};
+            host_view a{src(0).values(), src(0).ne}, b{src(1).values(), src(1).ne};
             int64_t o = 0;
             for (int64_t i3 = 0; i3 < n.ne[3]; ++i3)
                 for (int64_t i2 = 0; i2 < n.ne[2]; ++i2)
@@ -166,8 +166,8 @@ void fold_constant(graph& g, graph_node& n) {
         } break;
         case gop_interpolate: {
             const int mode = (int)n.ip[2];
-            if ((mode & 255) == 2 && !(mode & 256)) host_bicubic(src(0).host.data(), src(0).ne, out, n.ip[0], n.ip[1]);
-            else if ((mode & 255) == 1 && (mode & 256)) host_bilinear_ac(src(0).host.data(), src(0).ne, out, n.ip[0], n.ip[1]);
+            if ((mode & 255) == 2 && !(mode & 256)) host_bicubic(src(0).values(), src(0).ne, out, n.ip[0], n.ip[1]);
+            else if ((mode & 255) == 1 && (mode & 256)) host_bilinear_ac(src(0).values(), src(0).ne, out, n.ip[0], n.ip[1]);
             else throw except("interpolate: mode %d is not built (bicubic, and bilinear | align_corners, are)", mode);
         } break;
         default: throw except("graph: %s on constants is not folded", graph_op_name(n.op));
@@ -192,44 +192,34 @@ graph::~graph() {
     if (arena.ptr) vx_free(arena.ptr);
     for (void* p : const_allocs) vx_free(p);
 }
-
-graph* graph_create(backend_device const* dev) {
-    graph* g = new graph;
-    g->dev = dev;
-    return g;
+weight_store::~weight_store() {
+    for (void* p : allocs) vx_free(p);
 }
 
-static void require_building(graph const& g, const char* what) {
-    if (g.allocated) throw except("%s: the graph is already allocated (build a new one)", what);
-}
+std::shared_ptr<weight_store> weights_create() { return std::make_shared<weight_store>(); }
 
-int graph_add_weight(graph& g, char const* name, int32_t dtype, const int64_t ne[4], const float* data) {
-    require_building(g, "graph_add_weight");
-    if (!name || !*name) throw except("graph_add_weight: a weight needs a name");
-    if (g.weights.count(name)) throw except("graph_add_weight: '%s' exists already", name);
-    graph_node n;
-    n.op = gop_weight;
-    n.dtype = dtype == gdt_f32 ? gdt_f32 : gdt_f16;
+void weights_add(weight_store& ws, char const* name, int32_t dtype, const int64_t ne[4], const float* data) {
+    if (!name || !*name) throw except("weights: a tensor needs a name");
+    if (ws.tensors.count(name)) throw except("weights: '%s' exists already", name);
+    if (ws.dev) throw except("weights: '%s' added after a graph over these weights was allocated", name);
+    weight_store::entry e;
+    e.dtype = dtype == gdt_f32 ? gdt_f32 : gdt_f16;
+    int64_t n = 1;
     for (int i = 0; i < 4; ++i) {
-        if (ne[i] <= 0) throw except("graph_add_weight: '%s' has a non-positive extent", name);
-        n.ne[i] = ne[i];
+        if (ne[i] <= 0) throw except("weights: '%s' has a non-positive extent", name);
+        e.ne[i] = ne[i];
+        n *= ne[i];
     }
-    n.name = name;
-    n.constant = true;
-    if (data) n.host.assign(data, data + n.n_elements());
-    else n.host.assign((size_t)n.n_elements(), 0.0f);
-    g.nodes.push_back(std::move(n));
-    const int id = (int)g.nodes.size() - 1;
-    g.weights.emplace(name, id);
-    return id;
+    if (data) e.data.assign(data, data + n);
+    else e.data.assign((size_t)n, 0.0f);
+    ws.tensors.emplace(name, std::move(e));
 }
 
-void graph_load_weights(graph& g, char const* path) {
-    require_building(g, "graph_load_weights");
-    g.file = std::make_unique<model_file>(model_load(path));
-    model_file const& f = *g.file;
-    g.file_whcn = f.tensor_layout() == layout_whcn;
-    g.conv2d = f.conv2d_weights();
+std::shared_ptr<weight_store> weights_load(char const* path) {
+    auto ws = weights_create();
+    model_file f = model_load(path);
+    const bool file_whcn = f.tensor_layout() == layout_whcn;
+    std::vector<int32_t> conv2d = f.conv2d_weights();
     std::vector<float> tmp, perm;
     for (int idx = 0; idx < (int)f.tensors.size(); ++idx) {
         gguf_tensor const& t = f.tensors[idx];
@@ -241,7 +231,7 @@ void graph_load_weights(graph& g, char const* path) {
             for (int64_t i = 0; i < n; ++i) tmp[i] = f16_to_f32(reinterpret_cast<const uint16_t*>(t.data)[i]);
         int64_t ne[4] = {t.ne[0], t.ne[1], t.ne[2], t.ne[3]};
         const float* data = tmp.data();
-        if (g.file_whcn && std::binary_search(g.conv2d.begin(), g.conv2d.end(), idx)) {
+        if (file_whcn && std::binary_search(conv2d.begin(), conv2d.end(), idx)) {
             // torch OIHW (ne [kw, kh, Cin, Cout]) -> OHWI (ne [Cin, kw, kh, Cout]): what model_transfer does for a cwhn backend (ml.cpp:449-498)
             const int64_t kw = ne[0], kh = ne[1], ci = ne[2], co = ne[3];
             perm.resize((size_t)n);
@@ -252,13 +242,45 @@ void graph_load_weights(graph& g, char const* path) {
             ne[0] = ci; ne[1] = kw; ne[2] = kh; ne[3] = co;
             data = perm.data();
         }
-        graph_add_weight(g, t.name.c_str(), t.type, ne, data);
+        weights_add(*ws, t.name.c_str(), t.type, ne, data);
     }
+    return ws;
 }
 
-int graph_find_weight(graph const& g, char const* name) {
-    auto it = g.weights.find(std::string_view(name ? name : ""));
-    return it == g.weights.end() ? -1 : it->second;
+graph* graph_create(std::shared_ptr<weight_store> weights) {
+    graph* g = new graph;
+    g->store = weights ? std::move(weights) : weights_create();
+    return g;
+}
+
+static void require_building(graph const& g, const char* what) {
+    if (g.allocated) throw except("%s: the graph is already allocated (build a new one)", what);
+}
+
+int graph_find_weight(graph& g, char const* name) {
+    std::string_view key(name ? name : "");
+    auto it = g.weights.find(key);
+    if (it != g.weights.end()) return it->second;
+    auto st = g.store->tensors.find(key);
+    if (st == g.store->tensors.end()) return -1;
+    require_building(g, "model_ref::find");
+    graph_node n;
+    n.op = gop_weight;
+    n.dtype = st->second.dtype;
+    for (int i = 0; i < 4; ++i) n.ne[i] = st->second.ne[i];
+    n.name = st->first;
+    n.constant = true;
+    n.cdata = st->second.data.data(); // std::map nodes do not move
+    g.nodes.push_back(std::move(n));
+    const int id = (int)g.nodes.size() - 1;
+    g.weights.emplace(st->first, id);
+    return id;
+}
+
+int graph_add_weight(graph& g, char const* name, int32_t dtype, const int64_t ne[4], const float* data) {
+    require_building(g, "graph_add_weight");
+    weights_add(*g.store, name, dtype, ne, data);
+    return graph_find_weight(g, name);
 }
 
 int graph_input(graph& g, int32_t dtype, const int64_t ne[4], char const* name) {
@@ -284,7 +306,7 @@ void graph_set_name(graph& g, int t, char const* name) {
     if (name && *name) g.named[name] = t;
 }
 
-int graph_get_tensor(graph const& g, char const* name) {
+int graph_get_tensor(graph& g, char const* name) {
     auto it = g.named.find(std::string_view(name ? name : ""));
     if (it != g.named.end()) return it->second;
     return graph_find_weight(g, name);
@@ -485,7 +507,7 @@ struct lowering {
     std::vector<std::vector<int>> consumers;
     std::vector<char> relu_on_load;
     std::vector<std::pair<std::vector<int>, std::vector<int>>> io; // per launch: buffers read, buffers written
-    std::map<std::pair<int, int>, void*> const_cache;              // (node, role) -> device copy
+    std::map<std::pair<int, int>, void*> const_cache;              // (node, role) -> device copy of a constant folded in this graph
 
     explicit lowering(graph& gr) : g(gr) {}
 
@@ -520,32 +542,43 @@ struct lowering {
         return [gp, buf]() { return static_cast<char*>(gp->arena.ptr) + gp->buffers[buf].offset; };
     }
 
-    void* upload(const void* host, size_t bytes) {
+    // device image of constant t in `role`: model weights are cached in the weight store (shared by every graph over the model),
+    // constants folded inside this graph belong to the graph
+    void* cached(int t, int role, std::function<void*(bool)> make) {
+        auto key = std::make_pair(t, role);
+        auto it = const_cache.find(key);
+        if (it != const_cache.end()) return it->second;
+        graph_node const& n = g.nodes[t];
+        void* d = nullptr;
+        if (n.op == gop_weight && g.dev) {
+            auto skey = std::make_pair(n.name, role);
+            auto sit = g.store->packs.find(skey);
+            if (sit != g.store->packs.end()) d = sit->second; // uploaded by an earlier graph over the same weights
+            else { d = make(true); g.store->packs[skey] = d; }
+        } else d = make(false);
+        const_cache[key] = d;
+        return d;
+    }
+    void* upload(const void* host, size_t bytes, bool to_store) {
         g.const_bytes += bytes;
         if (!g.dev) return nullptr;
         void* d = nullptr;
         VX(vx_malloc(&d, bytes + 256));
-        g.const_allocs.push_back(d);
+        if (to_store) { g.store->allocs.push_back(d); g.store->device_bytes += bytes; }
+        else g.const_allocs.push_back(d);
         VX(vx_memcpy_h2d(d, host, bytes, g.dev->stream));
+        VX(vx_stream_sync(g.dev->stream)); // the host image is a temporary
         return d;
     }
     float* const_f32(int t) {
-        auto key = std::make_pair(t, 0);
-        auto it = const_cache.find(key);
-        if (it != const_cache.end()) return static_cast<float*>(it->second);
-        void* d = upload(g.nodes[t].host.data(), g.nodes[t].host.size() * 4);
-        const_cache[key] = d;
-        return static_cast<float*>(d);
+        return static_cast<float*>(cached(t, 0, [&](bool st) { return upload(g.nodes[t].values(), (size_t)g.nodes[t].n_elements() * 4, st); }));
     }
     void* const_f16(int t) {
-        auto key = std::make_pair(t, 1);
-        auto it = const_cache.find(key);
-        if (it != const_cache.end()) return it->second;
-        std::vector<uint16_t> h(g.nodes[t].host.size());
-        for (size_t i = 0; i < h.size(); ++i) h[i] = f32_to_f16(g.nodes[t].host[i]);
-        void* d = upload(h.data(), h.size() * 2);
-        const_cache[key] = d;
-        return d;
+        return cached(t, 1, [&](bool st) {
+            std::vector<uint16_t> h((size_t)g.nodes[t].n_elements());
+            for (size_t i = 0; i < h.size(); ++i) h[i] = f32_to_f16(g.nodes[t].values()[i]);
+            return upload(h.data(), h.size() * 2, st);
+        });
     }
     // rows [n][k] -> f16 [N pad][K pad 64] + f32 bias [N pad] (bias of `period` elements repeated)
     packed_operand pack_matrix(int wt, int role, int n, int k, std::function<float(int, int)> at, int bias_t, int bias_period) {
@@ -553,39 +586,30 @@ struct lowering {
         p.n_real = n; p.k_real = k;
         p.N = round_up(n, n > 64 ? 64 : 32);
         p.K = round_up(k, 64);
-        auto key = std::make_pair(wt, role);
-        auto it = const_cache.find(key);
-        if (it != const_cache.end()) p.w = it->second;
-        else {
+        p.w = cached(wt, role, [&](bool st) {
             std::vector<uint16_t> h((size_t)p.N * p.K, 0);
             for (int r = 0; r < n; ++r)
                 for (int c = 0; c < k; ++c) h[(size_t)r * p.K + c] = f32_to_f16(at(r, c));
-            p.w = upload(h.data(), h.size() * 2);
-            const_cache[key] = p.w;
-        }
-        if (bias_t >= 0) {
-            auto bkey = std::make_pair(bias_t, 16 + role);
-            auto bit = const_cache.find(bkey);
-            if (bit != const_cache.end()) p.bias = static_cast<float*>(bit->second);
-            else {
+            return upload(h.data(), h.size() * 2, st);
+        });
+        if (bias_t >= 0)
+            p.bias = static_cast<float*>(cached(bias_t, 16 + role, [&](bool st) {
                 std::vector<float> b((size_t)p.N, 0.0f);
-                for (int r = 0; r < n; ++r) b[r] = g.nodes[bias_t].host[r % bias_period];
-                p.bias = static_cast<float*>(upload(b.data(), b.size() * 4));
-                const_cache[bkey] = p.bias;
-            }
-        }
+                for (int r = 0; r < n; ++r) b[r] = g.nodes[bias_t].values()[r % bias_period];
+                return upload(b.data(), b.size() * 4, st);
+            }));
         return p;
     }
     packed_operand pack_rows(int wt, int bias_t, int n) { // linear [K, N] and conv [Cin, kw, kh, Cout]: the n rows of the host image as they are
         graph_node const& w = g.nodes[wt];
         const int k = (int)(w.n_elements() / n);
-        const float* h = w.host.data();
+        const float* h = w.values();
         return pack_matrix(wt, 2, n, k, [h, k](int r, int c) { return h[(size_t)r * k + c]; }, bias_t, n);
     }
     packed_operand pack_conv_transpose(int wt, int bias_t, int s) { // ne [kw, kh, Cout, Cin]: row (dy * s + dx) * Cout + co, column ci
         graph_node const& w = g.nodes[wt];
         const int kw = (int)w.ne[0], kh = (int)w.ne[1], cout = (int)w.ne[2], cin = (int)w.ne[3];
-        const float* h = w.host.data();
+        const float* h = w.values();
         return pack_matrix(wt, 3, s * s * cout, cin,
                            [=](int r, int c) {
                                const int tap = r / cout, co = r % cout, dy = tap / s, dx = tap % s;
@@ -660,7 +684,7 @@ struct lowering {
             if (f == last) break;
         }
         const float* w = const_f32(n.src[1]);
-        const float bias = n.n_src == 3 ? g.nodes[n.src[2]].host[0] : 0.0f;
+        const float bias = n.n_src == 3 ? g.nodes[n.src[2]].values()[0] : 0.0f;
         const int xbuf = buf_of(n.src[0]);
         materialise(t);
         const int obuf = n.buffer;
@@ -1035,8 +1059,13 @@ struct lowering {
 
 } // namespace
 
-void graph_allocate(graph& g) {
+void graph_allocate(graph& g, backend_device const* dev) {
     if (g.allocated) return;
+    g.dev = dev;
+    if (dev) {
+        if (g.store->dev && g.store->dev != dev) throw except("compute_graph_allocate: the weights of this graph live on another device");
+        g.store->dev = dev;
+    }
     lowering low(g);
     low.run();
     if (g.dev) {

@@ -64,7 +64,9 @@ struct graph_node {
     std::string name;
     bool is_output = false;
     bool constant = false;        // a weight, or computed from weights alone: evaluated on the host when the node is made
-    std::vector<float> host;      // constants: the values
+    std::vector<float> host;      // folded constants: the values
+    const float* cdata = nullptr; // weights: the values live in the weight store
+    const float* values() const { return cdata ? cdata : host.data(); }
     // filled by graph_allocate
     int alias_of = -1;            // shares the buffer of that node (views, fused activations)
     int buffer = -1;              // index into graph::buffers (materialised nodes)
@@ -83,14 +85,33 @@ struct graph_launch {
     std::function<void(void* stream)> run;
 };
 
+// model_weights (ml.h:126-149): the tensors of a model by name, f32 on the host, and -- once a graph over them has been allocated on a
+// device -- their packed device images per consumer role (GEMM operand, pixel-shuffle rows, f32 vector, ...). Shared by every graph built
+// over the model: rebuilding the graph for another input extent (the reference's lazy graph build, vision.cpp:150-158) uploads nothing.
+struct weight_store {
+    struct entry {
+        int32_t dtype = gdt_f16;
+        int64_t ne[4] = {1, 1, 1, 1};
+        std::vector<float> data;
+    };
+    std::map<std::string, entry, std::less<>> tensors;
+    backend_device const* dev = nullptr;                    // bound by the first graph_allocate with a device
+    std::map<std::pair<std::string, int>, void*> packs;     // (name, role) -> device image
+    std::vector<void*> allocs;
+    size_t device_bytes = 0;
+    ~weight_store();
+};
+std::shared_ptr<weight_store> weights_create();
+// all f16 / f32 tensors of a GGUF file (conv kernels listed in <arch>.conv2d_weights of a whcn file are presented as CWHN)
+std::shared_ptr<weight_store> weights_load(char const* gguf_path);
+void weights_add(weight_store&, char const* name, int32_t dtype, const int64_t ne[4], const float* data);
+
 struct graph {
     backend_device const* dev = nullptr; // null: build / fold / plan only (no device work; the CPU tests)
+    std::shared_ptr<weight_store> store;
     std::vector<graph_node> nodes;
-    std::map<std::string, int, std::less<>> weights; // name -> node
+    std::map<std::string, int, std::less<>> weights; // name -> node (made when first looked up)
     std::map<std::string, int, std::less<>> named;   // graph_set_name, inputs, outputs
-    std::unique_ptr<model_file> file;
-    bool file_whcn = false;
-    std::vector<int32_t> conv2d;
 
     bool allocated = false;
     std::vector<graph_buffer> buffers;
@@ -104,17 +125,15 @@ struct graph {
     ~graph();
 };
 
-graph* graph_create(backend_device const* dev);
-// all tensors of a GGUF file become weights (conv kernels listed in <arch>.conv2d_weights of a whcn file are presented as CWHN)
-void graph_load_weights(graph&, char const* gguf_path);
+graph* graph_create(std::shared_ptr<weight_store> weights); // null: the graph gets a store of its own (graph_add_weight)
 int graph_add_weight(graph&, char const* name, int32_t dtype, const int64_t ne[4], const float* data);
-int graph_find_weight(graph const&, char const* name); // -1 if absent
+int graph_find_weight(graph&, char const* name); // -1 if absent
 int graph_input(graph&, int32_t dtype, const int64_t ne[4], char const* name);
 int graph_add(graph&, int32_t op, const int* src, int n_src, const int64_t* ip, int n_ip, const float* fp, int n_fp);
 void graph_set_name(graph&, int t, char const* name);
-int graph_get_tensor(graph const&, char const* name); // -1 if absent
+int graph_get_tensor(graph&, char const* name); // -1 if absent
 void graph_output(graph&, int t, char const* name);
-void graph_allocate(graph&);
+void graph_allocate(graph&, backend_device const* dev); // dev == null: lower and plan only
 void graph_compute(graph&);
 void graph_tensor_set(graph&, int t, const void* data, size_t bytes);            // the tensor's own dtype
 void graph_tensor_get(graph&, int t, void* data, size_t bytes, bool as_f32);     // as_f32: converted on the host

@@ -52,14 +52,38 @@ class Tensor:
         return f"Tensor({self.index}, ne={self.ne})"
 
 
-class Graph:
-    """`compute_graph` + the weights it is built over. `device=None` makes a planning-only graph (no GPU needed)."""
+class Weights:
+    """`model_weights` (ml.h:126-149): a model's tensors by name. Device images are made by the first graph that uses a tensor and shared
+    by every later graph over the same weights."""
 
-    def __init__(self, device=None):
+    def __init__(self, path=None):
         self._api = get_lib()
-        self._device = device  # keep the device alive
         h = c_void_p()
-        check(self._api.visp_graph_create(device._handle if device is not None else None, byref(h)))
+        if path is None:
+            check(self._api.visp_weights_create(byref(h)))
+        else:
+            check(self._api.visp_weights_load(lib.path_to_char_p(path), byref(h)))
+        self._handle = h
+
+    def add(self, name: str, array: np.ndarray, dtype: int = F16):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        check(self._api.visp_weights_add(self._handle, name.encode(), dtype, (c_int64 * 4)(*_ne(a.shape[::-1])), a.ctypes.data_as(c_void_p)))
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            self._api.visp_weights_destroy(self._handle)
+            self._handle = None
+
+
+class Graph:
+    """`compute_graph` over a model's weights. `device=None`: lower and plan only (no GPU needed)."""
+
+    def __init__(self, device=None, weights: Weights | None = None):
+        self._api = get_lib()
+        self._device = device  # kept alive; bound when the graph is allocated (compute_graph_allocate(graph, backend))
+        self._weights = weights
+        h = c_void_p()
+        check(self._api.visp_graph_create(weights._handle if weights is not None else None, byref(h)))
         self._handle = h
 
     def __del__(self):
@@ -68,9 +92,6 @@ class Graph:
             self._handle = None
 
     # ---- weights
-    def load_weights(self, path):
-        check(self._api.visp_graph_load_weights(self._handle, lib.path_to_char_p(path)))
-
     def add_weight(self, name: str, array: np.ndarray, dtype: int = F16) -> Tensor:
         """`array` in torch / numpy index order (slowest first): its reversed shape is the ggml ne."""
         a = np.ascontiguousarray(array, dtype=np.float32)
@@ -125,7 +146,7 @@ class Graph:
 
     # ---- execution
     def allocate(self):
-        check(self._api.visp_graph_allocate(self._handle))
+        check(self._api.visp_graph_allocate(self._handle, self._device._handle if self._device is not None else None))
 
     def use_hip_graph(self, enable: bool = True):
         check(self._api.visp_graph_use_hip_graph(self._handle, 1 if enable else 0))
