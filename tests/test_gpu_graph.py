@@ -68,7 +68,8 @@ def test_linear_layer_norm_gelu_mul_add(device):
     ref_h = F.gelu(F.linear(t(h(ref_ln.numpy())), tw["fc1.weight"], tw["fc1.bias"]), approximate="tanh")
     ref_y = t(x) + F.linear(t(h(ref_h.numpy())), tw["fc2.weight"], tw["fc2.bias"]) * tw["ls.lambda1"]
     assert rel(got_y, ref_y.numpy()) < 3e-3
-    assert g.describe().splitlines()[1].startswith("gemm[gelu]")
+    lines = g.describe().splitlines()
+    assert lines[1].startswith("gemm[gelu]") and lines[2].startswith("gemm[*scale][+res]")  # layer scale folded into fc2, residual in its epilogue
 
 
 @pytest.mark.parametrize("T,B,heads", [(50, 2, 2), (257, 1, 6), (1370, 1, 6)])
@@ -87,6 +88,20 @@ def test_attention_node(device, T, B, heads):
     q, k, v = (G.reshape(m, G.linear(m[n], xi), 64, heads, T, B) for n in ("query", "key", "value"))
     y = g.output(G.attention(m, q, k, v, None, 1 / 8, m["dense"]), "y")
     (got,) = run(g, {xi: x}, [y])
+    assert g.describe().splitlines()[0].startswith("gemm[qkv heads-major]")  # the three projections of one input: one launch
+    # the same attention with q also read by an output: the projections stay three products + three head-major copies
+    g2 = G.Graph(device)
+    for n in ws:
+        g2.add_weight(f"{n}.weight", ws[n]); g2.add_weight(f"{n}.bias", bs[n], G.F32)
+    m2 = G.ModelRef(g2)
+    xi2 = g2.input((C, T, B), G.F16)
+    lq = G.linear(m2["query"], xi2)
+    g2.output(lq, "q")
+    q2, k2, v2 = G.reshape(m2, lq, 64, heads, T, B), *(G.reshape(m2, G.linear(m2[n], xi2), 64, heads, T, B) for n in ("key", "value"))
+    y2 = g2.output(G.attention(m2, q2, k2, v2, None, 1 / 8, m2["dense"]), "y")
+    (got2,) = run(g2, {xi2: x}, [y2])
+    assert g2.describe().count("heads_major") == 3
+    assert rel(got2, got) < 2e-3
     tq, tk, tv = (t(h(F.linear(t(x), t(ws[n]), t(bs[n])).numpy())).reshape(B, T, heads, 64).transpose(1, 2) for n in ("query", "key", "value"))
     att = torch.softmax(tq @ tk.transpose(-1, -2) / 8, -1) @ tv
     ref = F.linear(t(h(att.transpose(1, 2).reshape(B, T, C).numpy())), t(ws["dense"]), t(bs["dense"]))

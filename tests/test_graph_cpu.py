@@ -96,16 +96,21 @@ def planned(tmp_path_factory):
 
 
 def test_depth_anything_lowers_to_fused_launches(planned):
-    """572 graph nodes (weights included) lower to 247 launches: activations, ReLU-on-load and conv residuals are epilogues and loader
-    flags of the matrix kernels, views cost nothing, everything computed from weights alone was folded when the node was made."""
+    """567 graph nodes (weights included) lower to 139 launches, 7 per encoder layer: the three q / k / v products of an attention are one
+    GEMM with a head-major epilogue, LayerScale is folded into the packed weights so the residual rides in the product's epilogue,
+    activations, ReLU-on-load and conv residuals are epilogues and loader flags, views cost nothing, and everything computed from weights
+    alone was folded when the node was made."""
     g, img, out = planned
     lines = g.describe().strip().splitlines()
     s = g.summary()
-    assert s["launches"] == len(lines) - 1 == 247
+    assert s["launches"] == len(lines) - 1 == 139
     text = "\n".join(lines)
+    assert text.count("gemm[qkv heads-major] M=2740 N=1152 K=384") == 12  # query | key | value (dino.cpp:59-70): one product
+    assert text.count("gemm[*scale][+res]") == 24                # out-proj and fc2 with layer_scale + residual (dino.cpp:48-50, 80-87)
+    assert not any(l.startswith(("mul", "heads_major")) for l in lines)
     assert text.count("gemm[gelu]") == 12                       # fc1 + gelu (dino.cpp:52-56)
     assert text.count("attention B=2 heads=6 T=1370") == 12
-    assert text.count("[relu-in][relu]") == 7 and text.count("[+res]") == 7  # residual_conv x 7 (depth-anything.cpp:15-23): two launches each
+    assert text.count("[relu-in][relu]") == 7 and text.count("conv3x3[+res]") == 7  # residual_conv x 7 (depth-anything.cpp:15-23): two launches each
     assert text.count("gemm+pixel_shuffle") == 2                 # conv_transpose k == s (nn.cpp:117-129)
     assert "conv3x3s2 M=722 N=384 K=3456" in text                # reassemble 3: 3x3 stride 2 on 37 x 37
     assert lines[-2].startswith("conv1x1_to_1[relu] M=536648 C=32")  # head.conv3 + relu, f32

@@ -507,7 +507,7 @@ struct lowering {
     std::vector<std::vector<int>> consumers;
     std::vector<char> relu_on_load;
     std::vector<std::pair<std::vector<int>, std::vector<int>>> io; // per launch: buffers read, buffers written
-    std::map<std::pair<int, int>, void*> const_cache;              // (node, role) -> device copy of a constant folded in this graph
+    std::map<std::pair<std::pair<int, int>, std::string>, void*> const_cache; // (node, role, derived-from) -> device copy made for this graph
 
     explicit lowering(graph& gr) : g(gr) {}
 
@@ -544,14 +544,16 @@ struct lowering {
 
     // device image of constant t in `role`: model weights are cached in the weight store (shared by every graph over the model),
     // constants folded inside this graph belong to the graph
-    void* cached(int t, int role, std::function<void*(bool)> make) {
-        auto key = std::make_pair(t, role);
+    // `with`: names of the other weights a derived image was made from (a folded LayerScale vector, the k and v parts of a fused
+    // q|k|v operand) -- part of its identity
+    void* cached(int t, int role, std::function<void*(bool)> make, std::string const& with = {}) {
+        auto key = std::make_pair(std::make_pair(t, role), with);
         auto it = const_cache.find(key);
         if (it != const_cache.end()) return it->second;
         graph_node const& n = g.nodes[t];
         void* d = nullptr;
         if (n.op == gop_weight && g.dev) {
-            auto skey = std::make_pair(n.name, role);
+            auto skey = std::make_pair(with.empty() ? n.name : n.name + "|" + with, role);
             auto sit = g.store->packs.find(skey);
             if (sit != g.store->packs.end()) d = sit->second; // uploaded by an earlier graph over the same weights
             else { d = make(true); g.store->packs[skey] = d; }
@@ -581,30 +583,64 @@ struct lowering {
         });
     }
     // rows [n][k] -> f16 [N pad][K pad 64] + f32 bias [N pad] (bias of `period` elements repeated)
-    packed_operand pack_matrix(int wt, int role, int n, int k, std::function<float(int, int)> at, int bias_t, int bias_period) {
+    packed_operand pack_matrix(int wt, int role, int n, int k, std::function<float(int, int)> at, int bias_t, int bias_period, int scale_t = -1) {
         packed_operand p;
+        // LayerScale folded into the operand: W' = f16(lambda[n] * W[n, :]), b' = lambda[n] * b[n] (what csrc/depthany.cpp does for the
+        // block kernel: the product's epilogue can then take the residual)
+        const float* lam = scale_t >= 0 ? g.nodes[scale_t].values() : nullptr;
+        const std::string with = scale_t >= 0 ? "*" + (g.nodes[scale_t].name.empty() ? std::to_string(scale_t) : g.nodes[scale_t].name) : std::string();
         p.n_real = n; p.k_real = k;
         p.N = round_up(n, n > 64 ? 64 : 32);
         p.K = round_up(k, 64);
         p.w = cached(wt, role, [&](bool st) {
             std::vector<uint16_t> h((size_t)p.N * p.K, 0);
             for (int r = 0; r < n; ++r)
-                for (int c = 0; c < k; ++c) h[(size_t)r * p.K + c] = f32_to_f16(at(r, c));
+                for (int c = 0; c < k; ++c) h[(size_t)r * p.K + c] = f32_to_f16(lam ? lam[r] * at(r, c) : at(r, c));
             return upload(h.data(), h.size() * 2, st);
-        });
+        }, with);
         if (bias_t >= 0)
             p.bias = static_cast<float*>(cached(bias_t, 16 + role, [&](bool st) {
                 std::vector<float> b((size_t)p.N, 0.0f);
-                for (int r = 0; r < n; ++r) b[r] = g.nodes[bias_t].values()[r % bias_period];
+                for (int r = 0; r < n; ++r) b[r] = g.nodes[bias_t].values()[r % bias_period] * (lam ? lam[r] : 1.0f);
                 return upload(b.data(), b.size() * 4, st);
-            }));
+            }, with));
         return p;
     }
-    packed_operand pack_rows(int wt, int bias_t, int n) { // linear [K, N] and conv [Cin, kw, kh, Cout]: the n rows of the host image as they are
+    packed_operand pack_rows(int wt, int bias_t, int n, int scale_t = -1) { // linear [K, N] and conv [Cin, kw, kh, Cout]: the n rows of the host image as they are
         graph_node const& w = g.nodes[wt];
         const int k = (int)(w.n_elements() / n);
         const float* h = w.values();
-        return pack_matrix(wt, 2, n, k, [h, k](int r, int c) { return h[(size_t)r * k + c]; }, bias_t, n);
+        return pack_matrix(wt, 2, n, k, [h, k](int r, int c) { return h[(size_t)r * k + c]; }, bias_t, n, scale_t);
+    }
+    // q | k | v rows of three linears over the same input as one operand (N = 3 * heads * 64), for the head-major epilogue
+    packed_operand pack_qkv(const int lin[3]) {
+        graph_node const* w[3];
+        int bias[3];
+        std::string with;
+        for (int i = 0; i < 3; ++i) {
+            w[i] = &g.nodes[g.nodes[lin[i]].src[1]];
+            bias[i] = g.nodes[lin[i]].n_src == 3 ? g.nodes[lin[i]].src[2] : -1;
+            if (i) with += (i > 1 ? "|" : "") + w[i]->name;
+        }
+        const int k = (int)w[0]->ne[0], n1 = (int)w[0]->ne[1];
+        packed_operand p;
+        p.n_real = 3 * n1; p.k_real = k; p.N = 3 * n1; p.K = round_up(k, 64);
+        p.w = cached(g.nodes[lin[0]].src[1], 4, [&](bool st) {
+            std::vector<uint16_t> h((size_t)p.N * p.K, 0);
+            for (int i = 0; i < 3; ++i)
+                for (int r = 0; r < n1; ++r)
+                    for (int c = 0; c < k; ++c) h[((size_t)i * n1 + r) * p.K + c] = f32_to_f16(w[i]->values()[(size_t)r * k + c]);
+            return upload(h.data(), h.size() * 2, st);
+        }, with);
+        if (bias[0] >= 0 || bias[1] >= 0 || bias[2] >= 0)
+            p.bias = static_cast<float*>(cached(g.nodes[lin[0]].src[1], 20, [&](bool st) {
+                std::vector<float> b((size_t)p.N, 0.0f);
+                for (int i = 0; i < 3; ++i)
+                    if (bias[i] >= 0)
+                        for (int r = 0; r < n1; ++r) b[(size_t)i * n1 + r] = g.nodes[bias[i]].values()[r];
+                return upload(b.data(), b.size() * 4, st);
+            }, with));
+        return p;
     }
     packed_operand pack_conv_transpose(int wt, int bias_t, int s) { // ne [kw, kh, Cout, Cin]: row (dy * s + dx) * Cout + co, column ci
         graph_node const& w = g.nodes[wt];
@@ -622,12 +658,24 @@ struct lowering {
     int sole_consumer(int t) const { return uses[t] == 1 && !g.nodes[t].is_output && consumers[t].size() == 1 ? consumers[t][0] : -1; }
 
     // epilogue fusion behind a matrix product: [gelu | relu] then [+ residual]
-    struct epilogue { int act = 0; int res = -1; int last = -1; };
-    epilogue fuse_epilogue(int t, bool allow_gelu) {
+    struct epilogue { int act = 0; int res = -1; int last = -1; int scale = -1; };
+    epilogue fuse_epilogue(int t, bool allow_gelu, bool allow_scale = false) {
         epilogue e;
         e.last = t;
         int c = sole_consumer(t);
-        if (c >= 0 && ((g.nodes[c].op == gop_gelu && allow_gelu) || g.nodes[c].op == gop_relu)) {
+        if (allow_scale && c >= 0 && g.nodes[c].op == gop_mul) { // LayerScale behind a linear (dino.cpp:48-50): folded into the weights
+            graph_node const& mu = g.nodes[c];
+            const int v = root(mu.src[0]) == t ? mu.src[1] : mu.src[0];
+            if (g.nodes[v].constant && g.nodes[v].n_elements() == g.nodes[t].ne[0] && root(mu.src[0]) == t) {
+                e.scale = v;
+                skip[c] = 1;
+                g.nodes[c].alias_of = t;
+                if (g.nodes[c].is_output) g.nodes[t].is_output = true;
+                e.last = c;
+                c = sole_consumer(c);
+            }
+        }
+        if (e.scale < 0 && c >= 0 && ((g.nodes[c].op == gop_gelu && allow_gelu) || g.nodes[c].op == gop_relu)) {
             e.act = g.nodes[c].op == gop_gelu ? 1 : 2;
             skip[c] = 1;
             g.nodes[c].alias_of = t;
@@ -707,8 +755,11 @@ struct lowering {
         int xbuf = -1;
         std::string kind;
         bool conv = false;
+        epilogue e;
+        e.last = t;
         if (n.op == gop_linear) {
-            p = pack_rows(wt, bt, (int)n.ne[0]);
+            e = fuse_epilogue(t, true, true);
+            p = pack_rows(wt, bt, (int)n.ne[0], e.scale);
             a.M = (int)(x.n_elements() / x.ne[0]);
             xbuf = padded_rows(xs, p.k_real, p.K, a.M, who);
             a.lda = p.K;
@@ -744,10 +795,9 @@ struct lowering {
         if (n.ne[0] % 8) throw except("%s %s: %lld output channels; the f16 epilogues store 8 at a time", graph_op_name(n.op), who.c_str(), (long long)n.ne[0]);
         a.W = p.w; a.bias = p.bias; a.N = p.N; a.K = p.K; a.n_valid = n.op == gop_conv_transpose_2d ? p.n_real : (int)n.ne[0];
         a.ldo = n.ne[0];
-        epilogue e;
-        if (n.op == gop_conv_transpose_2d) { a.epi = VX_EPI_PIXSHUF; e.last = t; }
+        if (n.op == gop_conv_transpose_2d) a.epi = VX_EPI_PIXSHUF;
         else {
-            e = fuse_epilogue(t, true);
+            if (n.op != gop_linear) e = fuse_epilogue(t, true);
             a.epi = e.res >= 0 ? VX_EPI_F16_ADD : (e.act == 1 ? VX_EPI_F16_GELU : (e.act == 2 ? VX_EPI_F16_RELU : VX_EPI_F16));
             a.relu = e.res >= 0 && e.act == 2;
         }
@@ -758,8 +808,8 @@ struct lowering {
         if (e.res >= 0) { reads.push_back(buf_of(e.res)); rp = ptr(buf_of(e.res)); }
         const bool halo = conv && a.conv_kh == 3 && a.conv_kw == 3 && a.conv_stride == 1 && a.conv_pad == 1 && a.conv_W >= 96;
         char d[256];
-        snprintf(d, sizeof d, "%s%s%s%s%s M=%d N=%d K=%d <- %s", kind.c_str(), e.act ? "[" : "", act_name(e.act), e.act ? "]" : "", e.res >= 0 ? "[+res]" : "", a.M,
-                 (int)n.ne[0], p.k_real, who.c_str());
+        snprintf(d, sizeof d, "%s%s%s%s%s%s M=%d N=%d K=%d <- %s", kind.c_str(), e.scale >= 0 ? "[*scale]" : "", e.act ? "[" : "", act_name(e.act), e.act ? "]" : "",
+                 e.res >= 0 ? "[+res]" : "", a.M, (int)n.ne[0], p.k_real, who.c_str());
         auto xp = ptr(xbuf), op = ptr(obuf);
         emit(d, reads, {obuf}, [=](void* st) {
             vx_gemm_args r = a;
@@ -798,6 +848,67 @@ struct lowering {
         });
     }
 
+    // q, k, v of an attention that are views of three linears over ONE input, read by nothing else: the three products become one GEMM
+    // whose epilogue writes head-major q (scaled), k, v (dino.cpp:59-70 as one launch instead of three products + three permutes)
+    std::map<int, int> qkv_first;                 // first of the three linears (node order) -> attention node
+    std::map<int, std::array<int, 3>> qkv_lin;    // attention node -> its three linears
+    std::map<int, std::array<int, 3>> qkv_bufs;   // attention node -> head-major buffers, once the fused launch is emitted
+    void find_qkv_groups() {
+        for (int t = 0; t < (int)g.nodes.size(); ++t) {
+            graph_node const& n = g.nodes[t];
+            if (!needed[t] || n.op != gop_attention) continue;
+            std::array<int, 3> lin{-1, -1, -1};
+            bool ok = g.nodes[n.src[0]].ne[0] == 64 && g.nodes[n.src[0]].ne[2] == g.nodes[n.src[1]].ne[2];
+            for (int i = 0; i < 3 && ok; ++i) {
+                int v = n.src[i];
+                while (ok && (g.nodes[v].op == gop_reshape || g.nodes[v].op == gop_cont)) { // single-reader views only
+                    ok = uses[v] == 1 && !g.nodes[v].is_output;
+                    v = g.nodes[v].src[0];
+                }
+                ok = ok && g.nodes[v].op == gop_linear && uses[v] == 1 && !g.nodes[v].is_output;
+                lin[i] = v;
+            }
+            ok = ok && lin[0] != lin[1] && lin[1] != lin[2] && lin[0] != lin[2];
+            for (int i = 1; i < 3 && ok; ++i)
+                ok = g.nodes[lin[i]].src[0] == g.nodes[lin[0]].src[0] && g.nodes[g.nodes[lin[i]].src[1]].ne[0] == g.nodes[g.nodes[lin[0]].src[1]].ne[0] &&
+                     g.nodes[g.nodes[lin[i]].src[1]].ne[1] == g.nodes[g.nodes[lin[0]].src[1]].ne[1];
+            ok = ok && g.nodes[g.nodes[lin[0]].src[1]].ne[0] % 64 == 0 && g.nodes[g.nodes[lin[0]].src[1]].ne[1] == g.nodes[n.src[0]].ne[0] * g.nodes[n.src[0]].ne[1];
+            if (!ok) continue;
+            qkv_lin[t] = lin;
+            qkv_first[std::min({lin[0], lin[1], lin[2]})] = t;
+        }
+    }
+    void fused_qkv(int att) {
+        graph_node const& n = g.nodes[att];
+        graph_node const& q = g.nodes[n.src[0]];
+        const int64_t H = q.ne[1], T = q.ne[2], B = q.ne[3];
+        auto const& lin = qkv_lin[att];
+        packed_operand p = pack_qkv(lin.data());
+        const int xs = g.nodes[lin[0]].src[0];
+        const int xbuf = buf_of(xs);
+        std::array<int, 3> hb;
+        for (int i = 0; i < 3; ++i) hb[i] = new_buffer((size_t)(64 * H * T * B) * 2);
+        for (int i = 0; i < 3; ++i) { // the linears and their views are computed by this launch
+            skip[lin[i]] = 1;
+            for (int v = n.src[i]; v != lin[i]; v = g.nodes[v].src[0]) skip[v] = 1;
+        }
+        vx_gemm_args a;
+        memset(&a, 0, sizeof a);
+        a.lda = p.K; a.W = p.w; a.bias = p.bias; a.M = (int)(B * T); a.N = p.N; a.K = p.K; a.n_valid = p.N;
+        a.epi = VX_EPI_QKV;
+        a.qkv_T = (int)T; a.qkv_H = (int)H;
+        a.q_scale = n.fp[0] * 1.4426950408889634f; // the attention kernel works in the exp2 domain (VX_ATTN_Q_SCALE)
+        auto xp = ptr(xbuf), qp = ptr(hb[0]), kp = ptr(hb[1]), vp = ptr(hb[2]);
+        char d[200];
+        snprintf(d, sizeof d, "gemm[qkv heads-major] M=%d N=%d K=%d <- %s", a.M, p.N, p.k_real, g.nodes[g.nodes[lin[0]].src[1]].name.c_str());
+        emit(d, {xbuf}, {hb[0], hb[1], hb[2]}, [=](void* st) {
+            vx_gemm_args r = a;
+            r.A = xp(); r.q = qp(); r.k = kp(); r.vt = vp();
+            VX(vx_gemm_f16(&r, st));
+        });
+        qkv_bufs[att] = hb;
+    }
+
     void attention(int t) {
         graph_node& n = g.nodes[t];
         graph_node const &q = g.nodes[n.src[0]], &k = g.nodes[n.src[1]];
@@ -805,6 +916,9 @@ struct lowering {
         if (hd != 64 || Tq != Tk) throw except("attention: head_dim %lld, %lld queries on %lld keys; the fused kernel is built for head_dim 64 self-attention", (long long)hd, (long long)Tq, (long long)Tk);
         const float q_scale = n.fp[0] * 1.4426950408889634f; // the kernel works in the exp2 domain (VX_ATTN_Q_SCALE)
         int hb[3];
+        if (auto it = qkv_bufs.find(t); it != qkv_bufs.end()) {
+            for (int i = 0; i < 3; ++i) hb[i] = it->second[i];
+        } else
         for (int i = 0; i < 3; ++i) { // [hd, H, T, B] -> head-major [hd, T, H, B]
             const int sb = buf_of(n.src[i]);
             hb[i] = new_buffer((size_t)(hd * H * Tq * B) * 2);
@@ -893,8 +1007,10 @@ struct lowering {
                 consumers[n.src[i]].push_back(t);
             }
         }
+        find_qkv_groups();
         for (int t = 0; t < N; ++t) {
             graph_node& n = g.nodes[t];
+            if (auto it = qkv_first.find(t); it != qkv_first.end() && !skip[t]) fused_qkv(it->second);
             if (!needed[t] || skip[t]) continue;
             if (n.constant) {
                 if (n.is_output) throw except("graph_allocate: output '%s' is a constant", n.name.c_str());
