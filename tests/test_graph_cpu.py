@@ -121,11 +121,11 @@ def test_depth_anything_lowers_to_fused_launches(planned):
 
 
 def test_arena_recycles_buffers_by_liveness(planned):
-    """ggml_gallocr's job (ml.cpp:545-552): a buffer is reused after its last reader. Batch 2 at 518 x 518: 711 MB of node outputs
+    """ggml_gallocr's job (ml.cpp:545-552): a buffer is reused after its last reader. Batch 2 at 518 x 518: 534 MB of node outputs
     live in < 100 MB; the four tapped feature maps (read by the neck long after their layer) survive the encoder."""
     g, _, _ = planned
     s = g.summary()
-    assert s["unshared_bytes"] > 7 * s["arena_bytes"]
+    assert s["unshared_bytes"] > 5 * s["arena_bytes"]
     biggest = 2 * 518 * 518 * 32 * 2  # head.conv2's input, the largest single map
     assert 2 * biggest < s["arena_bytes"] < 3 * biggest
     assert s["constant_bytes"] > 49_000_000  # every weight packed once (24.8 M parameters in f16 + padding)
