@@ -8,9 +8,9 @@
 // image_normalize, per family *_load_model + *_compute for depth_anything, esrgan, birefnet and sam (sam_encode + sam_compute with a
 // point or a box), and the Depth-Anything pipeline pieces depthany_params / depthany_detect_params / depthany_image_extent /
 // depthany_process_input / depthany_process_output (vision.h:236-252).
-// Not covered (this backend has no graph IR): the ml.h layer -- compute_graph, model_ref, tensor, model_file --
-// and the *_predict(model_ref, tensor, ...) graph builders on it (so depthany_detect_params takes the loaded model instead of a
-// model_file); migan_* (family not built).
+// The ml.h layer -- model_weights, compute_graph, model_ref, tensor, transfer_* -- is visp/ml.h, the nn.h builders visp/nn.h, and
+// depthany_predict(model_ref, tensor, ...) on them visp/arch/depth-anything.h. Not covered: model_file (depthany_detect_params takes the
+// loaded model instead), the *_predict builders of the other families (hand schedules only), migan_* (family not built).
 #pragma once
 
 #include <array>
