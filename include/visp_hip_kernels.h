@@ -265,6 +265,8 @@ VX_API int vx_attention_f16(const void* q, const void* k, const void* v, void* o
 /* test hook: a lane's partial row sum above `limit` sends a key tile from the lagging-reference fast path to the full path
  * (0 = always the full path; negative = restore the default 1024) */
 VX_API void vx_attention_set_fast_limit(float limit);
+/* diagnostics (tools/attn_stamps.py): u64 [blocks][waves][4] = cycles in {wait + barrier, scores + softmax, PV, lifetime}; NULL = off */
+VX_API void vx_attention_set_stamps(void* stamps);
 
 /* ---- token-stationary DINOv2 block (kernels_block.hip; embed dim 384, mlp 1536, head dim 64) ------------------------------
  * One launch per layer replaces everything between two attentions of dino::layer (src/visp/arch/dino.cpp:48-90):

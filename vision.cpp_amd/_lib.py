@@ -115,7 +115,7 @@ KERNEL_SYMBOLS = [
     "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_malloc_host", "vx_free_host", "vx_memcpy_h2d_async", "vx_memcpy_d2h_async", "vx_event_sync", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
     "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_stream_wait_event", "vx_graph_begin_capture",
     "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_gemm_pick_k_splits", "vx_conv3x3_supported", "vx_conv3x3_f16",
-    "vx_attention_f16", "vx_attention_set_fast_limit",
+    "vx_attention_f16", "vx_attention_set_fast_limit", "vx_attention_set_stamps",
     "vx_layernorm_f32_f16", "vx_layernorm_resid_supported", "vx_layernorm_resid_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
     "vx_dconv3x3_f16", "vx_dconv_bilinear_supported", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
@@ -277,6 +277,7 @@ def init() -> ctypes.CDLL:
     lib.vx_conv3x3_f16.argtypes = [POINTER(GemmArgs), c_void_p]
     lib.vx_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.vx_attention_set_fast_limit.argtypes = [c_float]
+    lib.vx_attention_set_stamps.argtypes = [c_void_p]
     lib.vx_layernorm_f32_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
     lib.vx_preprocess_patches.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]
     lib.vx_preprocess_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]

@@ -31,6 +31,9 @@
 
 namespace {
 
+#ifndef VISP_ATTN_WPE
+#define VISP_ATTN_WPE 4 // waves per SIMD the register budget is held to (experiments: 3 = 168 registers)
+#endif
 #ifndef VISP_ATTN_SEQ
 #define VISP_ATTN_SEQ 1 // A/B builds: 0 lets hipcc overlap the two 32-key blocks of a tile (profiles/r03_attention_ab_fastpath.txt)
 #endif
@@ -58,9 +61,14 @@ __device__ __forceinline__ float other_half(float v) {
 // four waves per SIMD: the register allocation is held at 128 (the steady-state tile runs spill-free in it, the rare full path keeps
 // a few invariants in scratch). NW waves per block = 32 NW queries share one K/V tile stream: the 16 LDS-DMA instructions of a tile
 // are split over the block's waves, and every one of them costs its wave 60-180 issue cycles in a kernel that is issue bound.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
-                                                         const f16* __restrict__ V, f16* __restrict__ O, int H, int T, float FAST_LIMIT) {
+// STAMP (diagnostics only, tools/attn_stamps.py): per wave, cycles spent in {wait + barrier + DMA issue, scores + exponentials + row sum, PV product}
+// and the wave's lifetime, by s_memtime around the phases of every tile; never instantiated on the product path.
+template <int NW, bool STAMP = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(VISP_ATTN_WPE, VISP_ATTN_WPE))) void attention_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
+                                                         const f16* __restrict__ V, f16* __restrict__ O, int H, int T, float FAST_LIMIT,
+                                                         unsigned long long* __restrict__ stamps = nullptr) {
+    unsigned long long st_wait = 0, st_soft = 0, st_pv = 0, st_t0 = 0;
+    if constexpr (STAMP) st_t0 = __builtin_amdgcn_s_memtime();
     // LDS ring: 2 stages x (K tile, V tile)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];
 
@@ -201,9 +209,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // one 64-key tile; BUF is a compile-time constant so every LDS offset folds into an immediate
     auto tile_body = [&](int t, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
+        unsigned long long c0 = 0, c1 = 0, c2 = 0;
+        if constexpr (STAMP) c0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // tile t landed; every wave finished tile t-1, so the other stage is free
         if (t + 1 < n_tiles) issue_loads(t + 1, BUF ^ 1);
+        if constexpr (STAMP) { c1 = __builtin_amdgcn_s_memtime(); st_wait += c1 - c0; }
         const unsigned char* sk = smem + BUF * (2 * TILE_BYTES);
         const unsigned char* sv = sk + TILE_BYTES;
         if (q0 >= T) return; // (wave-uniform) a wave without queries only feeds the ring and keeps the barriers
@@ -248,7 +259,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
             psum = softmax_p(sk, k0, last, pf);
         }
         l_run += psum;
+        if constexpr (STAMP) { c2 = __builtin_amdgcn_s_memtime(); st_soft += c2 - c1; }
         pv(sv, pf); // the one place O is accumulated
+        if constexpr (STAMP) {
+            asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][0])); // the last PV results are due before the clock is read
+            st_pv += __builtin_amdgcn_s_memtime() - c2;
+        }
     };
 
     issue_loads(0, 0);
@@ -257,6 +273,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         if (t + 1 < n_tiles) tile_body(t + 1, std::integral_constant<int, 1>{});
     }
 
+    if constexpr (STAMP) {
+        if (lane == 0) {
+            unsigned long long* s = stamps + ((size_t)blockIdx.x * NW + wave) * 4;
+            s[0] = st_wait; s[1] = st_soft; s[2] = st_pv; s[3] = __builtin_amdgcn_s_memtime() - st_t0;
+        }
+    }
     // ---- finalize: O[q, head*64 + d] = o / l
     float inv = 1.0f / l_run;
     const int q = q0 + r;
@@ -281,14 +303,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 static float g_fast_limit = FAST_LIMIT_DEFAULT;
 extern "C" void vx_attention_set_fast_limit(float limit) { g_fast_limit = limit < 0.0f ? FAST_LIMIT_DEFAULT : limit; }
 
+// diagnostics: u64 [blocks][waves][4] = {wait, softmax, pv, lifetime} cycles of the next launches; NULL = the product kernel
+static void* g_attn_stamps = nullptr;
+extern "C" void vx_attention_set_stamps(void* stamps) { g_attn_stamps = stamps; }
+
 extern "C" int vx_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int T, void* stream) {
     VX_REQUIRE(B > 0 && H > 0 && T > 0, "vx_attention_f16: empty problem");
     static const int nw_env = getenv("VISP_ATTN_WAVES") ? atoi(getenv("VISP_ATTN_WAVES")) : 0;
     const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (T > 512 ? 8 : 4); // short sequences: smaller blocks fill the chip better
     const int qpb = Q_PER_WAVE * nw;
     dim3 grid(((T + qpb - 1) / qpb) * B * H);
-    hipLaunchKernelGGL((nw == 8 ? attention_kernel<8> : attention_kernel<4>), grid, dim3(64 * nw), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
-                       reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), H, T, g_fast_limit);
+    if (g_attn_stamps)
+        hipLaunchKernelGGL((nw == 8 ? attention_kernel<8, true> : attention_kernel<4, true>), grid, dim3(64 * nw), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
+                           reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), H, T, g_fast_limit,
+                           static_cast<unsigned long long*>(g_attn_stamps));
+    else
+        hipLaunchKernelGGL((nw == 8 ? attention_kernel<8, false> : attention_kernel<4, false>), grid, dim3(64 * nw), 0, as_stream(stream), reinterpret_cast<const f16*>(q),
+                           reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v), reinterpret_cast<f16*>(out), H, T, g_fast_limit,
+                           static_cast<unsigned long long*>(nullptr));
     VX_LAUNCH_CHECK();
     return 1;
 }
