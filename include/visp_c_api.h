@@ -106,7 +106,8 @@ VISP_API int32_t visp_depthany_compute_batch_host(visp_model* m, uint8_t const* 
 /* Multi-GPU from C: models[i] is a depth_anything model loaded on its own device (visp_hip_device_init(i) + visp_model_load);
  * the batch is cut into n_models contiguous shards (sizes differ by at most one), each shard runs on its model's device from
  * its own host thread, outputs land at the matching offsets of `out` [batch, h, w] f32. No collective is involved: images are
- * independent. (Per-device kernel attributes are set per (kernel, device), so several devices in one process are fine.) */
+ * independent. (Per-device kernel attributes are set per (kernel, device), so several devices in one process are fine. Models that share
+ * one visp_device share its compute stream: their shards take turns instead of running concurrently.) */
 VISP_API int32_t visp_depthany_compute_sharded(visp_model* const* models, int32_t n_models, uint8_t const* rgb_u8, int32_t batch,
                                                int32_t w, int32_t h, float* out);
 /* Overlapped host pipeline (the reference's benchmark loop -- upload, compute, download per call, tests/benchmark.cpp:55-91 --

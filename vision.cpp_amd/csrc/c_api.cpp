@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -351,12 +352,23 @@ int32_t visp_depthany_compute_sharded(visp_model* const* models, int32_t n_model
         }
         std::vector<std::string> errors((size_t)n_models);
         std::vector<std::thread> threads;
+        // models that sit on the same backend_device share its compute stream (a one-GPU rehearsal of the multi-device call): their
+        // shards take turns -- two host threads must not capture a hipGraph on one stream at once. One device per model: no lock.
+        std::map<void*, std::unique_ptr<std::mutex>> stream_turn;
+        for (auto* m : ms) {
+            int sharers = 0;
+            for (auto* o : ms) sharers += o->backend->stream == m->backend->stream;
+            if (sharers > 1 && !stream_turn.count(m->backend->stream)) stream_turn[m->backend->stream] = std::make_unique<std::mutex>();
+        }
         const int base = batch / n_models, rem = batch % n_models;
         for (int i = 0; i < n_models; ++i) {
             const int begin = i * base + std::min(i, rem), count = base + (i < rem ? 1 : 0);
             if (count == 0) continue;
             threads.emplace_back([&, i, begin, count]() {
                 try {
+                    auto turn = stream_turn.find(ms[(size_t)i]->backend->stream);
+                    std::unique_lock<std::mutex> lock;
+                    if (turn != stream_turn.end()) lock = std::unique_lock<std::mutex>(*turn->second);
                     depthany_compute_shard_host(*ms[(size_t)i], rgb + (size_t)begin * h * w * 3, count, w, h, out + (size_t)begin * h * w);
                 } catch (std::exception const& e) {
                     errors[(size_t)i] = e.what();
