@@ -334,6 +334,18 @@ VX_API int vx_bilinear_ac_f16(const void* x, void* y, int B, int H, int W, int C
 VX_API int vx_head_out_f32(const void* x, const float* w, float bias, float max_depth, float* depth,
                            int64_t n_pixels, int C, void* stream);
 
+/* ---- the DPT head's tail as one kernel (depth-anything.cpp:84-94; kernels_headconv.hip): x f16 [B, hs, ws, 32] --bilinear, align_corners-->
+ * [B, H, W, 32] -> conv 3x3 (32 -> 32, pad 1) + bias + ReLU -> conv 1x1 (32 -> 1) + b3 + ReLU -> * scale -> out f32 [B, H, W]. The 3x3 kernel
+ * is held in registers: `wfrag` = vx_headconv_pack (host code) of the GEMM-family rows [32][Kp], k = (ky, kx, c); vx_headconv_frag_bytes()
+ * bytes. Supported: cin = cout = 32 and a resize whose 18 x 34 halo fits a 13 x 22 source patch (scale up to about 0.6). */
+VX_API size_t vx_headconv_frag_bytes(void);
+VX_API int vx_headconv_pack(const void* w_rows, int Kp, void* out_frag);
+VX_API int vx_headconv_supported(int cin, int cout, int H, int W, int hs, int ws);
+/* diagnostics (tools/headconv_stamps.py): u64 [blocks][4][8] per-phase cycles of the next launches; NULL = off */
+VX_API void vx_headconv_set_stamps(void* stamps);
+VX_API int vx_headconv_bil_f16(const void* x, const void* wfrag, const float* bias, const float* w3, float b3, float scale, float* out, int B, int H, int W,
+                               int hs, int ws, void* stream);
+
 /* ---- post-processing: per-image min/max then (v-min)/(max-min) (image.cpp:537-576);
  * minmax: f32 [B,2] scratch ------------------------------------------------------------------ */
 VX_API int vx_minmax_normalize(const float* depth, float* out, float* minmax, int B, int64_t pixels_per_image,

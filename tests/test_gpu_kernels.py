@@ -504,3 +504,52 @@ def test_conv_split_k(cin, cout, stride, hw, epi):
     g = L.GemmArgs()
     g.M, g.N, g.K, g.k_splits, g.A, g.W = 128, 64, 128, 4, xd.ptr, xd.ptr
     assert api().vx_gemm_f16(C.byref(g), None) == 0 and b"k_partial" in api().vx_last_error()
+
+
+@pytest.mark.parametrize("B,hs,ws,H,W", [(2, 37, 37, 64, 64), (1, 296, 296, 518, 518), (3, 26, 40, 45, 70), (1, 10, 11, 17, 19)])
+def test_headconv_resize_conv_relu_conv_relu(B, hs, ws, H, W):
+    """kernels_headconv.hip: bilinear (align_corners) resize + conv 3x3 32 -> 32 + ReLU + conv 1x1 -> 1 + ReLU + scale in one kernel
+    (depth-anything.cpp:84-94) vs torch fp32 on the same f16 operands (the resized map rounded to f16, as the kernel holds it in LDS).
+    Shapes: whole tiles, the north star's 296 -> 518 (edge tiles in both directions), a ragged non-square map, a map smaller than a tile."""
+    import torch
+    import torch.nn.functional as F
+
+    lib = api()
+    assert lib.vx_headconv_supported(32, 32, H, W, hs, ws) == 1
+    rng = np.random.default_rng(B * 1000 + H)
+    x = (rng.standard_normal((B, hs, ws, 32)) * 0.7).astype(np.float16)
+    w2 = (rng.standard_normal((32, 3, 3, 32)) / np.sqrt(288)).astype(np.float16)  # OHWI rows, k = (ky, kx, c)
+    b2 = (0.1 * rng.standard_normal(32)).astype(np.float32)
+    w3 = (rng.standard_normal(32) / 4).astype(np.float32)
+    b3, scale = 0.05, 2.5
+    rows = np.zeros((32, 320), np.float16)
+    rows[:, :288] = w2.reshape(32, 288)
+    frag = np.empty(lib.vx_headconv_frag_bytes() // 2, np.float16)
+    L.vx_check(lib.vx_headconv_pack(rows.ctypes.data, 320, frag.ctypes.data))
+    xd, fd, bd, wd = dev(x), dev(frag), dev(b2), dev(w3)
+    out = empty(B * H * W * 4)
+    L.vx_check(lib.vx_headconv_bil_f16(xd.ptr, fd.ptr, bd.ptr, wd.ptr, b3, scale, out.ptr, B, H, W, hs, ws, None))
+    sync()
+    got = out.to_numpy(np.float32, (B, H, W))
+    up = F.interpolate(torch.from_numpy(x.astype(np.float32)).permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True)
+    up = up.half().float()
+    c2 = torch.relu(F.conv2d(up, torch.from_numpy(w2.astype(np.float32)).permute(0, 3, 1, 2), torch.from_numpy(b2), padding=1))
+    want = scale * torch.relu((c2 * torch.from_numpy(w3).view(1, 32, 1, 1)).sum(1) + b3)
+    want = want.numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - want)
+    assert err.max() < 6e-3 * max(1.0, float(np.abs(want).max())), (float(err.max()), float(np.abs(want).max()))
+    assert err.mean() < 6e-4
+    release()
+
+
+def test_headconv_limits():
+    lib = api()
+    assert lib.vx_headconv_supported(32, 32, 518, 518, 296, 296) == 1
+    assert lib.vx_headconv_supported(64, 32, 518, 518, 296, 296) == 0   # the kernel holds a 32-channel 3x3 kernel in registers
+    assert lib.vx_headconv_supported(32, 32, 518, 518, 400, 400) == 0   # scale 0.77: the halo's source does not fit the 13 x 22 patch
+    assert lib.vx_headconv_supported(32, 32, 700, 518, 400, 296) == 1   # the 640 x 480 request's model extent
+    x = empty(64)
+    assert lib.vx_headconv_bil_f16(x.ptr, x.ptr, x.ptr, x.ptr, 0.0, 1.0, x.ptr, 1, 518, 518, 400, 400, None) == 0
+    assert b"source patch" in lib.vx_last_error()
+    release()

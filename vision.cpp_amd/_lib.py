@@ -122,6 +122,7 @@ KERNEL_SYMBOLS = [
     "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_mbconv_dw_pw_supported", "vx_mbconv_pack_w3", "vx_mbconv_dw_pw_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
     "vx_bf_preprocess_half", "vx_bf_patches", "vx_bf_resize_f16", "vx_bf_deform_cols_f16", "vx_bf_mean_f16", "vx_bf_broadcast_f16", "vx_bf_mul_sigmoid_f16", "vx_bf_sigmoid_out_f32",
     "vx_swin_attention_pack_bias", "vx_window_attention_masked_f16", "vx_swin_layernorm_f16", "vx_swin_layernorm_strided_f16", "vx_swin_merge_layernorm_f16", "vx_swin_window_reverse_add_f16",
+    "vx_headconv_frag_bytes", "vx_headconv_pack", "vx_headconv_supported", "vx_headconv_bil_f16", "vx_headconv_set_stamps",
     "vx_copy_strided_f16", "vx_binary_rows", "vx_unary_f16", "vx_convert", "vx_im2col_patches_f32", "vx_conv1x1_to1_f32",
     "vx_dino_block_supported", "vx_dino_block_mlp_bytes", "vx_dino_block_qkv_bytes", "vx_dino_block_pack_mlp", "vx_dino_block_pack_qkv", "vx_dino_block_f16", "vx_dino_block16_pack_mlp", "vx_dino_block16_pack_qkv", "vx_dino_block16_f16",
 ]
@@ -278,6 +279,11 @@ def init() -> ctypes.CDLL:
     lib.vx_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.vx_attention_set_fast_limit.argtypes = [c_float]
     lib.vx_attention_set_stamps.argtypes = [c_void_p]
+    lib.vx_headconv_frag_bytes.restype = c_size_t
+    lib.vx_headconv_set_stamps.argtypes = [c_void_p]
+    lib.vx_headconv_pack.argtypes = [c_void_p, c_int, c_void_p]
+    lib.vx_headconv_supported.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int]
+    lib.vx_headconv_bil_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_layernorm_f32_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
     lib.vx_preprocess_patches.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]
     lib.vx_preprocess_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]

@@ -412,6 +412,10 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
     Wt.head1 = pk.conv("head.conv1");
     Wt.head2 = pk.conv("head.conv2");
     Wt.head_c = Wt.head1.n_real;
+    if (Wt.head2.n_real == 32 && Wt.head2.k_real == 288 && Wt.head2.N == 32) { // 3x3, 32 -> 32: the head kernel's operand
+        Wt.head2_frag = ab.alloc(vx_headconv_frag_bytes());
+        if (with_data) VX(vx_headconv_pack(ab.data.data() + Wt.head2.w, Wt.head2.K, ab.data.data() + Wt.head2_frag));
+    }
     if (Wt.head_c != 8 && Wt.head_c != 16 && Wt.head_c != 32 && Wt.head_c != 64) throw except("Unsupported head width %d", Wt.head_c);
     Wt.head3_w = pk.vec("head.conv3.weight");
     // the scalar bias of the final 1x1 conv lives in the arena too, so that an arena received by
@@ -1085,13 +1089,21 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     c.capture("head_conv1", c.buf("h1"), {B, fh, fw, HC}, true);
     // head: interpolate to the image extent, then conv2 (depth-anything.cpp:84-87): conv2's loader resizes h1 itself where it can
     // (0.55 GB written and read back per 32 images otherwise)
-    const bool head2_bil = !m.captures && Wt.head2.N == 32 && exec_ctx::bil_ok(Wt.head2, H, W, HC, VX_EPI_HEAD_OUT, fh, fw);
-    if (!head2_bil) {
+    // ... or, where the shape is the north star's (32 -> 32 channels, scale <= 0.6), the kernel made for this tail: resize + conv2 + ReLU +
+    // conv3 + ReLU with the 3x3 kernel in registers (kernels_headconv.hip)
+    static const bool no_headconv = getenv("VISP_NO_HEADCONV") != nullptr;
+    const bool head2_hc = !m.captures && !no_headconv && Wt.head2_frag != SIZE_MAX && Wt.head2.b != SIZE_MAX && vx_headconv_supported(HC, 32, H, W, fh, fw);
+    const bool head2_bil = !head2_hc && !m.captures && Wt.head2.N == 32 && exec_ctx::bil_ok(Wt.head2, H, W, HC, VX_EPI_HEAD_OUT, fh, fw);
+    if (!head2_bil && !head2_hc) {
         c.mark("bilinear", 1, 0, (double)B * ((double)fh * fw + (double)H * W) * HC * 2);
         if (!(ablate & 2)) VX(vx_bilinear_ac_f16(c.buf("h1"), c.buf("hup"), B, fh, fw, HC, H, W, stream));
     }
     float* depth = raw_out_dev ? static_cast<float*>(raw_out_dev) + (size_t)b0 * H * W : static_cast<float*>(c.buf("depth"));
-    if (Wt.head2.N == 32) {
+    if (head2_hc) {
+        c.mark("head_conv2+3", 1, 2.0 * B * H * W * 32 * (Wt.head2.k_real + 1), (double)B * ((double)fh * fw * HC * 2 + (double)H * W * 4));
+        VX(vx_headconv_bil_f16(c.buf("h1"), c.wptr(Wt.head2_frag), reinterpret_cast<const float*>(c.wa + Wt.head2.b), c.fptr(Wt.head3_w), Wt.head3_b, P.max_depth, depth, B,
+                               H, W, fh, fw, stream));
+    } else if (Wt.head2.N == 32) {
         // conv2 (3x3 -> 32) + ReLU + conv3 (1x1 -> 1) + ReLU [* max_depth] in one kernel: the 32-channel
         // full-resolution tensor never reaches HBM
         vx_gemm_args a = c.base(Wt.head2, (long)B * H * W);

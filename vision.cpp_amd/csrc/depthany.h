@@ -82,6 +82,7 @@ struct depthany_weights {
     int fusion_c = 0, head_c = 0;
     packed_gemm head1, head2;
     packed_vec head3_w;
+    size_t head2_frag = SIZE_MAX; // head.conv2 as register-resident MFMA fragments (kernels_headconv.hip), when it is 32 -> 32
     float head3_b = 0;
     size_t head3_b_off = 0;
 };

@@ -70,12 +70,10 @@ struct tile_grid {
 // RES: number of weight slabs kept RESIDENT in LDS for the whole launch (all cin/32 chunks of the conv fit next to the
 // halo ring), 0 = slabs stream through a 2-stage ring. HSV: halo ring stages of this variant.
 // max(x, 0) as ONE instruction: fmaxf() on an MFMA result costs a canonicalising v_max_f32 x, x, x first (IEEE mode), and the depth
-// head's epilogue is 32 of them per tile in a kernel bound by VALU issue
-__device__ __forceinline__ float relu1(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
-}
+// head's epilogue is 32 of them per tile in a kernel bound by VALU issue. Signed-integer max with 0 (same order as floats for non-NaN
+// values, -0.0 and negatives -> +0), NOT an inline-asm v_max_f32: the hazard recogniser does not look into inline asm, and one placed
+// right behind an accumulator's last MFMA reads it before the matrix pipe has written it (kernels_headconv.hip met exactly that).
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 // BIL: the input is a LOW-resolution map and the conv runs on its bilinear (align_corners) resize (the DPT head's two
 // `interpolate` calls, depth-anything.cpp:36-38 / 84-85 -> ml.cpp:782-788 ggml_interpolate): the resized map never exists. Per step
