@@ -187,7 +187,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this tile's patch (issued one tile ago) and the previous tile's stores
         __syncthreads();                                  // ... from every wave; and every wave is done reading the halo
         stamp(1); // wait + barrier
-        if (t + per_xcd_blocks < t_end) issue_patch(locate(t + per_xcd_blocks), cur ^ 1); // lands under this tile's work
 
         // ---- interpolate the halo: chunk c of pixel column hx is stored at c ^ ((hx >> 1) & 3) so that the 8 lanes a ds_read_b128
         // serves per cycle (8 consecutive pixels, 64 bytes apart) hit 8 different 16-byte bank groups. The phase is LDS-latency bound
@@ -249,12 +248,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         stamp(1);
 
         // ---- conv2 on the matrix pipe: wave owns output rows 4 wave .. + 3; acc[j] = D^T[cout, pixel] of row j, starting at the bias
-        f32x16 acc[4];
+        // the next tile's source patch: issued here, where the wave's instruction issue is mostly idle (72 MFMAs hold it for 576 of the
+        // phase's cycles); it lands under this phase. (Its buffer's last readers were the previous tile's interpolation.)
+        if (t + per_xcd_blocks < t_end) issue_patch(locate(t + per_xcd_blocks), cur ^ 1);
+        f32x16 acc[4], bias_tile; // the first MFMA of every accumulator takes the bias tile as its C operand: no 64 moves per tile
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(bias_lds + 16 * h + 4 * g);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { acc[0][4 * g + q] = v[q]; acc[1][4 * g + q] = v[q]; acc[2][4 * g + q] = v[q]; acc[3][4 * g + q] = v[q]; }
+            for (int q = 0; q < 4; ++q) bias_tile[4 * g + q] = v[q];
         }
         // B fragments one halo row ahead of their MFMAs (6 reads per row: 3 columns x 2 channel halves): a read consumed right
         // behind its issue exposes the LDS latency -- under the other block's interpolation traffic -- once per MFMA group
@@ -277,7 +279,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const int j = hr - dy; // output row whose window has halo row hr at tap row dy
-                        if (j >= 0 && j < 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(dy * 3 + dx) * 2 + ks], bf[hr & 1][dx * 2 + ks], acc[j], 0, 0, 0);
+                        const bool first = dy == 0 && dx == 0 && ks == 0; // (halo row hr = j: the accumulator's first product)
+                        if (j >= 0 && j < 4)
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(dy * 3 + dx) * 2 + ks], bf[hr & 1][dx * 2 + ks], first ? bias_tile : acc[j], 0, 0, 0);
                     }
                 }
             }
