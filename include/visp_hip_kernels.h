@@ -337,7 +337,7 @@ VX_API int vx_head_out_f32(const void* x, const float* w, float bias, float max_
 /* ---- the DPT head's tail as one kernel (depth-anything.cpp:84-94; kernels_headconv.hip): x f16 [B, hs, ws, 32] --bilinear, align_corners-->
  * [B, H, W, 32] -> conv 3x3 (32 -> 32, pad 1) + bias + ReLU -> conv 1x1 (32 -> 1) + b3 + ReLU -> * scale -> out f32 [B, H, W]. The 3x3 kernel
  * is held in registers: `wfrag` = vx_headconv_pack (host code) of the GEMM-family rows [32][Kp], k = (ky, kx, c); vx_headconv_frag_bytes()
- * bytes. Supported: cin = cout = 32 and a resize whose 18 x 34 halo fits a 13 x 22 source patch (scale up to about 0.6). */
+ * bytes. Supported: cin = cout = 32 and a resize whose 18 x 34 halo fits a 12 x 21 source patch (scale up to about 0.58). */
 VX_API size_t vx_headconv_frag_bytes(void);
 VX_API int vx_headconv_pack(const void* w_rows, int Kp, void* out_frag);
 VX_API int vx_headconv_supported(int cin, int cout, int H, int W, int hs, int ws);

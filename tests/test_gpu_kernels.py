@@ -547,7 +547,7 @@ def test_headconv_limits():
     lib = api()
     assert lib.vx_headconv_supported(32, 32, 518, 518, 296, 296) == 1
     assert lib.vx_headconv_supported(64, 32, 518, 518, 296, 296) == 0   # the kernel holds a 32-channel 3x3 kernel in registers
-    assert lib.vx_headconv_supported(32, 32, 518, 518, 400, 400) == 0   # scale 0.77: the halo's source does not fit the 13 x 22 patch
+    assert lib.vx_headconv_supported(32, 32, 518, 518, 400, 400) == 0   # scale 0.77: the halo's source does not fit the 12 x 21 patch
     assert lib.vx_headconv_supported(32, 32, 700, 518, 400, 296) == 1   # the 640 x 480 request's model extent
     x = empty(64)
     assert lib.vx_headconv_bil_f16(x.ptr, x.ptr, x.ptr, x.ptr, 0.0, 1.0, x.ptr, 1, 518, 518, 400, 400, None) == 0

@@ -716,6 +716,59 @@ struct lowering {
         return dst;
     }
 
+    // interpolate (bilinear, align_corners) -> conv 3x3 32 -> 32 + bias -> relu -> conv 1x1 -> 1 -> relu [-> scale], every link read by the
+    // next one only: the DPT head's tail (depth-anything.cpp:84-95) is ONE launch of the kernel made for it (kernels_headconv.hip)
+    bool head_tail(int t) {
+        graph_node const& up = g.nodes[t];
+        graph_node const& x = g.nodes[up.src[0]];
+        if ((up.ip[2] & 255) != 1 || !(up.ip[2] & 256) || x.ne[0] != 32) return false;
+        const int c2 = sole_consumer(t);
+        if (c2 < 0 || g.nodes[c2].op != gop_conv_2d || g.nodes[c2].src[0] != t || g.nodes[c2].n_src != 3) return false;
+        graph_node const& w2 = g.nodes[g.nodes[c2].src[1]];
+        if (w2.ne[0] != 32 || w2.ne[1] != 3 || w2.ne[2] != 3 || w2.ne[3] != 32 || g.nodes[c2].ip[0] != 1 || g.nodes[c2].ip[1] != 1) return false;
+        const int r1 = sole_consumer(c2);
+        if (r1 < 0 || g.nodes[r1].op != gop_relu) return false;
+        const int c3 = sole_consumer(r1);
+        if (c3 < 0 || g.nodes[c3].op != gop_conv_2d || g.nodes[c3].dtype != gdt_f32 || g.nodes[c3].src[0] != r1) return false;
+        const int r2 = sole_consumer(c3);
+        if (r2 < 0 || g.nodes[r2].op != gop_relu) return false; // the kernel's last ReLU is not optional
+        const int H = (int)up.ne[2], W = (int)up.ne[1], hs = (int)x.ne[2], ws = (int)x.ne[1], B = (int)x.ne[3];
+        if (!vx_headconv_supported(32, 32, H, W, hs, ws)) return false;
+        int last = r2;
+        float scale = 1.0f;
+        const int sc = sole_consumer(r2);
+        if (sc >= 0 && g.nodes[sc].op == gop_scale) { scale = g.nodes[sc].fp[0]; last = sc; }
+        // the 3x3 kernel as the head kernel's register fragments
+        const int wt = g.nodes[c2].src[1];
+        void* frag = cached(wt, 5, [&](bool st) {
+            std::vector<uint16_t> rows((size_t)32 * 320, 0), out(vx_headconv_frag_bytes() / 2);
+            for (int r = 0; r < 32; ++r)
+                for (int k = 0; k < 288; ++k) rows[(size_t)r * 320 + k] = f32_to_f16(w2.values()[(size_t)r * 288 + k]);
+            VX(vx_headconv_pack(rows.data(), 320, out.data()));
+            return upload(out.data(), out.size() * 2, st);
+        });
+        const float* bias2 = const_f32(g.nodes[c2].src[2]);
+        const float* w3 = const_f32(g.nodes[c3].src[1]);
+        const float b3 = g.nodes[c3].n_src == 3 ? g.nodes[g.nodes[c3].src[2]].values()[0] : 0.0f;
+        const int xbuf = buf_of(up.src[0]);
+        for (int f : {t, c2, r1, r2}) skip[f] = 1;
+        if (last != r2) skip[last] = 1;
+        skip[c3] = 1;
+        graph_node& n = g.nodes[c3];
+        for (int f : {r2, last}) {
+            g.nodes[f].alias_of = c3;
+            if (g.nodes[f].is_output) n.is_output = true;
+        }
+        materialise(c3);
+        const int obuf = n.buffer;
+        auto xp = ptr(xbuf), op = ptr(obuf);
+        char d[160];
+        snprintf(d, sizeof d, "head_tail[resize %dx%d -> %dx%d, conv3x3 32->32, relu, conv1x1 -> 1, relu%s] B=%d <- %s", ws, hs, W, H, scale != 1.0f ? ", scale" : "", B,
+                 g.nodes[wt].name.c_str());
+        emit(d, {xbuf}, {obuf}, [=](void* st) { VX(vx_headconv_bil_f16(xp(), frag, bias2, w3, b3, scale, reinterpret_cast<float*>(op()), B, H, W, hs, ws, st)); });
+        return true;
+    }
+
     // conv 1x1 -> one channel [-> relu] [-> scale]: one f32 launch
     void one_channel_head(int t) {
         graph_node& n = g.nodes[t];
@@ -1088,6 +1141,7 @@ struct lowering {
                          [=](void* st) { VX(vx_layernorm_f16(xp(), w, b, op(), rows, C, eps, 0, 0, 0, st)); });
                 } break;
                 case gop_interpolate: {
+                    if (!n.is_output && head_tail(t)) break;
                     graph_node const& x = g.nodes[n.src[0]];
                     if ((n.ip[2] & 255) != 1 || !(n.ip[2] & 256)) throw except("interpolate: mode %lld on activations is not built (bilinear | align_corners is; bicubic on constants)", (long long)n.ip[2]);
                     if (x.ne[0] % 8) throw except("interpolate: %lld channels (a multiple of 8)", (long long)x.ne[0]);

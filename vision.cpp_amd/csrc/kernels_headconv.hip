@@ -6,7 +6,7 @@
 // MFMA loop in an 8.7k-cycle step -- the ring cursors, the per-piece DMA issue and the block-wide epilogue are fixed costs per tile
 // that a 288-deep reduction cannot amortise. Here nothing streams:
 //   * the whole 3x3x32x32 kernel lives in REGISTERS as MFMA A fragments (18 x 4 registers per lane), loaded once per block;
-//   * a block = 4 waves, persistent, one 16 x 32 output tile at a time; its LDS holds two 13 x 22 source patches (the next tile's
+//   * a block = 4 waves, persistent, one 16 x 32 output tile at a time; its LDS holds two 12 x 21 source patches (the next tile's
 //     arrives by LDS-DMA under this tile's work) and the interpolated 18 x 34 halo (76 KB), so TWO blocks share a CU and one block's
 //     interpolation phase (VALU, LDS) runs under the other's MFMA phase -- no ring cursors, two barriers per tile. (A first,
 //     non-persistent form -- one tile per block, everything loaded at block start -- was latency-bound at the old kernel's speed:
@@ -28,7 +28,7 @@ namespace {
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int TH = 16, TW = 32, HH = TH + 2, HW = TW + 2; // output tile, halo
-constexpr int PR = 13, PC = 22;                           // source patch (rows, columns): covers the halo up to scale 0.6
+constexpr int PR = 12, PC = 21;                           // source patch (rows, columns): covers the halo up to scale 0.58 (floor(17 s) + 3 rows, floor(33 s) + 3 columns)
 constexpr int PIXB = 64;                                  // 32 channels f16
 constexpr int HALO_BYTES = HH * HW * PIXB;                // 39168
 constexpr int SRC_BYTES = PR * PC * PIXB + PIXB;          // + one zero pixel (what halo positions outside the map read)
@@ -342,7 +342,7 @@ extern "C" void vx_headconv_set_stamps(void* stamps) { g_headconv_stamps = stamp
 extern "C" int vx_headconv_bil_f16(const void* x, const void* wfrag, const float* bias, const float* w3, float b3, float scale, float* out, int B, int H, int W,
                                    int hs, int ws, void* stream) {
     VX_REQUIRE(x && wfrag && bias && w3 && out && B > 0, "vx_headconv_bil_f16: null operand");
-    VX_REQUIRE(vx_headconv_supported(32, 32, H, W, hs, ws), "vx_headconv_bil_f16: %dx%d from %dx%d is outside the kernel's source patch (scale up to 0.6)", W, H, ws, hs);
+    VX_REQUIRE(vx_headconv_supported(32, 32, H, W, hs, ws), "vx_headconv_bil_f16: %dx%d from %dx%d is outside the kernel's source patch (scale up to 0.58)", W, H, ws, hs);
     VX_REQUIRE((size_t)B * hs * ws * PIXB < (size_t)1 << 31, "vx_headconv_bil_f16: the source tensor must be below 2 GB (32-bit buffer offsets)");
     VX_CHECK(vx_ensure_dynamic_lds(reinterpret_cast<const void*>(headconv_kernel), SMEM_BYTES));
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
