@@ -104,6 +104,12 @@ def test_mean_broadcast_mul_sigmoid():
     L.vx_check(api().vx_bf_mean_f16(dev(x).ptr, Cc, y.ptr, empty(B * Cc * 4).ptr, B, n, Cc, None))
     sync()
     assert np.abs(y.to_numpy(np.float16, (B, Cc)).astype(np.float32) - x.astype(np.float32).mean(1)).max() < 2e-3
+    # a fixed summation order (no float atomics): the same bits every launch, whatever else the device is doing
+    first, xd = y.to_numpy(np.uint16, (B, Cc)).copy(), dev(x)
+    for _ in range(5):
+        L.vx_check(api().vx_bf_mean_f16(xd.ptr, Cc, y.ptr, empty(B * Cc * 4, zero=False).ptr, B, n, Cc, None))
+        sync()
+        assert np.array_equal(y.to_numpy(np.uint16, (B, Cc)), first)
     g = rng.standard_normal((B, Cc)).astype(np.float16)
     dst = empty(B * n * (Cc + 8) * 2)
     L.vx_check(api().vx_bf_broadcast_f16(dev(g).ptr, Cc, dst.ptr + 16, Cc + 8, B, n, Cc, None))

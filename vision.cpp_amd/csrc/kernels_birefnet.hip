@@ -137,20 +137,30 @@ __global__ __launch_bounds__(256) void bf_deform_cols_kernel(const f16* __restri
     *reinterpret_cast<f16x8*>(cols + pt * C + ch) = r;
 }
 
-// mean over the pixels of each image: x [B, n, C] (row stride ld) -> y [B, C]. Stage 1: one block per (image, 64-channel group,
-// chunk of 256 pixels) adds its partial sums to f32 accumulators (a 256^2 map is 256 chunks per image: the whole chip reads it);
-// stage 2 divides and converts.
-constexpr int MEAN_CHUNK = 256; // 64 dependent loads per thread: short enough to be bandwidth- rather than latency-bound
+// mean over the pixels of each image: x [B, n, C] (row stride ld) -> y [B, C]. One block per (image, 64-channel group): four pixel
+// slices of 64 channels add their pixels in a FIXED order (p = slice, slice + 4, ...; then slice 0 + 1 + 2 + 3), f32, and the block writes
+// the sum. No atomics: the first form added per-chunk partial sums with atomicAdd, whose order -- and with it the last bits of the mean,
+// 4e-4 on the mask after the decoder -- changed from launch to launch (tests/test_gpu_birefnet.py::test_birefnet_lite_1024_batch_8 met it
+// as a batch whose reversed order gave other bits). The map is the 1/32-scale ASPP input (32 x 32 pixels at 1024^2): 256 steps of four
+// independent loads per thread.
 __global__ __launch_bounds__(256) void bf_mean_partial_kernel(const f16* __restrict__ x, int ld, float* __restrict__ acc, long n, int C) {
     __shared__ float part[4][64];
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    const long p0 = (long)blockIdx.z * MEAN_CHUNK, p1 = min(p0 + MEAN_CHUNK, n);
-    float s = 0.0f;
-    if (c < C)
-        for (long p = p0 + slice; p < p1; p += 4) s += (float)x[((long)b * n + p) * ld + c];
-    part[slice][threadIdx.x & 63] = s;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f; // four chains per thread, combined in a fixed order
+    if (c < C) {
+        const f16* xb = x + (long)b * n * ld + c;
+        long p = slice;
+        for (; p + 12 < n; p += 16) {
+            s0 += (float)xb[p * ld];
+            s1 += (float)xb[(p + 4) * ld];
+            s2 += (float)xb[(p + 8) * ld];
+            s3 += (float)xb[(p + 12) * ld];
+        }
+        for (; p < n; p += 4) s0 += (float)xb[p * ld];
+    }
+    part[slice][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (slice == 0 && c < C) atomicAdd(acc + (long)b * C + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (slice == 0 && c < C) acc[(long)b * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void bf_mean_finish_kernel(const float* __restrict__ acc, f16* __restrict__ y, long n, int total) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -228,9 +238,7 @@ int vx_bf_deform_cols_f16(const void* x, const void* offmod, int ldom, void* col
 int vx_bf_mean_f16(const void* x, int ld, void* y, float* acc_scratch, int B, int64_t n, int C, void* stream) {
     VX_REQUIRE(x && y && acc_scratch && B > 0 && n > 0 && C > 0 && ld >= C, "vx_bf_mean_f16: bad operands");
     hipStream_t s = as_stream(stream);
-    VX_CHECK(hipMemsetAsync(acc_scratch, 0, (size_t)B * C * 4, s));
-    const unsigned chunks = (unsigned)((n + MEAN_CHUNK - 1) / MEAN_CHUNK);
-    hipLaunchKernelGGL(bf_mean_partial_kernel, dim3((C + 63) / 64, B, chunks), dim3(256), 0, s, reinterpret_cast<const f16*>(x), ld, acc_scratch, (long)n, C);
+    hipLaunchKernelGGL(bf_mean_partial_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, reinterpret_cast<const f16*>(x), ld, acc_scratch, (long)n, C);
     hipLaunchKernelGGL(bf_mean_finish_kernel, dim3(blocks_for((long)B * C)), dim3(256), 0, s, acc_scratch, reinterpret_cast<f16*>(y), (long)n, B * C);
     VX_LAUNCH_CHECK();
     return 1;
