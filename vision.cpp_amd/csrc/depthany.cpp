@@ -1092,7 +1092,8 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     // ... or, where the shape is the north star's (32 -> 32 channels, scale <= 0.6), the kernel made for this tail: resize + conv2 + ReLU +
     // conv3 + ReLU with the 3x3 kernel in registers (kernels_headconv.hip)
     static const bool no_headconv = getenv("VISP_NO_HEADCONV") != nullptr;
-    const bool head2_hc = !m.captures && !no_headconv && Wt.head2_frag != SIZE_MAX && Wt.head2.b != SIZE_MAX && vx_headconv_supported(HC, 32, H, W, fh, fw);
+    const bool head2_hc = !m.captures && !no_headconv && Wt.head2_frag != SIZE_MAX && Wt.head2.b != SIZE_MAX && vx_headconv_supported(HC, 32, H, W, fh, fw) &&
+                         (size_t)B * fh * fw * HC * 2 < ((size_t)1 << 31); // (the kernel addresses its source through one 32-bit buffer descriptor)
     const bool head2_bil = !head2_hc && !m.captures && Wt.head2.N == 32 && exec_ctx::bil_ok(Wt.head2, H, W, HC, VX_EPI_HEAD_OUT, fh, fw);
     if (!head2_bil && !head2_hc) {
         c.mark("bilinear", 1, 0, (double)B * ((double)fh * fw + (double)H * W) * HC * 2);

@@ -733,7 +733,7 @@ struct lowering {
         const int r2 = sole_consumer(c3);
         if (r2 < 0 || g.nodes[r2].op != gop_relu) return false; // the kernel's last ReLU is not optional
         const int H = (int)up.ne[2], W = (int)up.ne[1], hs = (int)x.ne[2], ws = (int)x.ne[1], B = (int)x.ne[3];
-        if (!vx_headconv_supported(32, 32, H, W, hs, ws)) return false;
+        if (!vx_headconv_supported(32, 32, H, W, hs, ws) || (size_t)B * hs * ws * 64 >= ((size_t)1 << 31)) return false;
         int last = r2;
         float scale = 1.0f;
         const int sc = sole_consumer(r2);
