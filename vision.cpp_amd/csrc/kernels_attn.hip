@@ -37,6 +37,9 @@ namespace {
 #ifndef VISP_ATTN_PAIR
 #define VISP_ATTN_PAIR 0 // 1: a 4-stage K/V ring and ONE block barrier per two 64-key tiles (A/B: profiles/r03_attention_stamps.txt)
 #endif
+#ifndef VISP_ATTN_RS
+#define VISP_ATTN_RS 1 // row sums: 1 = packed-f16 add tree (default), 2 = two f16 levels then f32, 0 = ones-MFMAs (profiles/r03_attention_stamps.txt)
+#endif
 #ifndef VISP_ATTN_SEQ
 #define VISP_ATTN_SEQ 1 // A/B builds: 0 lets hipcc overlap the two 32-key blocks of a tile (profiles/r03_attention_ab_fastpath.txt)
 #endif
@@ -173,6 +176,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(VISP_AT
         }
         return s;
     };
+    // (Row sum, round 3 late: a packed-f16 add tree over the 16 P registers -- 15 v_pk_add_f16, two converts, one lane-half swap -- replaced
+    // the four ones-MFMAs described below: timing-only ablations showed the kernel is the SUM of its parts (no row-sum MFMAs: -10 %, no PV:
+    // -25 %, no exponentials: -8 %, no barrier / DMA: -11 %), not bound by one pipe; 125 -> 119 us at batch 32, MAE vs the oracle unchanged
+    // (1.6e-4 / 2.2e-4 before). The partial sums are f16: 4 roundings of 2^-11 on sums of <= 16 values, zero-mean; an overflowed P still
+    // makes the sum inf and sends the tile to the full path.)
     // P = exp2(S^T - m_run) of both key blocks as packed f16 fragments (element j of k-step ks <-> key 16ks + 8(j>>2) + 4h + (j&3)),
     // one block at a time so that only 16 score registers are live. Returns the tile's row sum of the f16 P -- the values the PV
     // product uses -- taken on the matrix pipe: ones[32 x 64] P^T has the 64-key sum of query column q in every row, 4 MFMAs (32
@@ -186,6 +194,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(VISP_AT
 #pragma unroll
             for (int e = 0; e < 16; ++e) pf[2 * kb + (e >> 3)][e & 7] = (f16)__builtin_amdgcn_exp2f(s[e]);
             if (VISP_ATTN_SEQ) __builtin_amdgcn_sched_barrier(0); // keep the blocks in sequence: the register budget is 128 (4 waves per SIMD)
+        }
+        if constexpr (VISP_ATTN_RS) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 t[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = h2{pf[i >> 2][2 * (i & 3)], pf[i >> 2][2 * (i & 3) + 1]};
+#pragma unroll
+            for (int w = 8; w >= (VISP_ATTN_RS == 2 ? 4 : 1); w >>= 1)
+#pragma unroll
+                for (int i = 0; i < w; ++i) t[i] = t[i] + t[i + w];
+            float half_sum;
+            if (VISP_ATTN_RS == 2) // two f16 levels (sums of 4 values), the rest in f32
+                half_sum = (((float)t[0][0] + (float)t[0][1]) + ((float)t[1][0] + (float)t[1][1])) + (((float)t[2][0] + (float)t[2][1]) + ((float)t[3][0] + (float)t[3][1]));
+            else
+                half_sum = (float)t[0][0] + (float)t[0][1];
+            return half_sum + other_half(half_sum);
         }
         f32x16 rs = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
