@@ -6,11 +6,14 @@
 // What the reference implements on ggml (graph container, gallocr, one backend kernel per node) is this library's own executor
 // (csrc/graph.cpp): nn-level nodes lowered once into fused launches, constants folded on the host, a liveness arena in HBM.
 // Differences a caller sees, all in how a graph comes to be, none in how it is built or run:
-//   * model_load_weights(path) is model_load + model_init + model_transfer in one call (ml.cpp:206-217, 285-301, 449-516): tensors are
-//     uploaded when the first graph that uses them is allocated, packed for the kernel that reads them, and shared by later graphs;
+//   * model_load / model_init / model_transfer exist with the reference's roles (ml.cpp:206-217, 285-301, 449-516); model_load_weights(path)
+//     is the three in one call. Tensors are uploaded when the first graph that uses them is allocated, packed for the kernel that reads
+//     them, and shared by later graphs;
 //   * compute_graph_init takes the weights its model_refs look names up in (ggml: a second context passed to model_ref);
 //   * `tensor` is a value handle {graph, index, shape}: `x->ne[1]` and `nelements(x)` read as in the reference, there is no ggml_tensor;
 //   * 2D maps are CWHN ([C, W, H, N], model_build_flag::cwhn): the layout helpers of nn.h are identities, interpolate takes CWHN.
+// Source compatibility is checked, not claimed: tests/test_reference_sources_compile.py compiles the reference's src/visp/arch/dino.cpp and
+// depth-anything.cpp where they lie, unmodified, against this header set and builds Depth-Anything through them.
 #pragma once
 
 #include <array>
@@ -34,9 +37,23 @@ constexpr int32_t GGML_TYPE_F32 = 0, GGML_TYPE_F16 = 1;
 constexpr int32_t GGML_SCALE_MODE_NEAREST = 0, GGML_SCALE_MODE_BILINEAR = 1, GGML_SCALE_MODE_BICUBIC = 2, GGML_SCALE_FLAG_ALIGN_CORNERS = 1 << 8;
 
 enum class model_build_flag : uint32_t { cwhn = 1 << 0, conv_2d_direct_cwhn = 1 << 1, concat_n = 1 << 2, f16_conv_transpose = 1 << 3, window_partition = 1 << 4, flash_attention = 1 << 5 };
-using model_build_flags = uint32_t;
-constexpr model_build_flags operator|(model_build_flag a, model_build_flag b) { return uint32_t(a) | uint32_t(b); }
-constexpr model_build_flags operator&(model_build_flags a, model_build_flag b) { return a & uint32_t(b); }
+// a set of model_build_flag bits: `flags |= model_build_flag::cwhn`, `flags & model_build_flag::cwhn ? a : b` (ml.h:66-80)
+struct model_build_flags {
+    uint32_t bits = 0;
+    constexpr model_build_flags() = default;
+    constexpr model_build_flags(model_build_flag f) : bits(uint32_t(f)) {}
+    constexpr explicit model_build_flags(uint32_t b) : bits(b) {}
+    constexpr explicit operator bool() const { return bits != 0; }
+    constexpr bool has(model_build_flag f) const { return (bits & uint32_t(f)) != 0; }
+    constexpr model_build_flags& operator|=(model_build_flags o) { bits |= o.bits; return *this; }
+    constexpr model_build_flags& operator&=(model_build_flags o) { bits &= o.bits; return *this; }
+    friend constexpr model_build_flags operator|(model_build_flags a, model_build_flags b) { return model_build_flags(a.bits | b.bits); }
+    friend constexpr model_build_flags operator&(model_build_flags a, model_build_flags b) { return model_build_flags(a.bits & b.bits); }
+    friend constexpr model_build_flags operator~(model_build_flags a) { return model_build_flags(~a.bits); }
+    friend constexpr bool operator==(model_build_flags a, model_build_flags b) { return a.bits == b.bits; }
+};
+constexpr model_build_flags operator|(model_build_flag a, model_build_flag b) { return model_build_flags(a) | model_build_flags(b); }
+constexpr model_build_flags operator~(model_build_flag a) { return ~model_build_flags(a); }
 // what this backend builds with: NHWC maps, fused attention (ml.cpp:166-186 backend_default_flags)
 inline model_build_flags backend_default_flags(backend_type) { return model_build_flag::cwhn | model_build_flag::flash_attention; }
 
@@ -64,7 +81,39 @@ inline std::array<int64_t, 4> nelements(tensor t) { return {t->ne[0], t->ne[1], 
 inline int64_t n_elements(tensor t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
 
 //
-// model weights (ml.h:85-149)
+// model file (ml.h:85-103): a GGUF file in memory, key/values by name. get_int wants an i32 value, get_array an i32 array of exactly
+// out.size() entries; a missing key throws with its name (ml.cpp:223-254).
+
+struct model_file {
+    visp_file* handle = nullptr;
+    std::string path;
+    model_file() = default;
+    model_file(visp_file* h, std::string p) : handle(h), path(std::move(p)) {}
+    model_file(model_file&& o) noexcept : handle(std::exchange(o.handle, nullptr)), path(std::move(o.path)) {}
+    model_file& operator=(model_file&& o) noexcept { std::swap(handle, o.handle); std::swap(path, o.path); return *this; }
+    ~model_file() { if (handle) visp_file_destroy(handle); }
+
+    int64_t n_tensors() const { int64_t n = 0; detail::check(visp_file_n_tensors(handle, &n)); return n; }
+    int get_int(char const* name) const { int32_t v = 0; detail::check(visp_file_get_int(handle, name, &v)); return v; }
+    void get_array(char const* name, std::span<int> out_values) const { detail::check(visp_file_get_int_array(handle, name, out_values.data(), int64_t(out_values.size()))); }
+    std::string get_string(char const* name) const {
+        int64_t need = 0;
+        detail::check(visp_file_get_string(handle, name, nullptr, 0, &need));
+        std::string v(size_t(need), '\0');
+        detail::check(visp_file_get_string(handle, name, v.data(), need, nullptr));
+        v.resize(size_t(need) - 1);
+        return v;
+    }
+    std::string arch() const { return get_string("general.architecture"); }
+};
+inline model_file model_load(char const* filepath) {
+    visp_file* f = nullptr;
+    detail::check(visp_file_load(filepath, &f));
+    return model_file(f, filepath);
+}
+
+//
+// model weights (ml.h:105-149)
 
 struct model_weights {
     visp_weights* handle = nullptr;
@@ -79,11 +128,19 @@ inline model_weights model_load_weights(char const* filepath) {
     detail::check(visp_weights_load(filepath, &w));
     return model_weights(w);
 }
-inline model_weights model_init() { // an empty store; model_add_tensor fills it (ml.cpp:285-301 model_init + ggml_new_tensor)
+inline model_weights model_init(size_t /*n_tensors*/ = 0) { // an empty store; model_transfer / model_add_tensor fill it (ml.cpp:285-301)
     visp_weights* w = nullptr;
     detail::check(visp_weights_create(&w));
     return model_weights(w);
 }
+// the file's f16 / f32 tensors become the model's weights (ml.cpp:449-516). Nothing is uploaded here: device images are made per consumer
+// role when a graph over the weights is allocated, so the device argument of the reference's signature is optional.
+inline void model_transfer(model_file const& file, model_weights& weights) {
+    visp_weights* w = nullptr;
+    detail::check(visp_weights_from_file(file.handle, &w));
+    weights = model_weights(w);
+}
+inline void model_transfer(model_file const& file, model_weights& weights, backend_device const&) { model_transfer(file, weights); }
 inline void model_add_tensor(model_weights& w, char const* name, int32_t type, i64x4 ne, std::span<float const> data) {
     detail::check(visp_weights_add(w.handle, name, type, ne.data(), data.data()));
 }
@@ -110,6 +167,8 @@ inline bool compute_graph_allocate(compute_graph& g, backend_device const& dev) 
     detail::check(visp_graph_allocate(g.handle, dev.handle));
     return true;
 }
+// lower and plan only: the launch list and the arena size without a device (compute_graph_describe shows them)
+inline void compute_graph_plan(compute_graph& g) { detail::check(visp_graph_allocate(g.handle, nullptr)); }
 inline void compute(compute_graph const& g, backend_device const&) { detail::check(visp_graph_compute(g.handle)); } // blocks until done (ml.cpp:559-562)
 inline std::string compute_graph_describe(compute_graph const& g) { // one line per launch + the arena summary
     int64_t need = 0;
@@ -124,19 +183,20 @@ inline std::string compute_graph_describe(compute_graph const& g) { // one line 
 // model_ref (ml.h:199-245)
 
 struct model_ref {
-    visp_graph* graph = nullptr;
+    compute_graph* graph = nullptr; // `*m.graph` is what the reference hands to ggml_build_forward_expand
     model_build_flags flags = model_build_flag::cwhn | model_build_flag::flash_attention;
     tensor_name prefix;
 
     model_ref() = default;
-    model_ref(compute_graph& g) : graph(g.handle) {}
-    explicit model_ref(visp_graph* g, model_build_flags f = model_build_flag::cwhn | model_build_flag::flash_attention, tensor_name p = {}) : graph(g), flags(f), prefix(std::move(p)) {}
+    model_ref(compute_graph& g) : graph(&g) {}
+    explicit model_ref(compute_graph* g, model_build_flags f = model_build_flag::cwhn | model_build_flag::flash_attention, tensor_name p = {}) : graph(g), flags(f), prefix(std::move(p)) {}
 
+    visp_graph* handle() const { return graph ? graph->handle : nullptr; }
     tensor_name full(char const* name) const { return prefix.empty() ? tensor_name(name) : prefix + "." + name; }
     tensor find(char const* name) const { // null tensor if not found
         int32_t id = -1;
-        detail::check(visp_graph_find_weight(graph, full(name).c_str(), &id));
-        return id < 0 ? tensor() : tensor(graph, id);
+        detail::check(visp_graph_find_weight(handle(), full(name).c_str(), &id));
+        return id < 0 ? tensor() : tensor(handle(), id);
     }
     tensor weights(char const* name) const { // throws if not found (the reference asserts)
         tensor t = find(name);
@@ -150,25 +210,25 @@ struct model_ref {
 };
 
 inline tensor named(model_ref const& m, tensor t) { // ml.cpp:640-643: the tensor takes the current prefix as its name
-    detail::check(visp_graph_set_name(m.graph, t.id, m.prefix.c_str()));
+    detail::check(visp_graph_set_name(m.handle(), t.id, m.prefix.c_str()));
     return t;
 }
 inline tensor set_name(model_ref const& m, tensor t, char const* name) { // ggml_set_name / ggml_format_name
-    detail::check(visp_graph_set_name(m.graph, t.id, name));
+    detail::check(visp_graph_set_name(m.handle(), t.id, name));
     return t;
 }
 inline tensor get_tensor(model_ref const& m, char const* name) { // ggml_get_tensor
     int32_t id = -1;
-    detail::check(visp_graph_get_tensor(m.graph, name, &id));
-    return id < 0 ? tensor() : tensor(m.graph, id);
+    detail::check(visp_graph_get_tensor(m.handle(), name, &id));
+    return id < 0 ? tensor() : tensor(m.handle(), id);
 }
 inline tensor compute_graph_input(model_ref const& m, int32_t type, i64x4 ne, tensor_name name = "input") {
     int32_t id = -1;
-    detail::check(visp_graph_input(m.graph, type, ne.data(), name.c_str(), &id));
-    return tensor(m.graph, id);
+    detail::check(visp_graph_input(m.handle(), type, ne.data(), name.c_str(), &id));
+    return tensor(m.handle(), id);
 }
 inline tensor compute_graph_output(model_ref const& m, tensor t, tensor_name name = "output") {
-    detail::check(visp_graph_output(m.graph, t.id, name.c_str()));
+    detail::check(visp_graph_output(m.handle(), t.id, name.c_str()));
     return t;
 }
 
@@ -191,8 +251,8 @@ inline uint16_t f32_to_f16(float f) { // IEEE binary16, round to nearest even
 inline tensor op(model_ref const& m, int32_t kind, std::initializer_list<tensor> src, std::initializer_list<int64_t> ip = {}, std::initializer_list<float> fp = {}) {
     int32_t ids[4] = {-1, -1, -1, -1}, n = 0, id = -1;
     for (tensor const& t : src) ids[n++] = t.id;
-    check(visp_graph_op(m.graph, kind, ids, n, ip.begin(), int32_t(ip.size()), fp.begin(), int32_t(fp.size()), &id));
-    return tensor(m.graph, id);
+    check(visp_graph_op(m.handle(), kind, ids, n, ip.begin(), int32_t(ip.size()), fp.begin(), int32_t(fp.size()), &id));
+    return tensor(m.handle(), id);
 }
 } // namespace detail
 

@@ -6,6 +6,9 @@
 // with a model_ref where ggml takes its context, which is how that code passes it.
 #pragma once
 
+#include <cstdarg>
+#include <cstdio>
+
 #include "ml.h"
 
 namespace visp {
@@ -66,6 +69,19 @@ inline tensor attention(model_ref m, tensor q, tensor k, tensor v, tensor mask, 
 }
 
 #ifdef VISP_GGML_NAMES
+// the two calls the reference's arch code makes without a context (dino.cpp:104-105): the tensor knows its graph
+inline tensor ggml_format_name(tensor t, char const* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline tensor ggml_format_name(tensor t, char const* fmt, ...) {
+    char buf[128];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    detail::check(visp_graph_set_name(t.graph, t.id, buf));
+    return t;
+}
+// ggml adds the tensor to the forward graph so that it is computed and kept; here: it becomes an output under its current name
+inline void ggml_build_forward_expand(compute_graph& g, tensor t) { detail::check(visp_graph_output(g.handle, t.id, nullptr)); }
 inline tensor ggml_add(model_ref const& m, tensor a, tensor b) { return add(m, a, b); }
 inline tensor ggml_add_inplace(model_ref const& m, tensor a, tensor b) { return add(m, a, b); }
 inline tensor ggml_mul(model_ref const& m, tensor a, tensor b) { return mul(m, a, b); }

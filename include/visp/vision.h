@@ -8,9 +8,12 @@
 // image_normalize, per family *_load_model + *_compute for depth_anything, esrgan, birefnet and sam (sam_encode + sam_compute with a
 // point or a box), and the Depth-Anything pipeline pieces depthany_params / depthany_detect_params / depthany_image_extent /
 // depthany_process_input / depthany_process_output (vision.h:236-252).
-// The ml.h layer -- model_weights, compute_graph, model_ref, tensor, transfer_* -- is visp/ml.h, the nn.h builders visp/nn.h, and
-// depthany_predict(model_ref, tensor, ...) on them visp/arch/depth-anything.h. Not covered: model_file (depthany_detect_params takes the
-// loaded model instead), the *_predict builders of the other families (hand schedules only), migan_* (family not built).
+// The ml.h layer -- model_file, model_weights, compute_graph, model_ref, tensor, transfer_* -- is visp/ml.h, the nn.h builders visp/nn.h.
+// The graph builders of the reference's arch sources (dino::*, dpt::*, depthany_predict) are DECLARED in visp/builders.h and defined by
+// those sources themselves: src/visp/arch/dino.cpp and depth-anything.cpp compile unmodified against these headers with
+// -DVISP_GGML_NAMES -DVISP_ARCH_FROM_SOURCE (tests/test_reference_sources_compile.py). With VISP_ARCH_FROM_SOURCE the pipeline pieces
+// the reference defines in depth-anything.cpp (image_extent / process_input / process_output) are declared here, not defined.
+// Not covered: the *_predict builders of the other families (hand schedules only), migan_* (family not built).
 #pragma once
 
 #include <array>
@@ -25,6 +28,9 @@
 #include "../visp_c_api.h"
 
 namespace visp {
+using std::byte;
+using std::span;
+using f32x4 = std::array<float, 4>; // per-channel offset / scale of image_u8_to_f32 (arithmetic: util/math.h)
 
 struct exception : std::exception { // reference src/util/... visp::exception: what() = the library's message
     std::string message;
@@ -73,6 +79,7 @@ struct image_view { // include/visp/image.h:37-41: non-owning
     image_view(i32x2 e, image_format f, void const* d) : extent(e), stride(e[0] * n_bytes(f)), format(f), data(d) {}
     image_view(i32x2 e, int32_t s, image_format f, void const* d) : extent(e), stride(s), format(f), data(d) {}
     image_view(image_data const& img);
+    image_view(i32x2 e, std::span<float const> d) : image_view(e, image_format::alpha_f32, d.data()) {} // one float per pixel
     std::span<uint8_t const> as_bytes() const { return {static_cast<uint8_t const*>(data), size_t(stride) * size_t(extent[1])}; }
     std::span<float const> as_floats() const { return {static_cast<float const*>(data), size_t(extent[0]) * size_t(extent[1]) * size_t(n_channels(format))}; }
 };
@@ -199,6 +206,12 @@ struct depthany_params {
     std::array<int, 4> feature_layers = {2, 5, 8, 11};
     dino_params dino;
 };
+#ifdef VISP_ARCH_FROM_SOURCE
+// the reference's own definitions (src/visp/arch/depth-anything.cpp:112-149) are part of the build
+i32x2 depthany_image_extent(i32x2 input_extent, depthany_params const&);
+image_data depthany_process_input(image_view image, depthany_params const&);
+image_data depthany_process_output(std::span<float const> output_data, i32x2 target_extent, depthany_params const&);
+#else
 // round the short side up to a multiple of image_multiple (at least image_size), keep the aspect ratio, round both up (:112-117)
 inline i32x2 depthany_image_extent(i32x2 extent, depthany_params const& p) {
     auto next_multiple = [](int x, int m) { return (x + m - 1) / m * m; };
@@ -206,6 +219,7 @@ inline i32x2 depthany_image_extent(i32x2 extent, depthany_params const& p) {
     const int tgt = next_multiple(min_side, p.image_multiple) > p.image_size ? next_multiple(min_side, p.image_multiple) : p.image_size;
     return i32x2(next_multiple(extent[0] * tgt / min_side, p.image_multiple), next_multiple(extent[1] * tgt / min_side, p.image_multiple));
 }
+#endif
 inline depthany_params depthany_detect_params(depthany_model const& model, i32x2 input_extent = {}) { // (:119-128)
     visp_depthany_info info{};
     detail::check(visp_depthany_get_info(model.handle, &info));
@@ -218,6 +232,7 @@ inline depthany_params depthany_detect_params(depthany_model const& model, i32x2
     if (input_extent[0] > 0 && input_extent[1] > 0) p.image_extent = depthany_image_extent(input_extent, p);
     return p;
 }
+#ifndef VISP_ARCH_FROM_SOURCE
 // image_scale to the model extent where it differs, then (u8 / 255 - mean) / std -> rgb_f32 (:130-140)
 inline image_data depthany_process_input(image_view image, depthany_params const& p) {
     image_data resized;
@@ -233,6 +248,7 @@ inline image_data depthany_process_output(std::span<float const> output_data, i3
     if (normalized.extent[0] != target_extent[0] || normalized.extent[1] != target_extent[1]) return image_scale(normalized, target_extent);
     return normalized;
 }
+#endif
 
 // ESRGAN (vision.h:284-304): any size, tiled, -> rgba_u8 at scale x the input extent (vision.cpp:220-253)
 using esrgan_model = detail::model_handle<VISP_ESRGAN>;

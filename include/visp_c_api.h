@@ -126,7 +126,7 @@ VISP_API int32_t visp_depthany_pipeline_wait(visp_depthany_pipeline* p, int32_t 
  * every later compute of that shape (enable = 0 turns it off) */
 VISP_API int32_t visp_depthany_use_graph(visp_model* m, int32_t enable);
 /* encoder schedule: -1 = auto (default: 1 where the model has the kernel's shape), 0 = one launch per op group, 1 = one attention
- * + one token-stationary block launch per layer (csrc/kernels_block.hip; embed dim 384 / mlp 1536 / head dim 64 only).
+ * + one token-stationary block launch per layer (csrc/kernels_block16.hip; embed dim 384 / mlp 1536 / head dim 64 only).
  * Results agree to f16 rounding. */
 VISP_API int32_t visp_depthany_set_schedule(visp_model* m, int32_t schedule);
 /* sub-batches of one step on parallel HIP streams (parallel branches of the step's hipGraph): 0 = automatic (3 from batch 24, 2
@@ -266,6 +266,16 @@ enum visp_graph_op {
  * <arch>.conv2d_weights of a whcn file are presented as [Cin,kw,kh,Cout]. Device images are made when a graph that uses a tensor is
  * allocated, once per (tensor, role), and are reused by later graphs over the same weights. */
 VISP_API int32_t visp_weights_load(char const* gguf_path, visp_weights** out);
+/* model_file (ml.h:85-103; ml.cpp:206-281): a GGUF file read into memory, its key/values by name. get_int needs an i32 value, the array
+ * getter an i32 array of exactly n entries (the reference's rules); a missing key is an error naming it. */
+typedef struct visp_file visp_file;
+VISP_API int32_t visp_file_load(char const* gguf_path, visp_file** out);
+VISP_API void visp_file_destroy(visp_file* f);
+VISP_API int32_t visp_file_n_tensors(visp_file const* f, int64_t* out);
+VISP_API int32_t visp_file_get_int(visp_file const* f, char const* key, int32_t* out);
+VISP_API int32_t visp_file_get_int_array(visp_file const* f, char const* key, int32_t* out, int64_t n);
+VISP_API int32_t visp_file_get_string(visp_file const* f, char const* key, char* out, int64_t capacity, int64_t* needed);
+VISP_API int32_t visp_weights_from_file(visp_file const* f, visp_weights** out); /* model_transfer: the file's tensors as model weights */
 VISP_API int32_t visp_weights_create(visp_weights** out);
 VISP_API int32_t visp_weights_add(visp_weights* w, char const* name, int32_t dtype, int64_t const ne[4], float const* data);
 VISP_API void visp_weights_destroy(visp_weights* w); /* graphs over the weights keep them alive */

@@ -268,15 +268,18 @@ VX_API void vx_attention_set_fast_limit(float limit);
 /* diagnostics (tools/attn_stamps.py): u64 [blocks][waves][4] = cycles in {wait + barrier, scores + softmax, PV, lifetime}; NULL = off */
 VX_API void vx_attention_set_stamps(void* stamps);
 
-/* ---- token-stationary DINOv2 block (kernels_block.hip; embed dim 384, mlp 1536, head dim 64) ------------------------------
+/* ---- token-stationary DINOv2 block (kernels_block16.hip; embed dim 384, mlp 1536, head dim 64) ----------------------------
  * One launch per layer replaces everything between two attentions of dino::layer (src/visp/arch/dino.cpp:48-90):
  *   att != NULL:  x += lambda1 * (att Wo^T + bo);  x += lambda2 * (gelu(LN2(x) W1^T + b1) W2^T + b2)
  *   feat != NULL: feat = LN_final(x) as f16 rows (get_intermediate_layers, dino.cpp:100-107)
  *   q != NULL:    q, k, v = LN1(x) Wqkv^T + b of the NEXT layer, head-major f16 [B, H, T, 64], q scaled by q_scale
  * (att == NULL, q != NULL: the first layer's LN1 + QKV on x as it is.)
- * att f16 [M, 384]; x f32 [M, 384] in place; weights as the slab streams of vx_dino_block_pack_mlp / _qkv;
- * vec_mlp f32 = bo | lambda1 | ln2.w | ln2.b | b1[1536] | b2 | lambda2 (3840 floats), vec_qkv f32 = ln1.w | ln1.b | bqkv[1152]
- * (1920 floats), vec_tap f32 = lnf.w | lnf.b (768 floats). M % T == 0 when q != NULL. */
+ * att f16 [M, 384]; x f32 [M, 384] in place; weights as the slab streams of vx_dino_block16_pack_mlp / _qkv. LayerScale arrives FOLDED
+ * in by the caller: wo / w2 rows and bo / b2 scaled by lambda1 / lambda2 -- the residual stream then stays in the MFMA accumulators from
+ * the attention output to the next layer's q, k, v (x read once, written once per launch).
+ * vec_mlp f32 = bo' | (unused) | ln2.w | ln2.b | b1[1536] | b2' | (unused) (3840 floats), vec_qkv f32 = ln1.w | ln1.b | bqkv[1152]
+ * (1920 floats), vec_tap f32 = lnf.w | lnf.b (768 floats). M % T == 0 when q != NULL. 16 tokens per wave on v_mfma_f32_16x16x32_f16,
+ * two waves per SIMD. */
 typedef struct {
     const void* att; float* x;
     const void* w_mlp; const float* vec_mlp;
@@ -291,15 +294,8 @@ typedef struct {
 VX_API int vx_dino_block_supported(int embed_dim, int hidden, int head_dim);
 VX_API size_t vx_dino_block_mlp_bytes(void);
 VX_API size_t vx_dino_block_qkv_bytes(void);
-/* host code: f16 row-major wo [384][384], w1 [1536][384], w2 [384][1536] -> out (vx_dino_block_mlp_bytes());
+/* host code: f16 row-major wo' [384][384], w1 [1536][384], w2' [384][1536] -> out (vx_dino_block_mlp_bytes());
  * wqkv [1152][384] (q rows, then k, then v) -> out (vx_dino_block_qkv_bytes()) */
-VX_API int vx_dino_block_pack_mlp(const void* wo, const void* w1, const void* w2, void* out);
-VX_API int vx_dino_block_pack_qkv(const void* wqkv, void* out);
-VX_API int vx_dino_block_f16(const vx_dino_block_args* args, void* stream);
-/* the same operation on v_mfma_f32_16x16x32_f16 with 16 tokens per wave and two waves per SIMD (kernels_block16.hip); same
- * argument block, its own slab contents (same sizes: vx_dino_block_mlp_bytes / _qkv_bytes). It expects LayerScale FOLDED in by the
- * caller: wo / w2 rows and bo / b2 scaled by lambda1 / lambda2 (the lambda slots of vec_mlp are not read) -- the residual stream then
- * stays in the MFMA accumulators from the attention output to the next layer's q, k, v (x read once, written once). */
 VX_API int vx_dino_block16_pack_mlp(const void* wo, const void* w1, const void* w2, void* out);
 VX_API int vx_dino_block16_pack_qkv(const void* wqkv, void* out);
 VX_API int vx_dino_block16_f16(const vx_dino_block_args* args, void* stream);
@@ -307,12 +303,6 @@ VX_API int vx_dino_block16_f16(const vx_dino_block_args* args, void* stream);
 /* ---- LayerNorm (nn.cpp:14-19): x f32 [M,C] -> y f16 [M,C]; biased variance, eps in sqrt --- */
 VX_API int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y, int M, int C,
                                 float eps, void* stream);
-/* x f32 [M,C] += lambda[C] * y_in f16 [M,C] (stored back), then LayerNorm of the updated row -> y f16 [M,C]
- * (y == NULL: update only). The residual add of dino.cpp:80-90 fused into the LayerNorm that follows it; the
- * projection GEMM then writes y_in with a plain f16 epilogue. C in {128, 384, 768, 1024}. */
-VX_API int vx_layernorm_resid_supported(int C);
-VX_API int vx_layernorm_resid_f32_f16(float* x, const void* y_in, const float* lambda, const float* w, const float* b, void* y, int M,
-                                      int C, float eps, void* stream);
 
 /* ---- pre-processing (depth-anything.cpp:130-140, image.cpp:215-255) + im2col of the 14x14
  * stride-14 patch embedding (nn.cpp:166-180): rgb_u8 [B,H,W,3] -> f16 [B*P, Kp],

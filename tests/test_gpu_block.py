@@ -1,4 +1,4 @@
-"""-m gpu: the token-stationary DINOv2 block kernel (csrc/kernels_block.hip, vx_dino_block_f16) against the CPU oracle's
+"""-m gpu: the token-stationary DINOv2 block kernel (csrc/kernels_block16.hip, vx_dino_block16_f16) against the CPU oracle's
 linear / layer_norm / gelu on the same seeded inputs, through the vx_* C ABI. Every output the kernel produces is
 compared: the residual stream after the attention half (capture), after the MLP half, the tapped LayerNorm rows and the
 next layer's head-major q / k / v. Tolerances are relative to the largest reference magnitude of each tensor."""
@@ -51,11 +51,11 @@ def make_weights(seed, lam=0.1):
 
 def pack(w, fn=None):
     a = api()
-    pack_mlp, pack_qkv = (fn.pack_mlp, fn.pack_qkv) if fn is not None else (a.vx_dino_block_pack_mlp, a.vx_dino_block_pack_qkv)
+    pack_mlp, pack_qkv = (fn.pack_mlp, fn.pack_qkv) if fn is not None else (a.vx_dino_block16_pack_mlp, a.vx_dino_block16_pack_qkv)
     mlp = np.zeros(a.vx_dino_block_mlp_bytes() // 2, np.uint16)
     qkv = np.zeros(a.vx_dino_block_qkv_bytes() // 2, np.uint16)
     f16 = lambda m: np.ascontiguousarray(m.astype(np.float16))  # noqa: E731
-    fold = fn is not None and getattr(fn, "folded", False)  # the 16-token form takes LayerScale folded into Wo / W2 and their biases
+    fold = fn is None or getattr(fn, "folded", True)  # the kernel takes LayerScale folded into Wo / W2 and their biases
     l1, l2 = (w["lam1"], w["lam2"]) if fold else (np.ones(D, np.float32), np.ones(D, np.float32))
     wo, w1, w2, wq = f16(l1[:, None] * w["wo"]), f16(w["w1"]), f16(l2[:, None] * w["w2"]), f16(w["wqkv"])
     L.vx_check(pack_mlp(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, mlp.ctypes.data))
@@ -90,10 +90,10 @@ def reference(w, x, att, eps, mlp, tap, qkv, T, q_scale):
     return out
 
 
-@pytest.fixture(params=["vx_dino_block", "vx_dino_block16"], ids=["32-token", "16-token"])
+@pytest.fixture(params=["vx_dino_block16"], ids=["16-token"])
 def block_fn(request):
-    """Both forms of the kernel (kernels_block.hip: 32 tokens per wave, one wave per SIMD; kernels_block16.hip: 16 tokens per wave,
-    two waves per SIMD); each has its own weight packers, the launch carries them along for pack()."""
+    """The kernel (kernels_block16.hip: 16 tokens per wave, two waves per SIMD) with its weight packers; the launch carries them along
+    for pack(). (The 32-token first form was removed in round 4; its numbers are in profiles/r02_block_kernel_anatomy.txt.)"""
     a = api()
     fn = getattr(a, request.param + "_f16")
     fn.pack_mlp, fn.pack_qkv = getattr(a, request.param + "_pack_mlp"), getattr(a, request.param + "_pack_qkv")
@@ -260,8 +260,8 @@ def test_block_rows_are_independent(block_fn):
 
 def test_block_argument_errors():
     a = L.DinoBlockArgs()
-    assert api().vx_dino_block_f16(C.byref(a), None) == 0  # empty problem
+    assert api().vx_dino_block16_f16(C.byref(a), None) == 0  # empty problem
     x = empty(128 * D * 4)
     a.x, a.M = x.ptr, 128
-    assert api().vx_dino_block_f16(C.byref(a), None) == 0 and b"nothing to do" in api().vx_last_error()
+    assert api().vx_dino_block16_f16(C.byref(a), None) == 0 and b"nothing to do" in api().vx_last_error()
     assert api().vx_dino_block_supported(384, 1536, 64) == 1 and api().vx_dino_block_supported(768, 3072, 64) == 0

@@ -328,19 +328,17 @@ def test_intermediates_are_not_readable_and_errors_surface(device):
         g2.allocate()
 
 
-@pytest.mark.parametrize("w,h", [(518, 518), (640, 480)])
-def test_cpp_graph_layer_runs_the_reference_call_sequence(tmp_path, w, h):
-    """tests/cpp/graph_check.cpp: include/visp/ml.h + nn.h + arch/depth-anything.h used the way the reference's depthany_compute uses its
-    graph layer (vision.cpp:137-167) -- model_load_weights, compute_graph_init, model_ref, compute_graph_input, depthany_predict,
-    compute_graph_allocate, transfer_to_backend, compute, transfer_from_backend -- against the hand-scheduled depthany_compute.
-    640 x 480 goes through image_scale to 700 x 518 and back (non-square grid: resized position embeddings)."""
+def test_cpp_graph_layer_on_a_network_of_its_own():
+    """tests/cpp/graph_check.cpp: include/visp/ml.h + nn.h from C++ (model_init, model_add_tensor, compute_graph_init, model_ref prefixes,
+    compute_graph_input / _output, the nn.h builders, compute_graph_allocate, transfer_to_backend, compute, transfer_from_backend) on a token
+    mixer + small conv decoder that the same program also evaluates in float loops. (Depth-Anything itself is built through this layer by the
+    reference's own arch sources in tests/test_reference_sources_compile.py, and through the Python face below.)"""
     import subprocess
     from pathlib import Path
 
     exe = Path(__file__).resolve().parents[1] / "vision.cpp_amd" / "lib" / "graph_check"
     assert exe.exists(), "run __graft_entry__.build() first"
-    path = synth.write_gguf(tmp_path / "small.gguf", synth.SMALL, seed=0)
-    r = subprocess.run([str(exe), str(path), str(w), str(h)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0 and "graph_check ok" in r.stdout, (r.stdout, r.stderr)
 

@@ -443,28 +443,6 @@ def test_conv3x3_halo_kernel(cin, cout, hw, mode):
     assert rel_err(out.to_numpy(np.float16, (B, Hh, Ww, cout)).astype(np.float32), want) < F16_TOL
 
 
-@pytest.mark.parametrize("M,Cc", [(7, 384), (300, 384), (65, 128), (33, 768)])
-def test_layernorm_with_deferred_residual(M, Cc):
-    """vx_layernorm_resid_f32_f16: x += lambda * y (f32, stored back) then LayerNorm of the updated row
-    (dino.cpp:80-90 with the residual add moved out of the projection GEMM's epilogue)."""
-    rng = np.random.default_rng(M + Cc)
-    x = _rand(rng, M, Cc) * 3
-    y = _h(_rand(rng, M, Cc))
-    lam, w, b = _rand(rng, Cc, scale=0.3), 1 + _rand(rng, Cc, scale=0.2), _rand(rng, Cc, scale=0.2)
-    xd, out = dev(x.astype(np.float32)), empty(M * Cc * 2)
-    L.vx_check(api().vx_layernorm_resid_f32_f16(xd.ptr, dev(y.astype(np.float16)).ptr, dev(lam).ptr, dev(w).ptr, dev(b).ptr, out.ptr, M, Cc, 1e-6, None))
-    sync()
-    x_new = x + lam * y
-    np.testing.assert_allclose(xd.to_numpy(np.float32, (M, Cc)), x_new, rtol=1e-6, atol=1e-6)
-    want = oracle.layer_norm(x_new, w, b, 1e-6)
-    assert rel_err(out.to_numpy(np.float16, (M, Cc)).astype(np.float32), want) < F16_TOL
-    # update only
-    xd2 = dev(x.astype(np.float32))
-    L.vx_check(api().vx_layernorm_resid_f32_f16(xd2.ptr, dev(y.astype(np.float16)).ptr, dev(lam).ptr, None, None, None, M, Cc, 1e-6, None))
-    sync()
-    np.testing.assert_allclose(xd2.to_numpy(np.float32, (M, Cc)), x_new, rtol=1e-6, atol=1e-6)
-
-
 @pytest.mark.parametrize("cin,cout,stride,hw,epi", [(384, 64, 1, (19, 19), "plain"), (192, 64, 1, (37, 37), "relu"), (384, 384, 2, (37, 37), "plain"),
                                                       (256, 64, 1, (9, 13), "add")])
 def test_conv_split_k(cin, cout, stride, hw, epi):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the token-stationary DINOv2 block kernel (vx_dino_block_f16) at the north-star shape
+"""Micro-benchmark of the token-stationary DINOv2 block kernel (vx_dino_block16_f16) at the north-star shape
 (M = 32 x 1370 tokens), next to the launches it replaces (LayerNorm + QKV / out-proj / fc1 / fc2 GEMMs)."""
 import ctypes as C
 import os
@@ -14,7 +14,7 @@ from bench_kernels import api, gemm_case, stream, timeit, L, DeviceBuffer  # noq
 D, HID, H, T = 384, 1536, 6, 1370
 
 
-def block_case(B, mlp=True, tap=False, qkv=True, fn="vx_dino_block_f16"):
+def block_case(B, mlp=True, tap=False, qkv=True, fn="vx_dino_block16_f16"):
     M = B * T
     rng = np.random.default_rng(0)
     f16 = lambda *s, sc=1.0: np.ascontiguousarray((rng.standard_normal(s) * sc).astype(np.float16))  # noqa: E731
@@ -59,6 +59,12 @@ if __name__ == "__main__" and "--pmc" in sys.argv:
     attn_case(32, 6, 1370)
     sys.exit(0)
 
+if __name__ == "__main__" and "--l2" in sys.argv:
+    # target of the L2 counter passes (tools/pmc_block_l2.sh): the block kernel at 118 / 247 / 343 workgroups, nothing else
+    for B in (11, 23, 32):
+        block_case(B, fn="vx_dino_block16_f16")
+    sys.exit(0)
+
 if __name__ == "__main__" and "--only16" in sys.argv:
     for B in (23, 32, 11):
         block_case(B, fn="vx_dino_block16_f16")
@@ -72,12 +78,6 @@ if __name__ == "__main__" and "--stamps" not in sys.argv:
             block_case(11, fn=f16)
             block_case(32, mlp=False, fn=f16)
             block_case(32, qkv=False, tap=True, fn=f16)
-        block_case(11)
-        block_case(23)          # 247 workgroups: one round on 256 CUs
-        block_case(32)          # 343 workgroups: the north-star batch, two rounds
-        block_case(32, tap=True)
-        block_case(32, mlp=False)
-        block_case(32, qkv=False, tap=True)
     if "--gemms" in sys.argv:
         M = 32 * T
         gemm_case("qkv", M, 1152, 384, L.EPI_QKV, 0)
@@ -86,7 +86,7 @@ if __name__ == "__main__" and "--stamps" not in sys.argv:
         gemm_case("out_resid", M, 384, 384, L.EPI_RESID_F32, 0)
 
 
-def block_stamps(B, fn="vx_dino_block_f16"):
+def block_stamps(B, fn="vx_dino_block16_f16"):
     """Per-workgroup phase anatomy from in-kernel s_memtime stamps (diagnostic)."""
     M = B * T
     rng = np.random.default_rng(0)
@@ -141,6 +141,5 @@ if __name__ == "__main__" and "--stamps16" in sys.argv:
     sys.exit(0)
 
 if __name__ == "__main__" and "--stamps" in sys.argv:
-    for fn in ("vx_dino_block16_f16", "vx_dino_block_f16"):
-        block_stamps(11, fn)
-        block_stamps(23, fn)
+    block_stamps(11)
+    block_stamps(23)

@@ -106,6 +106,7 @@ C_API_SYMBOLS = [
     "visp_swin_load", "visp_swin_output_dims", "visp_swin_encode_batch_device", "visp_swin_encode_batch_host", "visp_swin_enable_captures",
     "visp_swin_read_capture", "visp_swin_enable_timing", "visp_swin_read_timing", "visp_swin_set_mask_mode",
     "visp_weights_load", "visp_weights_create", "visp_weights_add", "visp_weights_destroy",
+    "visp_file_load", "visp_file_destroy", "visp_file_n_tensors", "visp_file_get_int", "visp_file_get_int_array", "visp_file_get_string", "visp_weights_from_file",
     "visp_graph_create", "visp_graph_destroy", "visp_graph_add_weight", "visp_graph_find_weight", "visp_graph_input",
     "visp_graph_op", "visp_graph_set_name", "visp_graph_get_tensor", "visp_graph_output", "visp_graph_tensor_info", "visp_graph_read_constant",
     "visp_graph_allocate", "visp_graph_use_hip_graph", "visp_graph_compute", "visp_graph_tensor_set", "visp_graph_tensor_get", "visp_graph_describe",
@@ -116,7 +117,7 @@ KERNEL_SYMBOLS = [
     "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_stream_wait_event", "vx_graph_begin_capture",
     "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_gemm_pick_k_splits", "vx_conv3x3_supported", "vx_conv3x3_f16",
     "vx_attention_f16", "vx_attention_set_fast_limit", "vx_attention_set_stamps",
-    "vx_layernorm_f32_f16", "vx_layernorm_resid_supported", "vx_layernorm_resid_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
+    "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
     "vx_dconv3x3_f16", "vx_dconv_bilinear_supported", "vx_dconv_prepare", "vx_tv_preprocess", "vx_dwconv3x3_f16", "vx_layernorm_f16", "vx_window_attention_f16", "vx_window_attention_bias_bytes", "vx_window_attention_pack_bias",
     "vx_window_reverse_add_f16", "vx_add_gelu_f16", "vx_add_rows_f16", "vx_small_attention_f16", "vx_sam_interpolate", "vx_mbconv_dw_pw_supported", "vx_mbconv_pack_w3", "vx_mbconv_dw_pw_f16", "vx_esrgan_tiles_in", "vx_esrgan_tiles_out",
@@ -124,7 +125,7 @@ KERNEL_SYMBOLS = [
     "vx_swin_attention_pack_bias", "vx_window_attention_masked_f16", "vx_swin_layernorm_f16", "vx_swin_layernorm_strided_f16", "vx_swin_merge_layernorm_f16", "vx_swin_window_reverse_add_f16",
     "vx_headconv_frag_bytes", "vx_headconv_pack", "vx_headconv_supported", "vx_headconv_bil_f16", "vx_headconv_set_stamps",
     "vx_copy_strided_f16", "vx_binary_rows", "vx_unary_f16", "vx_convert", "vx_im2col_patches_f32", "vx_conv1x1_to1_f32",
-    "vx_dino_block_supported", "vx_dino_block_mlp_bytes", "vx_dino_block_qkv_bytes", "vx_dino_block_pack_mlp", "vx_dino_block_pack_qkv", "vx_dino_block_f16", "vx_dino_block16_pack_mlp", "vx_dino_block16_pack_qkv", "vx_dino_block16_f16",
+    "vx_dino_block_supported", "vx_dino_block_mlp_bytes", "vx_dino_block_qkv_bytes", "vx_dino_block16_pack_mlp", "vx_dino_block16_pack_qkv", "vx_dino_block16_f16",
 ]
 
 
@@ -229,6 +230,13 @@ def init() -> ctypes.CDLL:
     lib.visp_graph_destroy.argtypes = [c_void_p]
     lib.visp_weights_load.argtypes = [c_char_p, POINTER(c_void_p)]
     lib.visp_weights_create.argtypes = [POINTER(c_void_p)]
+    lib.visp_file_load.argtypes = [c_char_p, POINTER(c_void_p)]
+    lib.visp_file_destroy.argtypes = [c_void_p]
+    lib.visp_file_n_tensors.argtypes = [c_void_p, POINTER(c_int64)]
+    lib.visp_file_get_int.argtypes = [c_void_p, c_char_p, POINTER(c_int32)]
+    lib.visp_file_get_int_array.argtypes = [c_void_p, c_char_p, POINTER(c_int32), c_int64]
+    lib.visp_file_get_string.argtypes = [c_void_p, c_char_p, c_char_p, c_int64, POINTER(c_int64)]
+    lib.visp_weights_from_file.argtypes = [c_void_p, POINTER(c_void_p)]
     lib.visp_weights_add.argtypes = [c_void_p, c_char_p, c_int32, POINTER(c_int64), c_void_p]
     lib.visp_weights_destroy.argtypes = [c_void_p]
     lib.visp_graph_add_weight.argtypes = [c_void_p, c_char_p, c_int32, POINTER(c_int64), c_void_p, POINTER(c_int32)]
@@ -251,6 +259,7 @@ def init() -> ctypes.CDLL:
     lib.visp_depthany_pipeline_destroy.restype = None
     lib.visp_graph_destroy.restype = None
     lib.visp_weights_destroy.restype = None
+    lib.visp_file_destroy.restype = None
 
     lib.vx_last_error.restype = c_char_p
     lib.vx_device_info.argtypes = [c_int, c_char_p, c_int, c_char_p, c_int, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_int)]
@@ -292,8 +301,6 @@ def init() -> ctypes.CDLL:
     lib.vx_head_out_f32.argtypes = [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_int, c_void_p]
     lib.vx_minmax_normalize.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]
     lib.vx_f32_to_u8.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
-    lib.vx_layernorm_resid_supported.argtypes = [c_int]
-    lib.vx_layernorm_resid_f32_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
     lib.vx_tv_preprocess.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     lib.vx_dwconv3x3_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.vx_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_int, c_void_p]
@@ -335,9 +342,6 @@ def init() -> ctypes.CDLL:
     lib.vx_dino_block_mlp_bytes.restype = c_size_t
     lib.vx_dino_block_qkv_bytes.argtypes = []
     lib.vx_dino_block_qkv_bytes.restype = c_size_t
-    lib.vx_dino_block_pack_mlp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
-    lib.vx_dino_block_pack_qkv.argtypes = [c_void_p, c_void_p]
-    lib.vx_dino_block_f16.argtypes = [POINTER(DinoBlockArgs), c_void_p]
     lib.vx_dino_block16_pack_mlp.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
     lib.vx_dino_block16_pack_qkv.argtypes = [c_void_p, c_void_p]
     lib.vx_dino_block16_f16.argtypes = [POINTER(DinoBlockArgs), c_void_p]

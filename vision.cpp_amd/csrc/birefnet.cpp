@@ -262,7 +262,7 @@ birefnet_model* birefnet_load_model(char const* filepath, backend_device const& 
         D.conv_out1 = pk.conv(d + "conv_out1.0", &k, &cin);
         if (k != 1 || D.conv_out1.n_real != 1 || cin != carried + D.ipt[4].cout) throw except("birefnet: decoder.conv_out1.0 has an unexpected shape");
     }
-    VX(vx_set_device(dev.index));
+    device_turn turn(dev);
     model->dec_arena.bytes = round_up<size_t>(ab.data.size(), 256) + 4096;
     VX(vx_malloc(&model->dec_arena.ptr, model->dec_arena.bytes));
     VX(vx_memcpy_h2d(model->dec_arena.ptr, ab.data.data(), ab.data.size(), dev.stream));
@@ -274,7 +274,7 @@ void birefnet_compute_batch_device(birefnet_model& m, void const* rgb_dev, int B
     if (B < 1 || !rgb_dev || !mask_dev) throw except("birefnet: empty batch or null pointer");
     // the half-size pass needs extents that are multiples of 32 after the division by 2 (swin: patch 4, three even merges)
     if (w < 64 || h < 64 || w % 64 || h % 64) throw except("birefnet: image extent %dx%d must be a positive multiple of 64", w, h);
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     void* s = stream ? stream : m.backend->stream;
     birefnet_weights const& D = m.dec;
     const int C0 = m.params.embed_dim;
@@ -429,7 +429,7 @@ void birefnet_compute_batch_device(birefnet_model& m, void const* rgb_dev, int B
 
 void birefnet_compute_batch_host(birefnet_model& m, uint8_t const* rgb, int B, int w, int h, float* mask) {
     if (B < 1 || !rgb || !mask) throw except("birefnet: empty batch or null pointer");
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     void* s = m.backend->stream;
     void *in = nullptr, *out = nullptr;
     auto release = [&]() { vx_free(in); vx_free(out); };

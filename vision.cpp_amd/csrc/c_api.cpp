@@ -28,6 +28,7 @@ struct visp_image_data : image_data {};
 struct visp_device : backend_device {};
 struct visp_graph : graph {};
 struct visp_weights { std::shared_ptr<weight_store> store; };
+struct visp_file { model_file file; };
 // visp_model stays opaque: handles are depthany_model* (any_model in the reference, c-api.cpp:193)
 
 namespace {
@@ -352,23 +353,15 @@ int32_t visp_depthany_compute_sharded(visp_model* const* models, int32_t n_model
         }
         std::vector<std::string> errors((size_t)n_models);
         std::vector<std::thread> threads;
-        // models that sit on the same backend_device share its compute stream (a one-GPU rehearsal of the multi-device call): their
-        // shards take turns -- two host threads must not capture a hipGraph on one stream at once. One device per model: no lock.
-        std::map<void*, std::unique_ptr<std::mutex>> stream_turn;
-        for (auto* m : ms) {
-            int sharers = 0;
-            for (auto* o : ms) sharers += o->backend->stream == m->backend->stream;
-            if (sharers > 1 && !stream_turn.count(m->backend->stream)) stream_turn[m->backend->stream] = std::make_unique<std::mutex>();
-        }
+        // models that sit on the same backend_device share its compute stream (a one-GPU rehearsal of the multi-device call): every call
+        // that touches that stream holds the device's turn (device_turn, csrc/depthany.h), so the shards interleave chunk by chunk and a
+        // hipGraph capture by one thread is never crossed by another thread's launches
         const int base = batch / n_models, rem = batch % n_models;
         for (int i = 0; i < n_models; ++i) {
             const int begin = i * base + std::min(i, rem), count = base + (i < rem ? 1 : 0);
             if (count == 0) continue;
             threads.emplace_back([&, i, begin, count]() {
                 try {
-                    auto turn = stream_turn.find(ms[(size_t)i]->backend->stream);
-                    std::unique_lock<std::mutex> lock;
-                    if (turn != stream_turn.end()) lock = std::unique_lock<std::mutex>(*turn->second);
                     depthany_compute_shard_host(*ms[(size_t)i], rgb + (size_t)begin * h * w * 3, count, w, h, out + (size_t)begin * h * w);
                 } catch (std::exception const& e) {
                     errors[(size_t)i] = e.what();
@@ -731,6 +724,53 @@ int32_t visp_swin_read_timing(visp_model* m, visp_timing* out, int32_t cap, int3
     });
 }
 
+// ---- model file: the GGUF key/value surface of the reference's model_file (ml.h:85-103, ml.cpp:206-281) ----
+
+static model_file const& as_file(visp_file const* f) {
+    if (!f) throw except("model file handle is null");
+    return f->file;
+}
+int32_t visp_file_load(char const* gguf_path, visp_file** out) {
+    return handle_errors([&]() {
+        if (!out) throw except("visp_file_load: null out pointer");
+        if (!gguf_path) throw except("visp_file_load: null path");
+        *out = new visp_file{model_load(gguf_path)};
+    });
+}
+void visp_file_destroy(visp_file* f) { delete f; }
+int32_t visp_file_n_tensors(visp_file const* f, int64_t* out) {
+    return handle_errors([&]() {
+        if (!out) throw except("visp_file_n_tensors: null out pointer");
+        *out = as_file(f).n_tensors();
+    });
+}
+int32_t visp_file_get_int(visp_file const* f, char const* key, int32_t* out) {
+    return handle_errors([&]() {
+        if (!key || !out) throw except("visp_file_get_int: null argument");
+        *out = as_file(f).get_int(key);
+    });
+}
+int32_t visp_file_get_int_array(visp_file const* f, char const* key, int32_t* out, int64_t n) {
+    return handle_errors([&]() {
+        if (!key || !out || n < 0) throw except("visp_file_get_int_array: bad argument");
+        as_file(f).get_array(key, out, (size_t)n);
+    });
+}
+int32_t visp_file_get_string(visp_file const* f, char const* key, char* out, int64_t capacity, int64_t* needed) {
+    return handle_errors([&]() {
+        if (!key) throw except("visp_file_get_string: null key");
+        std::string_view v = as_file(f).get_string(key);
+        if (needed) *needed = (int64_t)v.size() + 1;
+        if (out && capacity > 0) snprintf(out, (size_t)capacity, "%.*s", (int)v.size(), v.data());
+    });
+}
+int32_t visp_weights_from_file(visp_file const* f, visp_weights** out) {
+    return handle_errors([&]() {
+        if (!out) throw except("visp_weights_from_file: null out pointer");
+        *out = new visp_weights{weights_from_file(as_file(f))};
+    });
+}
+
 // ---- graph layer (graph.h) ----
 
 int32_t visp_weights_load(char const* gguf_path, visp_weights** out) {
@@ -777,20 +817,32 @@ int32_t visp_graph_add_weight(visp_graph* g, char const* name, int32_t dtype, in
     });
 }
 int32_t visp_graph_find_weight(visp_graph* g, char const* name, int32_t* out) {
-    return handle_errors([&]() { *out = graph_find_weight(as_graph(g), name); });
+    return handle_errors([&]() {
+        if (!out) throw except("visp_graph_find_weight: null out pointer");
+        *out = graph_find_weight(as_graph(g), name);
+    });
 }
 int32_t visp_graph_input(visp_graph* g, int32_t dtype, int64_t const ne[4], char const* name, int32_t* out) {
-    return handle_errors([&]() { *out = graph_input(as_graph(g), dtype, ne, name); });
+    return handle_errors([&]() {
+        if (!out || !ne) throw except("visp_graph_input: null pointer");
+        *out = graph_input(as_graph(g), dtype, ne, name);
+    });
 }
 int32_t visp_graph_op(visp_graph* g, int32_t op, int32_t const* src, int32_t n_src, int64_t const* iparams, int32_t n_iparams, float const* fparams,
                       int32_t n_fparams, int32_t* out) {
-    return handle_errors([&]() { *out = graph_add(as_graph(g), op, src, n_src, iparams, n_iparams, fparams, n_fparams); });
+    return handle_errors([&]() {
+        if (!out || !src) throw except("visp_graph_op: null pointer");
+        *out = graph_add(as_graph(g), op, src, n_src, iparams, n_iparams, fparams, n_fparams);
+    });
 }
 int32_t visp_graph_set_name(visp_graph* g, int32_t tensor, char const* name) {
     return handle_errors([&]() { graph_set_name(as_graph(g), tensor, name); });
 }
 int32_t visp_graph_get_tensor(visp_graph* g, char const* name, int32_t* out) {
-    return handle_errors([&]() { *out = graph_get_tensor(as_graph(g), name); });
+    return handle_errors([&]() {
+        if (!out) throw except("visp_graph_get_tensor: null out pointer");
+        *out = graph_get_tensor(as_graph(g), name);
+    });
 }
 int32_t visp_graph_output(visp_graph* g, int32_t tensor, char const* name) {
     return handle_errors([&]() { graph_output(as_graph(g), tensor, name); });
@@ -810,6 +862,7 @@ int32_t visp_graph_read_constant(visp_graph const* g, int32_t tensor, float* out
         graph const& gr = as_cgraph(g);
         if (tensor < 0 || tensor >= (int)gr.nodes.size()) throw except("visp_graph_read_constant: tensor handle %d is not part of this graph", tensor);
         graph_node const& n = gr.nodes[tensor];
+        if (!out) throw except("visp_graph_read_constant: null out pointer");
         if (!n.constant) throw except("visp_graph_read_constant: tensor %d is not a constant", tensor);
         if (capacity < n.n_elements()) throw except("visp_graph_read_constant: capacity %lld < %lld elements", (long long)capacity, (long long)n.n_elements());
         memcpy(out, n.values(), (size_t)n.n_elements() * 4);

@@ -24,6 +24,8 @@ T round_up(T x, T m) { return (x + m - 1) / m * m; }
 //
 // backend (reference src/visp/ml.cpp:59-95)
 
+device_turn::device_turn(backend_device const& dev) : lock(dev.turn) { device_turn turn(dev); }
+
 backend_device* backend_init(int device_index) {
     int n = vx_device_count();
     if (n <= 0) throw except("Failed to initialize backend, no suitable device available");
@@ -326,10 +328,8 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
     }
     Wt.final_ln_w = pk.vec("backbone.layernorm.weight");
     Wt.final_ln_b = pk.vec("backbone.layernorm.bias");
-    // second packing of the encoder for the block kernel (kernels_block.hip): slab streams in the kernel's order of use
+    // second packing of the encoder for the block kernel (kernels_block16.hip): slab streams in the kernel's order of use
     Wt.use_block = P.dino.n_layers > 0 && vx_dino_block_supported(D, Wt.layers[0].fc1.n_real, D / P.dino.n_heads) != 0;
-    // which form of the block kernel the slab streams are packed for: 16 tokens per wave (kernels_block16.hip) unless VISP_BLOCK32=1
-    Wt.block16 = getenv("VISP_BLOCK32") == nullptr;
     if (Wt.use_block) {
         for (int i = 0; i < P.dino.n_layers; ++i) {
             std::string p = "backbone.encoder.layer." + std::to_string(i);
@@ -347,24 +347,17 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
                 std::vector<float> l1, l2;
                 pk.append_vec(l1, p + ".layer_scale1.lambda1");
                 pk.append_vec(l2, p + ".layer_scale2.lambda1");
-                if (Wt.block16) {
-                    // the 16-token kernel keeps the residual stream in its accumulators: LayerScale is folded into the two residual
-                    // products (exact in real arithmetic; the scaled weights are re-rounded to f16): x1 = x + Wo' att + bo', x2 = x1 + W2' h + b2'
-                    const int Hd = (int)b1.size();
-                    for (int n = 0; n < D; ++n) {
-                        for (int k = 0; k < D; ++k) wo[(size_t)n * D + k] = f32_to_f16(f16_to_f32(wo[(size_t)n * D + k]) * l1[n]);
-                        for (int k = 0; k < Hd; ++k) w2[(size_t)n * Hd + k] = f32_to_f16(f16_to_f32(w2[(size_t)n * Hd + k]) * l2[n]);
-                        bo[n] *= l1[n];
-                        b2[n] *= l2[n];
-                    }
+                // the kernel keeps the residual stream in its accumulators: LayerScale is folded into the two residual products (exact in
+                // real arithmetic; the scaled weights are re-rounded to f16): x1 = x + Wo' att + bo', x2 = x1 + W2' h + b2'
+                const int Hd = (int)b1.size();
+                for (int n = 0; n < D; ++n) {
+                    for (int k = 0; k < D; ++k) wo[(size_t)n * D + k] = f32_to_f16(f16_to_f32(wo[(size_t)n * D + k]) * l1[n]);
+                    for (int k = 0; k < Hd; ++k) w2[(size_t)n * Hd + k] = f32_to_f16(f16_to_f32(w2[(size_t)n * Hd + k]) * l2[n]);
+                    bo[n] *= l1[n];
+                    b2[n] *= l2[n];
                 }
-                if (Wt.block16) {
-                    VX(vx_dino_block16_pack_mlp(wo.data(), w1.data(), w2.data(), ab.data.data() + L.blk_mlp));
-                    VX(vx_dino_block16_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
-                } else {
-                    VX(vx_dino_block_pack_mlp(wo.data(), w1.data(), w2.data(), ab.data.data() + L.blk_mlp));
-                    VX(vx_dino_block_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
-                }
+                VX(vx_dino_block16_pack_mlp(wo.data(), w1.data(), w2.data(), ab.data.data() + L.blk_mlp));
+                VX(vx_dino_block16_pack_qkv(wqkv.data(), ab.data.data() + L.blk_qkv));
                 vm = bo;
                 vm.insert(vm.end(), l1.begin(), l1.end());
                 pk.append_vec(vm, p + ".norm2.weight");
@@ -426,7 +419,7 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
         memcpy(ab.data.data() + Wt.head3_b_off, &Wt.head3_b, 4);
     }
 
-    VX(vx_set_device(dev.index));
+    device_turn turn(dev);
     VX(vx_dconv_prepare());
     for (void*& s : model->aux_stream) VX(vx_stream_create(&s));
     VX(vx_event_create(&model->fork_event));
@@ -442,7 +435,7 @@ depthany_model* depthany_load_model(char const* filepath, backend_device const& 
 }
 
 void depthany_weights_ready(depthany_model& m) {
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     VX(vx_memcpy_d2h(&m.weights.head3_b, static_cast<const uint8_t*>(m.weight_arena.ptr) + m.weights.head3_b_off, 4, m.backend->stream));
     m.weights_uploaded = true;
 }
@@ -461,7 +454,7 @@ depthany_model::~depthany_model() {
 
 depthany_model* depthany_clone_executor(depthany_model const& src) {
     if (!src.weights_uploaded) throw except("depthany: cannot clone an executor before the weights are on the device");
-    VX(vx_set_device(src.backend->index));
+    device_turn turn(*src.backend);
     auto m = std::make_unique<depthany_model>();
     m->backend = src.backend;
     m->params = src.params;
@@ -558,7 +551,6 @@ void depthany_reserve(depthany_model& m, int B, int W, int H) {
     L.add("k", (size_t)M * D * 2);
     L.add("vt", (size_t)M * D * 2);
     L.add("att", (size_t)M * D * 2);
-    L.add("y", (size_t)M * D * 2); // projection output awaiting its deferred residual add
     L.add("hidden", (size_t)M * Wt.layers[0].fc1.N * 2);
     for (int j = 0; j < 4; ++j) L.add("feat" + std::to_string(j), (size_t)M * D * 2);
     for (int j = 0; j < 4; ++j) L.add("r" + std::to_string(j), (size_t)B * Pn * Wt.re_proj[j].N * 2);
@@ -579,7 +571,7 @@ void depthany_reserve(depthany_model& m, int B, int W, int H) {
     L.add("out", (size_t)B * H * W * 4);
     L.add("minmax", (size_t)B * 2 * 4);
 
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     if (m.ws.graph_exec) { vx_graph_destroy(m.ws.graph_exec); m.ws.graph_exec = nullptr; }
     if (m.ws.arena.bytes < L.total) {
         VX(vx_free(m.ws.arena.ptr));
@@ -804,11 +796,8 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     c.capture("tokens", x, {B, T, D, 1}, false);
 
     // ---- dino::layer x n_layers (dino.cpp:76-90)
-    // Optional (VISP_DEFER_RESID=1): residual adds deferred into the LayerNorm that follows them -- the out-proj / fc2
-    // GEMMs write y = f(...) as a plain f16 tile and vx_layernorm_resid applies x += lambda * y while it normalises
-    // the row. Measured on the same device: the GEMMs get 0.36 ms faster per step (no strided f32 read-modify-write
-    // epilogue) but the LayerNorms 0.42 ms slower (they now also write x); total traffic is the same 236 MB per
-    // residual, so the read-modify-write epilogue stays the default.
+    // (GEMM schedule: the residual adds are the out-proj / fc2 GEMMs' read-modify-write epilogues. Deferring them into the following
+    // LayerNorm was measured in round 1 -- GEMMs -0.36 ms, LayerNorms +0.42 ms per step -- and removed in round 4.)
     // attention() scales the scores by 1/sqrt(head_dim) (nn.cpp:232-233); the attention kernel works in the exp2 domain, so log2(e)
     // rides along in the same factor (VX_ATTN_Q_SCALE for head_dim 64)
     const float q_scale = 1.4426950408889634f / std::sqrt((float)D / (float)NH);
@@ -816,7 +805,13 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     // offset into the same workspace; VISP_SPLIT=n runs n sub-batches on parallel streams (captured as parallel branches of
     // the hipGraph) so that kernels with different bottlenecks -- HBM-bound LayerNorms, VALU-bound attention, MFMA/LDS-bound
     // GEMMs -- of different sub-batches overlap.
-    bool in_split = false; // set while the sub-batches of a split step are being scheduled
+    // Timing-only ablations (results invalid by construction): what the step would cost without a stage. They exist only in diagnostic
+    // builds of the library (make ABLATE=1 -> -DVISP_TIMING_ABLATIONS); the shipped library has no switch that skips work.
+#ifdef VISP_TIMING_ABLATIONS
+    static const int ablate = getenv("VISP_ABLATE") ? atoi(getenv("VISP_ABLATE")) : 0; // 1 = no DPT, 2 = no bilinear launches, 4 = no attention
+#else
+    constexpr int ablate = 0;
+#endif
     auto run_sub = [&](int b0, int nb, void* strm) {
     const int B = nb;
     const long M = (long)nb * T, MP = (long)nb * Pn;
@@ -831,42 +826,21 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     void* const vb = sub("vt", (size_t)D * 2);
     void* const attb = sub("att", (size_t)D * 2);
     void* const hidb = sub("hidden", (size_t)Wt.layers[0].fc1.N * 2);
-    const bool defer = !m.captures && vx_layernorm_resid_supported(D) && getenv("VISP_DEFER_RESID") != nullptr;
-    void* ybuf = sub("y", (size_t)D * 2);
-    const float* pending = nullptr; // LayerScale vector of the residual still sitting in ybuf
-    auto layernorm = [&](const float* w, const float* b, void* out) { // norm(x), applying a pending residual first
-        c.mark("layernorm", 1, 0, (double)M * D * (pending ? 12 : 6));
-        if (pending) VX(vx_layernorm_resid_f32_f16(x, ybuf, pending, w, b, out, (int)M, D, 1e-6f, stream));
-        else VX(vx_layernorm_f32_f16(x, w, b, out, (int)M, D, 1e-6f, stream));
-        pending = nullptr;
+    auto layernorm = [&](const float* w, const float* b, void* out) {
+        c.mark("layernorm", 1, 0, (double)M * D * 6);
+        VX(vx_layernorm_f32_f16(x, w, b, out, (int)M, D, 1e-6f, stream));
     };
     auto residual_gemm = [&](packed_gemm const& g, const void* A, int lda, packed_vec const& lambda, const char* group, double flops, double bytes) {
         vx_gemm_args a = c.base(g, M);
         a.A = A; a.lda = lda;
-        if (defer) {
-            a.epi = VX_EPI_F16;
-            a.out = ybuf; a.ldo = D;
-            pending = c.fptr(lambda);
-        } else {
-            a.epi = VX_EPI_RESID_F32;
-            a.out = x; a.ldo = D;
-            a.lambda = c.fptr(lambda);
-        }
+        a.epi = VX_EPI_RESID_F32;
+        a.out = x; a.ldo = D;
+        a.lambda = c.fptr(lambda);
         c.mark(group, 1, flops, bytes);
         c.gemm(a);
     };
-    int tap = 0, tap_due = -1, tap_due_n = 0; // a tapped layer (and how many taps name it) whose final LayerNorm waits
-                                               // for the layer's last residual to be applied
-    auto run_tap = [&]() {
-        for (; tap_due_n > 0 && tap < 4; --tap_due_n, ++tap) {
-            std::string fb = "feat" + std::to_string(tap);
-            layernorm(c.fptr(Wt.final_ln_w), c.fptr(Wt.final_ln_b), sub(fb.c_str(), (size_t)D * 2));
-            if (m.captures) { std::string nm = "dino_layer_" + std::to_string(tap_due); c.capture(nm.c_str(), sub(fb.c_str(), (size_t)D * 2), {B, T, D, 1}, true); }
-        }
-        tap_due = -1;
-        tap_due_n = 0;
-    };
-    // Token-stationary schedule (kernels_block.hip): per layer one attention launch and ONE block launch that does the
+    int tap = 0;
+    // Token-stationary schedule (kernels_block16.hip): per layer one attention launch and ONE block launch that does the
     // output projection, both residual updates, LN2 + MLP, the tap's final LayerNorm and the next layer's LN1 + QKV for
     // 128 token rows per workgroup with everything but the weights in registers. Alone it is no faster than the launches it
     // replaces (381 vs 363 us per layer at batch 32, profiles/r02_block_kernel_anatomy.txt), but it has none of their HBM
@@ -904,14 +878,13 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
                 bytes += (double)M * D * 2;
             }
             c.mark(group, 1, flops, bytes);
-            VX(Wt.block16 ? vx_dino_block16_f16(&a, stream) : vx_dino_block_f16(&a, stream));
+            VX(vx_dino_block16_f16(&a, stream));
         };
         block(-1, 0, nullptr, "block_qkv0");
         int tap = 0;
         for (int i = 0; i < P.dino.n_layers; ++i) {
             c.mark("attention", 1, 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
-            static const bool no_attn = getenv("VISP_ABLATE") && (atoi(getenv("VISP_ABLATE")) & 4); // timing-only ablation
-            if (!no_attn) VX(vx_attention_f16(qb, kb, vb, attb, B, NH, T, stream));
+            if (!(ablate & 4)) VX(vx_attention_f16(qb, kb, vb, attb, B, NH, T, stream));
             // get_intermediate_layers (dino.cpp:100-107): every tap that names this layer (the first one is written by the kernel)
             void* first = nullptr;
             int tap0 = tap;
@@ -938,8 +911,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
     }
     for (int i = 0; i < (use_block ? 0 : P.dino.n_layers); ++i) {
         dino_layer_weights const& L = Wt.layers[i];
-        layernorm(c.fptr(L.ln1_w), c.fptr(L.ln1_b), ln); // applies the previous layer's fc2 residual
-        if (tap_due >= 0) run_tap();                        // x of the tapped previous layer is complete now
+        layernorm(c.fptr(L.ln1_w), c.fptr(L.ln1_b), ln);
         {
             vx_gemm_args a = c.base(L.qkv, M);
             a.A = ln; a.lda = D;
@@ -952,7 +924,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         }
         c.mark("attention", 1, 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
         VX(vx_attention_f16(qb, kb, vb, attb, B, NH, T, stream));
-        residual_gemm(L.out, attb, D, L.lambda1, "gemm_out", 2.0 * M * D * D, (double)M * D * (2 + (defer ? 2 : 8)) + (double)D * D * 2);
+        residual_gemm(L.out, attb, D, L.lambda1, "gemm_out", 2.0 * M * D * D, (double)M * D * (2 + 8) + (double)D * D * 2);
         layernorm(c.fptr(L.ln2_w), c.fptr(L.ln2_b), ln);
         {
             vx_gemm_args a = c.base(L.fc1, M);
@@ -963,39 +935,27 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
             c.gemm(a);
         }
         residual_gemm(L.fc2, hidb, L.fc1.N, L.lambda2, "gemm_fc2", 2.0 * M * D * L.fc2.k_real,
-                      (double)M * (L.fc1.N * 2 + D * (defer ? 2 : 8)) + (double)L.fc2.K * D * 2);
+                      (double)M * (L.fc1.N * 2 + D * 8) + (double)L.fc2.K * D * 2);
         if (m.captures) { std::string nm = "layer_" + std::to_string(i); c.capture(nm.c_str(), x, {B, T, D, 1}, false); }
-        // get_intermediate_layers (dino.cpp:100-107): shared final layernorm on the tapped layers. With a residual still
-        // pending, the tap waits for the next layer's first LayerNorm to apply it (the last layer applies it itself).
+        // get_intermediate_layers (dino.cpp:100-107): the shared final LayerNorm on the tapped layers, once per tap that names this layer
         for (int f = 0; f < 4; ++f)
-            if (P.feature_layers[f] == i) ++tap_due_n;
-        if (tap_due_n > 0) {
-            tap_due = i;
-            if (!pending || i + 1 == P.dino.n_layers) run_tap();
-        }
+            if (P.feature_layers[f] == i && tap < 4) {
+                std::string fb = "feat" + std::to_string(tap++);
+                layernorm(c.fptr(Wt.final_ln_w), c.fptr(Wt.final_ln_b), sub(fb.c_str(), (size_t)D * 2));
+                if (m.captures) { std::string nm = "dino_layer_" + std::to_string(i); c.capture(nm.c_str(), sub(fb.c_str(), (size_t)D * 2), {B, T, D, 1}, true); }
+            }
     }
     if (!use_block && tap != 4) throw except("depthany: expected 4 feature layers, found %d", tap);
 
-    // timing-only ablations (results invalid): what the step would cost without a stage -- bounds what fusing it away can buy
-    static const int ablate = getenv("VISP_ABLATE") ? atoi(getenv("VISP_ABLATE")) : 0; // 1 = no DPT, 2 = no bilinear launches, 4 = no attention
     if (ablate & 1) return;
     // ---- dpt::neck reassemble (depth-anything.cpp:44-64)
     const int lh[4] = {4 * ph, 2 * ph, ph, (ph + 2 - 3) / 2 + 1};
     const int lw[4] = {4 * pw, 2 * pw, pw, (pw + 2 - 3) / 2 + 1};
     const void* lay[4];
     void* cb[4] = {c.buf("c0"), c.buf("c1"), c.buf("c2"), c.buf("c3")};
-    // Branch j = projection -> resize -> neck conv of tap j. The branches are independent (depth-anything.cpp:47-69)
-    // and several of their kernels have fewer blocks than the chip has CUs, so they CAN run on parallel streams.
-    // Measured (3 interleaved A/B rounds, batch 32): forking is 1-3 % SLOWER than the single stream (8.08-8.30 vs
-    // 8.00 ms per step), so it stays opt-in (VISP_FORK_NECK=1) as a documented negative result.
-    static const bool fork_enabled = getenv("VISP_FORK_NECK") != nullptr;
-    const bool fork = !m.timing && !m.captures && fork_enabled && !in_split; // (the sub-batch split uses the same streams and events)
-    if (fork) {
-        VX(vx_event_record(m.fork_event, stream));
-        for (int j = 0; j < 3; ++j) VX(vx_stream_wait_event(m.aux_stream[j], m.fork_event));
-    }
+    // Branch j = projection -> resize -> neck conv of tap j. (Running the four independent branches on parallel streams was measured
+    // in round 1: 1-3 % slower than one stream; removed in round 4, the sub-batch split below uses the streams.)
     for (int j = 0; j < 4; ++j) {
-        c.stream = (fork && j < 3) ? m.aux_stream[j] : stream;
         std::string fb = "feat" + std::to_string(j), rb = "r" + std::to_string(j);
         {
             vx_gemm_args a = c.base(Wt.re_proj[j], MP);
@@ -1028,12 +988,6 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         c.conv(Wt.neck_conv[j], lay[j], B, lh[j], lw[j], Wt.neck_c[j], 3, 1, 1, cb[j], F, VX_EPI_F16, false, false, nullptr, nullptr, "neck_convs");
         if (m.captures) { std::string nm = "neck_conv_" + std::to_string(j); c.capture(nm.c_str(), cb[j], {B, lh[j], lw[j], F}, true); }
     }
-    c.stream = stream;
-    if (fork)
-        for (int j = 0; j < 3; ++j) {
-            VX(vx_event_record(m.join_event[j], m.aux_stream[j]));
-            VX(vx_stream_wait_event(stream, m.join_event[j]));
-        }
 
     // ---- fusion stage (depth-anything.cpp:25-42, 71-77)
     void *t1 = c.buf("t1"), *t2 = c.buf("t2"), *t3 = c.buf("t3"), *up = c.buf("up"), *fused = c.buf("fused");
@@ -1146,7 +1100,6 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
         if (n_split == 1) {
             run_sub(0, B, stream);
         } else {
-            in_split = true;
             VX(vx_event_record(m.fork_event, stream));
             for (int j = 0; j < n_split; ++j) {
                 const int b0 = (int)((long)B * j / n_split), b1 = (int)((long)B * (j + 1) / n_split);
@@ -1169,7 +1122,7 @@ static void run_forward(depthany_model& m, const void* rgb, void* out_dev, void*
 void depthany_compute_batch_device(depthany_model& m, void const* rgb_dev, int batch, int w, int h, void* out_dev,
                                    void* raw_out_dev, void* stream) {
     if (!m.weights_uploaded) throw except("depthany: weights were not uploaded (load_no_upload) and no arena broadcast was marked complete");
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     depthany_reserve(m, batch, w, h);
     bool own_stream = stream == nullptr;
     void* s = own_stream ? m.backend->stream : stream;
@@ -1199,7 +1152,7 @@ void depthany_compute_batch_device(depthany_model& m, void const* rgb_dev, int b
 }
 
 void depthany_compute_batch_host(depthany_model& m, uint8_t const* rgb, int batch, int w, int h, float* out, float* raw_out) {
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     depthany_reserve(m, batch, w, h);
     void* s = m.backend->stream;
     size_t in_bytes = (size_t)batch * h * w * 3, out_bytes = (size_t)batch * h * w * 4;
@@ -1222,7 +1175,7 @@ void depthany_compute_batch_host(depthany_model& m, uint8_t const* rgb, int batc
 
 depthany_pipeline* depthany_pipeline_create(depthany_model& m, int batch, int w, int h, int n_slots) {
     if (n_slots < 2 || n_slots > 8) throw except("depthany pipeline: %d slots (2..8)", n_slots);
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     depthany_reserve(m, batch, w, h);
     auto p = std::make_unique<depthany_pipeline>();
     p->model = &m; p->batch = batch; p->w = w; p->h = h; p->n_slots = n_slots;
@@ -1279,7 +1232,7 @@ uint8_t* depthany_pipeline_input(depthany_pipeline& p) {
 
 int depthany_pipeline_submit(depthany_pipeline& p, uint8_t const* rgb) {
     depthany_model& m = *p.model;
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     const int ticket = p.next;
     auto& s = p.slots[(size_t)ticket];
     if (s.busy) throw except("depthany pipeline: slot %d still holds an unread result (wait for its ticket first)", ticket);
@@ -1313,7 +1266,7 @@ float const* depthany_pipeline_wait(depthany_pipeline& p, int ticket) {
     if (ticket < 0 || ticket >= p.n_slots) throw except("depthany pipeline: bad ticket %d", ticket);
     auto& s = p.slots[(size_t)ticket];
     if (!s.busy) throw except("depthany pipeline: ticket %d has nothing in flight", ticket);
-    VX(vx_set_device(p.model->backend->index));
+    device_turn turn(*p.model->backend);
     VX(vx_event_sync(s.downloaded));
     s.busy = false;
     return static_cast<float const*>(s.pin_out);

@@ -8,6 +8,7 @@
 #include <array>
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,7 +26,16 @@ struct backend_device { // include/visp/ml.h:44-55, here: one HIP device + its c
     size_t total_mem = 0;
     int n_cu = 0;
     backend_type type() const { return backend_type::gpu; }
+    // Every model and graph made on this device shares `stream`. Whatever enqueues on it, captures a hipGraph on it or synchronises it
+    // holds the device's turn (device_turn below), so that host threads driving different models of one device cannot interleave a
+    // capture with another thread's launches ("capturing stream has unjoined work"). Recursive: entry points nest.
+    mutable std::recursive_mutex turn;
     ~backend_device();
+};
+// makes the device current for the calling thread and holds its turn for the scope
+struct device_turn {
+    std::unique_lock<std::recursive_mutex> lock;
+    explicit device_turn(backend_device const& dev);
 };
 backend_device* backend_init(int device_index); // throws visp::exception if no gfx950 device
 
@@ -58,7 +68,7 @@ struct packed_vec { size_t off = SIZE_MAX; int n = 0; }; // f32 vector
 struct dino_layer_weights {
     packed_vec ln1_w, ln1_b, ln2_w, ln2_b, lambda1, lambda2;
     packed_gemm qkv, out, fc1, fc2;
-    // operands of the token-stationary block kernel (kernels_block.hip), when the model has its shape: weight slab streams
+    // operands of the token-stationary block kernel (kernels_block16.hip), when the model has its shape: weight slab streams
     // (out-proj + mlp; qkv) and the per-feature vectors bo|lambda1|ln2.w|ln2.b|b1|b2|lambda2 and ln1.w|ln1.b|bqkv
     size_t blk_mlp = SIZE_MAX, blk_qkv = SIZE_MAX, vec_mlp = SIZE_MAX, vec_qkv = SIZE_MAX;
 };
@@ -72,7 +82,6 @@ struct depthany_weights {
     std::vector<dino_layer_weights> layers;
     packed_vec final_ln_w, final_ln_b;
     bool use_block = false;   // embed dim 384 / mlp 1536 / head dim 64: one launch per layer between two attentions
-    bool block16 = true;      // slab streams packed for the 16-token form of the block kernel (kernels_block16.hip)
     size_t vec_tap = SIZE_MAX; // final layernorm w|b for the block kernel's tap
     std::array<packed_gemm, 4> re_proj;
     packed_gemm re_up0, re_up1, re_down3; // convT k4s4, convT k2s2, conv3x3 s2

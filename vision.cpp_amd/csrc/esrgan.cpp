@@ -183,7 +183,7 @@ esrgan_model* esrgan_load_model(char const* filepath, backend_device const& dev,
     for (packed_dconv const* g : {&Wt.trunk, &Wt.hr})
         if (g->cin_real != Wt.nf || g->cout_real != Wt.nf) throw except("ESRGAN: trunk/HR conv has shape %d -> %d", g->cin_real, g->cout_real);
 
-    VX(vx_set_device(dev.index));
+    device_turn turn(dev);
     VX(vx_dconv_prepare());
     model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256);
     VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
@@ -416,7 +416,7 @@ void esrgan_compute_batch_device(esrgan_model& m, void const* img_dev, int batch
     if (!m.weights_uploaded) throw except("esrgan: weights have not been uploaded (load_no_upload without weights_ready)");
     if (batch < 1 || w < 1 || h < 1) throw except("esrgan: empty input (%d images of %dx%d)", batch, w, h);
     if (is_float(format) || n_channels(format) < 3) throw except("esrgan: unsupported input image format [%d], expected an 8-bit colour image", int(format));
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     void* s = stream ? stream : m.backend->stream;
     tile_layout tiles({{w, h}}, esrgan_default_tile_size, esrgan_tile_overlap);
     tile_layout tiles_out = tile_scale(tiles, m.params.scale);
@@ -436,7 +436,7 @@ void esrgan_compute_batch_device(esrgan_model& m, void const* img_dev, int batch
 void esrgan_compute_batch_host(esrgan_model& m, uint8_t const* img, int batch, int w, int h, image_format format, uint8_t* out_rgba) {
     if (batch < 1 || w < 1 || h < 1) throw except("esrgan: empty input (%d images of %dx%d)", batch, w, h);
     if (is_float(format) || n_channels(format) < 3) throw except("esrgan: unsupported input image format [%d], expected an 8-bit colour image", int(format));
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     tile_layout tiles({{w, h}}, esrgan_default_tile_size, esrgan_tile_overlap);
     const int sc = m.params.scale;
     const size_t in_bytes = (size_t)batch * w * h * n_channels(format), out_bytes = (size_t)batch * w * sc * h * sc * 4;
@@ -471,7 +471,7 @@ image_data esrgan_compute(esrgan_model& m, image_view image) {
 void esrgan_generate_host(esrgan_model& m, float const* rgb, int n, int w, int h, float* out) {
     if (!m.weights_uploaded) throw except("esrgan: weights have not been uploaded");
     if (n < 1 || w < 1 || h < 1) throw except("esrgan: empty input");
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     reserve(m, n, w, h);
     const size_t px = (size_t)n * w * h;
     std::vector<uint16_t> x0(px * 32, 0);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <optional>
 
 #include "../../include/visp_hip_kernels.h"
 #include "visp_util.h"
@@ -188,11 +189,13 @@ void check_tensor(graph const& g, int t, const char* what) {
 const char* graph_op_name(int32_t op) { return op >= 0 && op < gop_count ? op_names[op] : "?"; }
 
 graph::~graph() {
+    if (dev) vx_set_device(dev->index); // frees go to the device the graph lives on, whatever the calling thread's current device is
     if (graph_exec) vx_graph_destroy(graph_exec);
     if (arena.ptr) vx_free(arena.ptr);
     for (void* p : const_allocs) vx_free(p);
 }
 weight_store::~weight_store() {
+    if (dev) vx_set_device(dev->index);
     for (void* p : allocs) vx_free(p);
 }
 
@@ -215,9 +218,10 @@ void weights_add(weight_store& ws, char const* name, int32_t dtype, const int64_
     ws.tensors.emplace(name, std::move(e));
 }
 
-std::shared_ptr<weight_store> weights_load(char const* path) {
+std::shared_ptr<weight_store> weights_load(char const* path) { return weights_from_file(model_load(path)); }
+
+std::shared_ptr<weight_store> weights_from_file(model_file const& f) {
     auto ws = weights_create();
-    model_file f = model_load(path);
     const bool file_whcn = f.tensor_layout() == layout_whcn;
     std::vector<int32_t> conv2d = f.conv2d_weights();
     std::vector<float> tmp, perm;
@@ -552,8 +556,11 @@ struct lowering {
         if (it != const_cache.end()) return it->second;
         graph_node const& n = g.nodes[t];
         void* d = nullptr;
-        if (n.op == gop_weight && g.dev) {
+        // only images made from NAMED model weights alone are shared: a derived image whose other operand is a constant folded inside this
+        // graph ("#<node>": a node index means nothing to another graph) stays with the graph
+        if (n.op == gop_weight && g.dev && with.find('#') == std::string::npos) {
             auto skey = std::make_pair(with.empty() ? n.name : n.name + "|" + with, role);
+            std::lock_guard<std::mutex> lock(g.store->mutex); // graphs over one store may be allocated from several threads
             auto sit = g.store->packs.find(skey);
             if (sit != g.store->packs.end()) d = sit->second; // uploaded by an earlier graph over the same weights
             else { d = make(true); g.store->packs[skey] = d; }
@@ -588,7 +595,7 @@ struct lowering {
         // LayerScale folded into the operand: W' = f16(lambda[n] * W[n, :]), b' = lambda[n] * b[n] (what csrc/depthany.cpp does for the
         // block kernel: the product's epilogue can then take the residual)
         const float* lam = scale_t >= 0 ? g.nodes[scale_t].values() : nullptr;
-        const std::string with = scale_t >= 0 ? "*" + (g.nodes[scale_t].name.empty() ? std::to_string(scale_t) : g.nodes[scale_t].name) : std::string();
+        const std::string with = scale_t >= 0 ? "*" + (g.nodes[scale_t].op == gop_weight && !g.nodes[scale_t].name.empty() ? g.nodes[scale_t].name : "#" + std::to_string(scale_t)) : std::string();
         p.n_real = n; p.k_real = k;
         p.N = round_up(n, n > 64 ? 64 : 32);
         p.K = round_up(k, 64);
@@ -1232,7 +1239,10 @@ struct lowering {
 void graph_allocate(graph& g, backend_device const* dev) {
     if (g.allocated) return;
     g.dev = dev;
+    std::optional<device_turn> turn; // the arena, the packed weights and the kernel attributes belong to THIS device; uploads use its stream
     if (dev) {
+        turn.emplace(*dev);
+        std::lock_guard<std::mutex> lock(g.store->mutex);
         if (g.store->dev && g.store->dev != dev) throw except("compute_graph_allocate: the weights of this graph live on another device");
         g.store->dev = dev;
     }
@@ -1254,6 +1264,7 @@ static void require_device(graph const& g, const char* what) {
 
 void graph_compute(graph& g) {
     require_device(g, "compute");
+    device_turn turn(*g.dev);
     void* st = g.dev->stream;
     if (g.use_hip_graph && g.graph_exec) {
         VX(vx_graph_launch(g.graph_exec, st));
@@ -1288,6 +1299,7 @@ static char* tensor_ptr(graph& g, int t, const char* what) {
 
 void graph_tensor_set(graph& g, int t, const void* data, size_t bytes) {
     require_device(g, "transfer_to_backend");
+    device_turn turn(*g.dev);
     char* p = tensor_ptr(g, t, "transfer_to_backend");
     if (bytes != g.nodes[t].n_bytes()) throw except("transfer_to_backend: %zu bytes for a tensor of %zu", bytes, g.nodes[t].n_bytes());
     VX(vx_memcpy_h2d(p, data, bytes, g.dev->stream));
@@ -1296,6 +1308,7 @@ void graph_tensor_set(graph& g, int t, const void* data, size_t bytes) {
 
 void graph_tensor_get(graph& g, int t, void* data, size_t bytes, bool as_f32) {
     require_device(g, "transfer_from_backend");
+    device_turn turn(*g.dev);
     char* p = tensor_ptr(g, t, "transfer_from_backend");
     graph_node const& n = g.nodes[t];
     const bool convert = as_f32 && n.dtype == gdt_f16;

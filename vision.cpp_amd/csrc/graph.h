@@ -19,6 +19,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -99,11 +100,13 @@ struct weight_store {
     std::map<std::pair<std::string, int>, void*> packs;     // (name, role) -> device image
     std::vector<void*> allocs;
     size_t device_bytes = 0;
+    std::mutex mutex;                                       // guards dev / packs / allocs / device_bytes
     ~weight_store();
 };
 std::shared_ptr<weight_store> weights_create();
 // all f16 / f32 tensors of a GGUF file (conv kernels listed in <arch>.conv2d_weights of a whcn file are presented as CWHN)
 std::shared_ptr<weight_store> weights_load(char const* gguf_path);
+std::shared_ptr<weight_store> weights_from_file(model_file const& file); // model_transfer (ml.cpp:449-516) from a file already read
 void weights_add(weight_store&, char const* name, int32_t dtype, const int64_t ne[4], const float* data);
 
 struct graph {

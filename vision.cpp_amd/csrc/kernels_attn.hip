@@ -34,9 +34,6 @@ namespace {
 #ifndef VISP_ATTN_WPE
 #define VISP_ATTN_WPE 4 // waves per SIMD the register budget is held to (experiments: 3 = 168 registers)
 #endif
-#ifndef VISP_ATTN_PAIR
-#define VISP_ATTN_PAIR 0 // 1: a 4-stage K/V ring and ONE block barrier per two 64-key tiles (A/B: profiles/r03_attention_stamps.txt)
-#endif
 #ifndef VISP_ATTN_RS
 #define VISP_ATTN_RS 1 // row sums: 1 = packed-f16 add tree (default), 2 = two f16 levels then f32, 0 = ones-MFMAs (profiles/r03_attention_stamps.txt)
 #endif
@@ -76,7 +73,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(VISP_AT
     unsigned long long st_wait = 0, st_soft = 0, st_pv = 0, st_t0 = 0;
     if constexpr (STAMP) st_t0 = __builtin_amdgcn_s_memtime();
     // LDS ring: 2 stages x (K tile, V tile)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(VISP_ATTN_PAIR ? 4 : 2) * 2 * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,16 +235,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(VISP_AT
         constexpr int BUF = decltype(buf_c)::value;
         unsigned long long c0 = 0, c1 = 0, c2 = 0;
         if constexpr (STAMP) c0 = __builtin_amdgcn_s_memtime();
-        if constexpr (!VISP_ATTN_PAIR) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads(); // tile t landed; every wave finished tile t-1, so the other stage is free
-            if (t + 1 < n_tiles) issue_loads(t + 1, BUF ^ 1);
-        } else if constexpr ((BUF & 1) == 0) { // pairs of tiles: tiles t, t+1 landed; every wave finished the previous pair, so its two stages are free
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t + 2 < n_tiles) issue_loads(t + 2, BUF ^ 2);
-            if (t + 3 < n_tiles) issue_loads(t + 3, (BUF ^ 2) + 1);
-        }
+        // (one barrier per TWO tiles with a 4-stage ring was measured in round 3: no change -- the wait is landing + issue, not skew)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // tile t landed; every wave finished tile t-1, so the other stage is free
+        if (t + 1 < n_tiles) issue_loads(t + 1, BUF ^ 1);
         if constexpr (STAMP) { c1 = __builtin_amdgcn_s_memtime(); st_wait += c1 - c0; }
         const unsigned char* sk = smem + BUF * (2 * TILE_BYTES);
         const unsigned char* sv = sk + TILE_BYTES;
@@ -302,14 +293,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(VISP_AT
     };
 
     issue_loads(0, 0);
-    if (VISP_ATTN_PAIR && n_tiles > 1) issue_loads(1, 1);
-    for (int t = 0; t < n_tiles; t += (VISP_ATTN_PAIR ? 4 : 2)) {
+    for (int t = 0; t < n_tiles; t += 2) {
         tile_body(t, std::integral_constant<int, 0>{});
         if (t + 1 < n_tiles) tile_body(t + 1, std::integral_constant<int, 1>{});
-        if constexpr (VISP_ATTN_PAIR) {
-            if (t + 2 < n_tiles) tile_body(t + 2, std::integral_constant<int, 2>{});
-            if (t + 3 < n_tiles) tile_body(t + 3, std::integral_constant<int, 3>{});
-        }
     }
 
     if constexpr (STAMP) {

@@ -1,8 +1,10 @@
-// Token-stationary DINOv2 block kernel, 16-token form (embed dim 384, MLP 1536, head dim 64) -- the same operation and the same
-// argument block as kernels_block.hip (include/visp_hip_kernels.h, vx_dino_block_args), built on v_mfma_f32_16x16x32_f16. One
-// difference at the interface: LayerScale is expected FOLDED into the residual products (rows of Wo / W2 and bo / b2 scaled by
-// lambda1 / lambda2 before packing), so that the residual stream can live in the MFMA accumulators from the attention output to
-// the next layer's q, k, v: x is read once and written once per launch.
+// Token-stationary DINOv2 block kernel (embed dim 384, MLP 1536, head dim 64; argument block vx_dino_block_args in
+// include/visp_hip_kernels.h), built on v_mfma_f32_16x16x32_f16: the rest of a dino::layer after attention and the next layer's
+// LN1 + QKV in one launch (reference dino.cpp:48-90, 100-107). LayerScale is expected FOLDED into the residual products (rows of
+// Wo / W2 and bo / b2 scaled by lambda1 / lambda2 before packing), so that the residual stream can live in the MFMA accumulators from
+// the attention output to the next layer's q, k, v: x is read once and written once per launch. (The first form of this kernel --
+// 32 tokens per wave, one wave per SIMD on 512 registers, 364 us against 247 -- is recorded in profiles/r02_block_kernel_anatomy.txt
+// and was removed in round 4.)
 //
 //   * 8 waves per workgroup, TWO per SIMD (256 registers each), a wave owns 16 token rows: D^T[16 features, 16 tokens] =
 //     W[16 features, 32 k] * X^T[32 k, 16 tokens]; lane l = (token n = l & 15, group g = l >> 4) holds features 4g .. 4g+3 of
@@ -38,7 +40,7 @@ constexpr int N_OUT = NT / 2;         // 12 slabs of the output projection (2 ti
 constexpr int N_MLP = 2 * (HID / 32); // fc1 slabs (2 hidden tiles each) + fc2 slabs (one 32-wide hidden block each)
 constexpr int N_QKV = 3 * NT / 2;     // 36
 
-constexpr int V_BO = 0, V_G2 = 768, V_B2 = 1152, V_B1 = 1536, V_BFC2 = 3072; // layout of kernels_block.hip; bo and b2 arrive scaled by lambda1 / lambda2, the lambda slots are not read
+constexpr int V_BO = 0, V_G2 = 768, V_B2 = 1152, V_B1 = 1536, V_BFC2 = 3072; // vec_mlp: bo' | (lambda1) | g2 | b2 | b1 | b2' | (lambda2); bo and b2 arrive scaled by lambda1 / lambda2, the lambda slots are not read
 constexpr int V_GN = 3840, V_BN = 4224, V_BQKV = 4608;
 constexpr int V_GF = 5760, V_BF = 6144;
 constexpr int V_TOTAL = 6528;
@@ -99,7 +101,7 @@ constexpr int DBG = VISP_BLOCK16_DBG;
 
 template <bool MLP, bool QKV, bool TAP>
 __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_args args) {
-    // every field in a local (see kernels_block.hip: a captured argument struct ends up in scratch)
+    // every field in a local (a lambda that captures the argument struct by reference puts it in scratch)
     float* const a_x = args.x; const void* const a_att = args.att; const void* const a_wmlp = args.w_mlp; const void* const a_wqkv = args.w_qkv;
     const float* const a_vmlp = args.vec_mlp; const float* const a_vqkv = args.vec_qkv; const float* const a_vtap = args.vec_tap;
     void* const a_feat = args.feat; void* const a_q = args.q; void* const a_k = args.k; void* const a_v = args.v; float* const a_cap = args.cap_x1;
@@ -602,6 +604,10 @@ int launch16(const vx_dino_block_args& a, void* stream) {
 } // namespace
 
 extern "C" {
+
+int vx_dino_block_supported(int embed_dim, int hidden, int head_dim) { return embed_dim == D && hidden == HID && head_dim == 64; }
+size_t vx_dino_block_mlp_bytes(void) { return (size_t)(N_OUT + N_MLP) * SLAB; }
+size_t vx_dino_block_qkv_bytes(void) { return (size_t)N_QKV * SLAB; }
 
 int vx_dino_block16_pack_mlp(const void* wo, const void* w1, const void* w2, void* out) {
     VX_REQUIRE(wo && w1 && w2 && out, "vx_dino_block16_pack_mlp: null pointer");

@@ -511,11 +511,8 @@ int dispatch_tile(const vx_gemm_args& a, hipStream_t s) {
             }
             return launch<128, 128, 64, 64, 1, EPI, CONV>(a, s);
         } else {
-            // Few tiles and a deep reduction (the 3x3 stride-2 reassemble conv of the DPT neck: 273 tiles, K = 3456): one workgroup
-            // per CU, nothing to hide a k-tile's L2 round trip behind -- a 3-stage ring keeps two k-tiles in flight instead (a.stages = 3).
-            const long tiles = (long)((a.M + 127) / 128) * (a.N / 128) * (a.k_splits > 1 ? a.k_splits : 1);
-            (void)tiles; // measured (DPT neck 3x3 stride-2 conv, 273 tiles, K = 3456): 103 us single stage, 138 us with the 3-stage ring -- opt-in only
-            if (a.stages == 3) return launch<128, 128, 64, 64, 3, EPI, CONV>(a, s);
+            // (few tiles and a deep reduction -- the DPT neck's 3x3 stride-2 conv, 273 tiles, K = 3456 -- was tried on a 3-stage ring:
+            // 138 us against 103 single-stage; removed in round 4)
             return launch<128, 128, 64, 64, 1, EPI, CONV>(a, s);
         }
     }

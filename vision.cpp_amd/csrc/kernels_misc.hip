@@ -42,53 +42,6 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     }
 }
 
-// ---- residual update fused into the LayerNorm that follows it (dino.cpp:80-90: x = x + lambda * f(...); norm(x)):
-// the projection GEMM leaves y = f(...) as an f16 tile (coalesced 16-byte stores instead of a strided f32
-// read-modify-write of x in its epilogue), this kernel applies x += lambda * y in f32, stores x and normalises the
-// row it already holds in registers: 33 MB less traffic per residual than RMW epilogue + separate LayerNorm.
-template <int VPL>
-__global__ __launch_bounds__(256) void layernorm_resid_vec_kernel(float* __restrict__ x, const f16* __restrict__ yin,
-                                                                   const float* __restrict__ lambda, const float* __restrict__ w,
-                                                                   const float* __restrict__ b, f16* __restrict__ y, int M, int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float2* xr = reinterpret_cast<float2*>(x + (long)row * C);
-    const f16x2* ur = reinterpret_cast<const f16x2*>(yin + (long)row * C);
-    const float2* lr = reinterpret_cast<const float2*>(lambda);
-    float2 v[VPL];
-    float sum = 0.0f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        v[i] = xr[lane + 64 * i];
-        const f16x2 u = ur[lane + 64 * i];
-        const float2 l = lr[lane + 64 * i];
-        v[i].x += (float)u[0] * l.x;
-        v[i].y += (float)u[1] * l.y;
-        xr[lane + 64 * i] = v[i];
-        sum += v[i].x + v[i].y;
-    }
-    if (!y) return; // update only (no consumer of the normalised row)
-    const float inv_c = 1.0f / (float)C; // uniform: one scalar division per wave
-    const float mean = wave_sum(sum) * inv_c;
-    float sq = 0.0f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        v[i].x -= mean; v[i].y -= mean;
-        sq += v[i].x * v[i].x + v[i].y * v[i].y;
-    }
-    const float rstd = __builtin_amdgcn_rsqf(fmaf(wave_sum(sq), inv_c, eps)); // v_rsq_f32: no IEEE division / sqrt sequence per lane
-    const float2* wr = reinterpret_cast<const float2*>(w);
-    const float2* br = reinterpret_cast<const float2*>(b);
-    f16x2* yr = reinterpret_cast<f16x2*>(y + (long)row * C);
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        float2 ww = wr[lane + 64 * i], bb = br[lane + 64 * i];
-        f16x2 o = {(f16)(v[i].x * rstd * ww.x + bb.x), (f16)(v[i].y * rstd * ww.y + bb.y)};
-        yr[lane + 64 * i] = o;
-    }
-}
-
 // generic fallback: any C, one wave per row, three strided passes
 __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ b, f16* __restrict__ y,
@@ -301,24 +254,6 @@ int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y
     else if (C == 768) hipLaunchKernelGGL(layernorm_vec_kernel<6>, grid, block, 0, s, x, w, b, yy, M, C, eps);
     else if (C == 1024) hipLaunchKernelGGL(layernorm_vec_kernel<8>, grid, block, 0, s, x, w, b, yy, M, C, eps);
     else hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, w, b, yy, M, C, eps);
-    VX_LAUNCH_CHECK();
-    return 1;
-}
-
-int vx_layernorm_resid_supported(int C) { return C == 128 || C == 384 || C == 768 || C == 1024; }
-
-int vx_layernorm_resid_f32_f16(float* x, const void* y_in, const float* lambda, const float* w, const float* b, void* y, int M, int C,
-                               float eps, void* stream) {
-    VX_REQUIRE(M > 0 && vx_layernorm_resid_supported(C), "vx_layernorm_resid: C = %d is not one of 128/384/768/1024", C);
-    VX_REQUIRE(x && y_in && lambda && (!y || (w && b)), "vx_layernorm_resid: null operand");
-    dim3 grid((M + 3) / 4), block(256);
-    hipStream_t s = as_stream(stream);
-    const f16* u = reinterpret_cast<const f16*>(y_in);
-    f16* yy = reinterpret_cast<f16*>(y);
-    if (C == 384) hipLaunchKernelGGL(layernorm_resid_vec_kernel<3>, grid, block, 0, s, x, u, lambda, w, b, yy, M, C, eps);
-    else if (C == 128) hipLaunchKernelGGL(layernorm_resid_vec_kernel<1>, grid, block, 0, s, x, u, lambda, w, b, yy, M, C, eps);
-    else if (C == 768) hipLaunchKernelGGL(layernorm_resid_vec_kernel<6>, grid, block, 0, s, x, u, lambda, w, b, yy, M, C, eps);
-    else hipLaunchKernelGGL(layernorm_resid_vec_kernel<8>, grid, block, 0, s, x, u, lambda, w, b, yy, M, C, eps);
     VX_LAUNCH_CHECK();
     return 1;
 }

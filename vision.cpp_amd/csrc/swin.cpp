@@ -125,7 +125,7 @@ void swin_load_into(swin_model& mdl, model_file const& file, backend_device cons
         Wt.out_norm_w[l] = pk.vec(e + "norm" + std::to_string(l) + ".weight");
         Wt.out_norm_b[l] = pk.vec(e + "norm" + std::to_string(l) + ".bias");
     }
-    VX(vx_set_device(dev.index));
+    device_turn turn(dev);
     model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256) + 4096;
     VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
     VX(vx_memcpy_h2d(model->weight_arena.ptr, ab.data.data(), ab.data.size(), dev.stream));
@@ -228,7 +228,7 @@ void swin_encode_pixels(swin_model& m, void const* in8_arg, int B, int w, int h,
     if (B < 1 || (!in8_arg && !rgb_dev)) throw except("swin: empty batch or null pointer");
     // patch 4, then three patch mergings that require even maps (swin.cpp:143)
     if (w < 32 || h < 32 || w % 32 || h % 32) throw except("swin: image extent %dx%d must be a positive multiple of 32", w, h);
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     void* s = stream ? stream : m.backend->stream;
     swin_params const& P = m.params;
     swin_weights const& Wt = m.weights;
@@ -325,7 +325,7 @@ void swin_encode_pixels(swin_model& m, void const* in8_arg, int B, int w, int h,
 
 void swin_encode_batch_host(swin_model& m, uint8_t const* rgb, int B, int w, int h, float* const outs[4]) {
     if (B < 1 || !rgb || !outs) throw except("swin: empty batch or null pointer");
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     void* s = m.backend->stream;
     int dims[4][3];
     swin_output_dims(m, w, h, dims);

@@ -143,7 +143,7 @@ sam_model* sam_load_model(char const* filepath, backend_device const& dev, int f
         }
     }
 
-    VX(vx_set_device(dev.index));
+    device_turn turn(dev);
     model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256) + 4096;
     VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
     if (with_data) {
@@ -159,7 +159,7 @@ sam_model* sam_load_model(char const* filepath, backend_device const& dev, int f
 void sam_weights_ready(sam_model& m) {
     samdec_weights& D = m.dec;
     if (D.present) {
-        VX(vx_set_device(m.backend->index));
+        device_turn turn(*m.backend);
         void* s = m.backend->stream;
         const uint8_t* wa = static_cast<const uint8_t*>(m.weight_arena.ptr);
         const int dim = D.dim;
@@ -284,7 +284,7 @@ struct tv_exec {
 void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out_dev, void* stream) {
     if (!m.weights_uploaded) throw except("sam: weights have not been uploaded (load_no_upload without weights_ready)");
     if (B < 1 || !rgb_dev || !out_dev) throw except("sam: empty batch or null pointer");
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     void* s = stream ? stream : m.backend->stream;
     tiny_vit_params const& P = m.params;
     tinyvit_weights const& Wt = m.weights;
@@ -382,7 +382,7 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
 
 void sam_encode_batch_host(sam_model& m, uint8_t const* rgb, int B, float* out) {
     if (B < 1 || !rgb || !out) throw except("sam: empty batch or null pointer");
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     const int S = m.params.img_size, R = m.params.layers[3].resolution;
     const size_t in_bytes = (size_t)B * S * S * 3, out_bytes = (size_t)B * R * R * 256 * 4;
     void *din = nullptr, *dout = nullptr;
@@ -429,7 +429,7 @@ void sam_encode(sam_model& m, image_view image) {
             memcpy(dst, dst - (size_t)S * 3, (size_t)S * 3);
         }
     }
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     const int R = m.params.layers[3].resolution;
     const size_t out_bytes = (size_t)R * R * 256 * 4;
     if (!m.embed.ptr) { // embedding + the staging copy of the input stay with the model
@@ -461,7 +461,7 @@ image_data sam_compute(sam_model& m, int const* prompt, int n_prompt) {
     if (!D.present) throw except("sam: this model file holds no prompt encoder / mask decoder (dec.* tensors)");
     if (D.gaussian.empty()) throw except("sam: the decoder's host tables were not read (model loaded without data)");
     if (!m.embed.ptr || m.image_extent[0] <= 0) throw except("Missing image embeds, call sam_encode() first");
-    VX(vx_set_device(m.backend->index));
+    device_turn turn(*m.backend);
     void* s = m.backend->stream;
     const int dim = D.dim, H = D.heads, res = D.res, Nk = res * res, Nt = 7, F = dim / 2;
     const int image_size = m.params.img_size, mask_size = 4 * res;

@@ -44,7 +44,7 @@ TINY = Config(embed_dim=32, n_layers=4, n_heads=2, image_size=70, neck_sizes=(8,
 MINI = Config(embed_dim=128, n_layers=4, n_heads=2, image_size=112, neck_sizes=(48, 96, 192, 384),
               fusion_size=64, head_size=32, feature_layers=(0, 1, 2, 3), name="mini")
 # "short": the north-star widths (384 / 1536, 6 heads of 64) with 3 layers on 8x8 patches -- the smallest model that runs
-# the token-stationary block kernel (csrc/kernels_block.hip); the last two taps name the same layer
+# the token-stationary block kernel (csrc/kernels_block16.hip); the last two taps name the same layer
 SHORT = Config(embed_dim=384, n_layers=3, n_heads=6, image_size=112, feature_layers=(0, 1, 2, 2), name="short")
 
 
