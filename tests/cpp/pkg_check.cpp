@@ -70,7 +70,8 @@ int main(int argc, char** argv) {
             expect(depth.format == visp::image_format::alpha_f32, "depth is alpha_f32");
             depth_stats s = stats_of(depth);
             expect(s.finite, "depth is finite");
-            expect(s.lo == 0.f && s.hi > 0.99f && s.hi <= 1.f, "depth is min-max normalised to [0, 1]");
+            // normalised to [0, 1] at the model's extent, then scaled back to the caller's (a cubic filter: small over- / undershoot)
+            expect(s.lo > -0.1f && s.lo < 0.2f && s.hi > 0.8f && s.hi < 1.1f, "depth spans the normalised range");
             visp::image_data again = visp::depthany_compute(model, image); // same model, same image: same bits
             expect(std::memcmp(depth.data.get(), again.data.get(), size_t(e[0]) * size_t(e[1]) * 4) == 0, "repeatable result");
         }

@@ -7,7 +7,7 @@ IFS=';' read -ra VS <<< "${VARIANTS:-base=;nofeed=-DVISP_BLOCK16_DBG=1;nofrag=-D
 for v in "${VS[@]}"; do
   name=${v%%=*}; flags=${v#*=}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 $flags -c kernels_block16.hip -o build/kernels_block16.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libvisioncpp_v_$name.so build/*.o -Wl,--no-undefined
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libvisioncpp_v_$name.so $(make -s print-obj) -Wl,--no-undefined
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -c kernels_block16.hip -o build/kernels_block16.o
 cd ../..

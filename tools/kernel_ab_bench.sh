@@ -6,7 +6,7 @@ cd vision.cpp_amd/csrc
 i=0
 for src in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -x hip -c "$src" -o build/$OBJ.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libvisioncpp_ab_$i.so build/*.o -Wl,--no-undefined
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libvisioncpp_ab_$i.so $(make -s print-obj) -Wl,--no-undefined
   i=$((i+1))
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -c $OBJ.hip -o build/$OBJ.o

@@ -24,7 +24,7 @@ T round_up(T x, T m) { return (x + m - 1) / m * m; }
 //
 // backend (reference src/visp/ml.cpp:59-95)
 
-device_turn::device_turn(backend_device const& dev) : lock(dev.turn) { device_turn turn(dev); }
+device_turn::device_turn(backend_device const& dev) : lock(dev.turn) { VX(vx_set_device(dev.index)); }
 
 backend_device* backend_init(int device_index) {
     int n = vx_device_count();

@@ -57,7 +57,15 @@ constexpr int V_TOTAL = 6528;
 #ifndef VISP_BLOCK16_LN_FENCE
 #define VISP_BLOCK16_LN_FENCE 1
 #endif
+#ifndef VISP_BLOCK16_SPREAD
+#define VISP_BLOCK16_SPREAD 1
+#endif
 constexpr int LN_FENCE = VISP_BLOCK16_LN_FENCE; // scheduling fence after every LN_FENCE k-blocks of a LayerNorm's fragment pass (0 = none)
+// SPREAD: the 6 LDS-DMA copies a wave owes per slab pair are issued one per MFMA group in groups 0 .. 5 of the step that follows the
+// boundary, not as a burst behind the barrier. An LDS-DMA instruction costs its wave 60-180 issue cycles (MI355X_MICROARCH.md, 'LDS-DMA
+// piece issue cost'): six in a row right after the barrier are ~600 cycles in which BOTH waves of a SIMD issue no MFMA (they pass the
+// barrier together); one per group rides under the group's own MFMAs. 0: the burst (A/B builds).
+constexpr int SPREAD = VISP_BLOCK16_SPREAD;
 constexpr int PF = VISP_BLOCK16_PF;   // fragment window per stream (A/B builds: tools/block16_diag.sh)
 constexpr int DG = VISP_BLOCK16_DEFER; // groups of a step that run after the next pair's boundary (0: every step opens with its own boundary)
 static_assert(PF % 2 == 0 && FR % PF == 0 && PF - 2 * DG >= 2, "the window must hold the deferred groups and the next step's first group");
@@ -94,10 +102,15 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
 
 // DBG: diagnostic builds only (-DVISP_BLOCK16_DBG=n, tools/bench_block.py): 1 no global weight loads, 2 no ring writes, 8 no fragment
 // reads, 32 no GELU, 64 no step barrier, 128 no q/k/v stores, 1024 time the waits at every boundary (valid results) -- results are garbage, the launch time shows what each part of the stream costs
+// 2048: a second workgroup barrier in the middle of every step (before group VISP_BLOCK16_MID); 4096 (with 2048): waves 4-7 run half a step behind
+// waves 0-3 (one extra barrier at their start, one at the leaders' end) -- the timing of a staggered schedule without its ring bookkeeping (data races)
 #ifndef VISP_BLOCK16_DBG
 #define VISP_BLOCK16_DBG 0
 #endif
 constexpr int DBG = VISP_BLOCK16_DBG;
+#ifndef VISP_BLOCK16_MID
+#define VISP_BLOCK16_MID 5
+#endif
 
 template <bool MLP, bool QKV, bool TAP>
 __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_args args) {
@@ -154,6 +167,14 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
 #pragma unroll
         for (int z = 0; z < WP; ++z) lds_dma16(src + z * 1024, dst + z * 1024);
     };
+    // SPREAD: the copies of the pair after the one a boundary opened, owed during the step that follows that boundary
+    const unsigned char* owed_src = nullptr;
+    unsigned owed_dst = 0;
+    bool owed = false;
+    auto feed_piece = [&](int z) __attribute__((always_inline)) {
+        if constexpr (DBG & 1) return;
+        if (owed) lds_dma16(owed_src + z * 1024, owed_dst + z * 1024);
+    };
     const unsigned char* const rd0 = ring + lane * 16;
     {
         feed_pair(0, 0);
@@ -166,6 +187,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
     }
 
     stamp(1);
+    if constexpr ((DBG & 4096) != 0) { if (wave >= 4) __builtin_amdgcn_s_barrier(); }
     int k = 0, st = 0; // first slab of the step in flight and its ring stage (0 or 2)
     const unsigned char *curx = rd0, *cury = rd0 + SLAB;
     f16x8 wfx[PF] = {}, wfy[PF] = {};
@@ -199,7 +221,15 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
                 wfy[i] = *reinterpret_cast<const f16x8*>(cury + i * 1024);
             }
         }
-        if (k + 2 < n_slabs) feed_pair(k + 2, st ^ 2);
+        if constexpr (SPREAD) {
+            owed = k + 2 < n_slabs;
+            if (owed) {
+                owed_src = pair_src(k + 2);
+                owed_dst = __builtin_amdgcn_readfirstlane(ring_lds + (st ^ 2) * SLAB + wave * WP * 1024);
+            }
+        } else {
+            if (k + 2 < n_slabs) feed_pair(k + 2, st ^ 2);
+        }
         st ^= 2;
         k += 2;
     };
@@ -216,6 +246,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
         static_for<FR / 2>([&](auto gc) __attribute__((always_inline)) {
             constexpr int gi = CI(gc), f0 = 2 * gi, f1 = f0 + 1;
             if constexpr (CONT && gi == FR / 2 - DG) boundary(yc, std::integral_constant<int, PF - 2 * DG>{});
+            if constexpr ((DBG & 2048) != 0 && gi == VISP_BLOCK16_MID) __builtin_amdgcn_s_barrier();
             ym(std::integral_constant<int, f1>{}, wfy[f1 % PF]);
             xm(std::integral_constant<int, f1>{}, wfx[f1 % PF]);
             ym(std::integral_constant<int, f0>{}, wfy[f0 % PF]);
@@ -228,6 +259,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
                 wfx[f1 % PF] = *reinterpret_cast<const f16x8*>(curx + (r0 + 1) * 1024);
                 wfy[f1 % PF] = *reinterpret_cast<const f16x8*>(cury + (r0 + 1) * 1024);
             }
+            if constexpr (SPREAD && gi < WP) feed_piece(gi);
             side(std::integral_constant<int, 2 * f0>{});
             side(std::integral_constant<int, 2 * f0 + 1>{});
             side(std::integral_constant<int, 2 * f0 + 2>{});
@@ -504,8 +536,9 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
                     if constexpr (i == 6) cvt4(raw[2], raw_sc, pend1, none);
                     if constexpr (i == 8) cvt4(raw[3], raw_sc, pend1, yes);
                     if constexpr (!(DBG & 128)) {
-                        if constexpr (i == 16) __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
-                        if constexpr (i == 32) __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
+                        // (both behind the last spread copy of group 5: the boundary's counted wait then leaves exactly these two in flight)
+                        if constexpr (i == (SPREAD ? 24 : 16)) __builtin_amdgcn_raw_buffer_store_b128(pend0, pend_rs, pend_off, 0, 0);
+                        if constexpr (i == (SPREAD ? 38 : 32)) __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
                     } else { // keep the results alive so that the MFMAs stay
                         if constexpr (i == 16) asm volatile("" ::"v"(pend0));
                         if constexpr (i == 32) asm volatile("" ::"v"(pend1));
@@ -565,6 +598,7 @@ __global__ __launch_bounds__(512) void dino_block16_kernel(const vx_dino_block_a
             __builtin_amdgcn_raw_buffer_store_b128(pend1, pend_rs, pend_off, 64, 0);
         }
     }
+    if constexpr ((DBG & 4096) != 0) { if (wave < 4) __builtin_amdgcn_s_barrier(); }
     stamp(10);
     stamp(15);
     if constexpr (DBG & 1024) {
