@@ -260,7 +260,10 @@ enum visp_graph_op {
     VISP_OP_RESHAPE = 15,          /* i0..i3 ne */
     VISP_OP_REPEAT = 16,           /* i0..i3 ne */
     VISP_OP_PATCH_EMBED = 17,      /* src x f32 [C,W,H,N], w, (b); i0 patch size                           nn.cpp:166-180 */
-    VISP_OP_CONT = 18
+    VISP_OP_CONT = 18,
+    /* extensions for callers that keep images in HBM (the reference does both steps on the host): */
+    VISP_OP_IMAGE_U8_TO_F32 = 19,  /* src x u8 input [3,W,H,N]; f0..f2 mean, f3..f5 1/std: (x / 255 - mean) / std        image.cpp:215-255 */
+    VISP_OP_IMAGE_NORMALIZE = 20   /* src x f32 [1,W,H,N]: per-image min-max to [0, 1]                                   image.cpp:537-582 */
 };
 /* every f16 / f32 tensor of the file becomes a weight (model_load + model_transfer, ml.cpp:206-217, 449-516); conv kernels listed in
  * <arch>.conv2d_weights of a whcn file are presented as [Cin,kw,kh,Cout]. Device images are made when a graph that uses a tensor is
@@ -284,7 +287,7 @@ VISP_API int32_t visp_graph_create(visp_weights* weights, visp_graph** out);
 VISP_API void visp_graph_destroy(visp_graph* g);
 VISP_API int32_t visp_graph_add_weight(visp_graph* g, char const* name, int32_t dtype, int64_t const ne[4], float const* data, int32_t* out);
 VISP_API int32_t visp_graph_find_weight(visp_graph* g, char const* name, int32_t* out); /* *out = -1 when absent (model_ref::find) */
-VISP_API int32_t visp_graph_input(visp_graph* g, int32_t dtype /* 0 f32, 1 f16 */, int64_t const ne[4], char const* name, int32_t* out);
+VISP_API int32_t visp_graph_input(visp_graph* g, int32_t dtype /* 0 f32, 1 f16, 24 u8 image bytes */, int64_t const ne[4], char const* name, int32_t* out);
 VISP_API int32_t visp_graph_op(visp_graph* g, int32_t op, int32_t const* src, int32_t n_src, int64_t const* iparams, int32_t n_iparams,
                                float const* fparams, int32_t n_fparams, int32_t* out);
 VISP_API int32_t visp_graph_set_name(visp_graph* g, int32_t tensor, char const* name);
@@ -296,6 +299,11 @@ VISP_API int32_t visp_graph_read_constant(visp_graph const* g, int32_t tensor, f
 /* compute_graph_allocate (ml.cpp:545-552): lower to launches, pack the weights the graph uses, plan + allocate the arena on `dev`.
  * dev == NULL: lower and plan only -- no device work (visp_graph_describe shows the launch list and the arena size) */
 VISP_API int32_t visp_graph_allocate(visp_graph* g, visp_device const* dev);
+/* before visp_graph_allocate. 1 (default): the lowering may replace whole node groups by the kernels written for them -- the dino::layer group
+ * (embed 384 / mlp 1536 / heads of 64) by attention + one token-stationary block launch on an f32 residual stream, 3x3 convs by the LDS-ring conv,
+ * interpolate -> conv by the resizing halo loader, interpolate -> conv 1x1 by projection-then-resize, a sliced GEMM operand by row addressing.
+ * 0: one launch per epilogue-fused node on f16 activations. */
+VISP_API int32_t visp_graph_set_fused_models(visp_graph* g, int32_t enable);
 VISP_API int32_t visp_graph_use_hip_graph(visp_graph* g, int32_t enable); /* replay the launch list as one hipGraph from the second compute on */
 VISP_API int32_t visp_graph_compute(visp_graph* g);   /* blocking (ml.cpp:559-562) */
 VISP_API int32_t visp_graph_tensor_set(visp_graph* g, int32_t tensor, void const* data, size_t n_bytes);

@@ -85,32 +85,79 @@ def test_constants_fold_on_the_host_like_the_oracle_computes_them():
     np.testing.assert_allclose(g.read_constant(r), np.broadcast_to(3.0 * g.read_constant(cls), (1, 3, 1, D)), rtol=1e-6)
 
 
-@pytest.fixture(scope="module")
-def planned(tmp_path_factory):
+def _planned(tmp_path_factory, fused_models):
     path = synth.write_gguf(tmp_path_factory.mktemp("g") / "small.gguf", synth.SMALL, seed=0)
     g = G.Graph(None, G.Weights(path))
+    g.set_fused_models(fused_models)
     img = g.input((3, 518, 518, 2), G.F32, "image")
     out = G.depthany_predict(G.ModelRef(g), img, 12, 6)
     g.allocate()
     return g, img, out
 
 
+@pytest.fixture(scope="module")
+def planned(tmp_path_factory):  # one launch per epilogue-fused node
+    return _planned(tmp_path_factory, False)
+
+
+@pytest.fixture(scope="module")
+def planned_fused(tmp_path_factory):  # node groups mapped onto the kernels written for them (the default)
+    return _planned(tmp_path_factory, True)
+
+
+def test_depth_anything_node_groups_lower_to_the_model_kernels(planned_fused):
+    """The default lowering of the same 567 nodes: 62 launches -- the launch list of the hand-written step this library measured in rounds 1-3,
+    now derived from the graph. dino.cpp:10-110: prepare_tokens = patches + cls rows + one GEMM whose epilogue writes f32 token rows; the
+    first layer's LN1 + QKV, then per layer ONE attention and ONE token-stationary block launch (out-proj, both residuals, MLP, the taps'
+    final LayerNorm, the next layer's LN1 + QKV). depth-anything.cpp:15-96: the cls-token slice is row addressing in the projection GEMM,
+    the 48 / 96-channel projections are written with the padded rows their conv_transpose reads, every 3x3 / stride-1 conv is the LDS-ring
+    kernel with ReLU-in / ReLU / two residual maps in its epilogue, the fusion projection runs BEFORE its resize, head.conv1 resizes in
+    its halo loader, the head's tail is one kernel."""
+    g, img, out = planned_fused
+    lines = g.describe().strip().splitlines()
+    assert g.summary()["launches"] == len(lines) - 1 == 62
+    assert lines[0].startswith("im2col_patches 14x14 M=2738") and lines[1] == "cls_rows B=2" and lines[2].startswith("gemm[tokens f32: + bias + pos] M=2738 N=384 K=588")
+    assert lines[3].startswith("dino_block[ln1 + qkv] M=2740")
+    assert [l.split(" M=")[0] for l in lines[4:28]] == ["attention B=2 heads=6 T=1370", "dino_block[out-proj + mlp + next ln1 + qkv]"] * 2 + \
+        (["attention B=2 heads=6 T=1370", "dino_block[out-proj + mlp + tap + next ln1 + qkv]"] + ["attention B=2 heads=6 T=1370", "dino_block[out-proj + mlp + next ln1 + qkv]"] * 2) * 3 + \
+        ["attention B=2 heads=6 T=1370", "dino_block[out-proj + mlp + tap]"]
+    text = "\n".join(lines)
+    assert text.count("gemm(conv1x1)[rows 1.. of 1370] M=2738") == 4 and not any(l.startswith(("slice", "pad_rows")) for l in lines)
+    assert text.count("gemm+pixel_shuffle") == 2 and "conv3x3s2 M=722 N=384 K=3456" in text
+    assert text.count("dconv3x3 M=") == 4                                            # neck.convs (no bias, no activation)
+    assert text.count("dconv3x3[relu-in][relu]") == 7 and text.count("dconv3x3[+res][+res]") == 3 and text.count("dconv3x3[+res] M=") == 4
+    assert text.count("gemm(conv1x1 before its resize)") == 4 and text.count("bilinear_ac") == 3
+    assert lines[-3].startswith("dconv3x3[resize 148x148 in the loader] M=175232 N=32 K=576 <- head.conv1.weight")
+    assert lines[-2].startswith("head_tail[resize 296x296 -> 518x518, conv3x3 32->32, relu, conv1x1 -> 1, relu] B=2 <- head.conv2.weight")
+    assert g.get_tensor("dino_layer_11").ne == (384, 1370, 2, 1)
+    # a group is only taken when nothing outside reads its interior: an output in the middle of a layer sends the encoder down the generic path
+    path = synth.write_gguf(__import__("pathlib").Path(__import__("tempfile").mkdtemp()) / "small.gguf", synth.SMALL, seed=0)
+    g2 = G.Graph(None, G.Weights(path))
+    x = g2.input((3, 518, 518, 1), G.F32, "image")
+    G.depthany_predict(G.ModelRef(g2), x, 12, 6)
+    hidden = g2.get_tensor("backbone.encoder.layer.4")  # a layer output: allowed (copied out of the f32 stream) ...
+    g2.output(hidden, "layer_4")
+    g2.allocate()
+    assert g2.describe().count("dino_block[") == 13 and "copy_f32 layer output" in g2.describe() and g2.get_tensor("layer_4").dtype == G.F32
+
+
 def test_depth_anything_lowers_to_fused_launches(planned):
-    """567 graph nodes (weights included) lower to 137 launches, 7 per encoder layer: the three q / k / v products of an attention are one
+    """Without the model-kernel groups (set_fused_models(False)) 567 graph nodes (weights included) lower to 134 launches, 7 per encoder layer: the three q / k / v products of an attention are one
     GEMM with a head-major epilogue, LayerScale is folded into the packed weights so the residual rides in the product's epilogue,
     activations, ReLU-on-load and conv residuals are epilogues and loader flags, views cost nothing, and everything computed from weights
     alone was folded when the node was made."""
     g, img, out = planned
     lines = g.describe().strip().splitlines()
     s = g.summary()
-    assert s["launches"] == len(lines) - 1 == 137
+    assert s["launches"] == len(lines) - 1 == 134
     text = "\n".join(lines)
     assert text.count("gemm[qkv heads-major] M=2740 N=1152 K=384") == 12  # query | key | value (dino.cpp:59-70): one product
     assert text.count("gemm[*scale][+res]") == 24                # out-proj and fc2 with layer_scale + residual (dino.cpp:48-50, 80-87)
     assert not any(l.startswith(("mul", "heads_major")) for l in lines)
     assert text.count("gemm[gelu]") == 12                       # fc1 + gelu (dino.cpp:52-56)
     assert text.count("attention B=2 heads=6 T=1370") == 12
-    assert text.count("[relu-in][relu]") == 7 and text.count("conv3x3[+res]") == 7  # residual_conv x 7 (depth-anything.cpp:15-23): two launches each
+    # residual_conv x 7 (depth-anything.cpp:15-23): two launches each; feature_fusion's x0 + ... rides in the same epilogue as a second residual
+    assert text.count("[relu-in][relu]") == 7 and text.count("conv3x3[+res] M=") == 4 and text.count("conv3x3[+res][+res]") == 3
     assert text.count("gemm+pixel_shuffle") == 2                 # conv_transpose k == s (nn.cpp:117-129)
     assert "conv3x3s2 M=722 N=384 K=3456" in text                # reassemble 3: 3x3 stride 2 on 37 x 37
     # the head's tail -- resize, conv2, relu, conv3, relu -- is the one launch of the kernel made for it (kernels_headconv.hip)

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""The generic path next to the hand-scheduled one: Depth-Anything-V2-Small built through the graph layer (vision.cpp_amd/graph.py::
-depthany_predict -> csrc/graph.cpp) at the north-star shape, timed as eager launches and as one hipGraph replay, against the static step
-of csrc/depthany.cpp (bench.py's workload). Prints ms per batch and images/s for each."""
+"""Depth-Anything-V2-Small at the north-star shape through the graph layer, every way it can be driven (round 4: the model entries of the
+library run on this layer too):
+  * a graph built by the Python face (vision.cpp_amd/graph.py::depthany_predict, the node list the reference's arch sources build) on an
+    f32 image, one stream, eager launches and one hipGraph replay -- with the model-kernel node groups (default) and without
+    (set_fused_models(False): one launch per epilogue-fused node);
+  * the library's own step (visp_depthany_compute_batch_device: u8 in HBM -> normalised depth, three sub-batch graphs on parallel
+    streams inside one hipGraph) -- bench.py's workload.
+Prints ms per batch and images/s for each."""
 import sys
 import tempfile
 import time
@@ -36,8 +41,10 @@ def timed(fn, n=20, warm=3):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for hip_graph in (False, True):
+depth = None
+for fused, hip_graph in ((False, True), (True, False), (True, True)):
     g = G.Graph(dev, G.Weights(path))
+    g.set_fused_models(fused)
     xi = g.input((3, W, H, B), G.F32, "image")
     out = G.depthany_predict(G.ModelRef(g), xi, 12, 6)
     t0 = time.perf_counter()
@@ -47,8 +54,8 @@ for hip_graph in (False, True):
     g.set(xi, pre)
     ms = timed(g.compute)
     s = g.summary()
-    print(f"graph executor ({'one hipGraph replay' if hip_graph else 'eager launches'}): {ms:.3f} ms per batch of {B} = {B / ms * 1e3:.0f} img/s; "
-          f"{s['launches']} launches, arena {s['arena_bytes'] / 1e6:.0f} MB (unshared {s['unshared_bytes'] / 1e6:.0f} MB), lower + pack + upload {t_alloc:.2f} s", flush=True)
+    print(f"graph ({'model-kernel groups' if fused else 'one launch per node'}, one stream, {'hipGraph replay' if hip_graph else 'eager launches'}): "
+          f"{ms:.3f} ms per batch of {B} = {B / ms * 1e3:.0f} img/s; {s['launches']} launches, arena {s['arena_bytes'] / 1e6:.0f} MB, lower + pack + upload {t_alloc:.2f} s", flush=True)
     depth = g.get(out)[..., 0]
     del g
 
@@ -57,7 +64,7 @@ model.use_graph(True)
 rgb = vision.DeviceBuffer.from_numpy(imgs)
 outb = vision.DeviceBuffer(B * W * H * 4)
 ms = timed(lambda: model.compute_batch_device(rgb.ptr, B, W, H, outb.ptr))
-print(f"hand-scheduled step (block kernel, 3 sub-batch streams, hipGraph): {ms:.3f} ms per batch of {B} = {B / ms * 1e3:.0f} img/s (includes u8 preprocessing and the min-max normalise)")
-static = outb.to_numpy(np.float32, (B, H, W))
+print(f"library step (u8 -> normalised depth, 3 sub-batch graphs on parallel streams, one hipGraph): {ms:.3f} ms per batch of {B} = {B / ms * 1e3:.0f} img/s")
+step = outb.to_numpy(np.float32, (B, H, W))
 nd = (depth - depth.min(axis=(1, 2), keepdims=True)) / (depth.max(axis=(1, 2), keepdims=True) - depth.min(axis=(1, 2), keepdims=True))
-print(f"mean |graph - static| on the normalised depth: {np.abs(nd - static).mean():.2e}")
+print(f"mean |one-stream graph - library step| on the normalised depth: {np.abs(nd - step).mean():.2e}")

@@ -109,7 +109,7 @@ C_API_SYMBOLS = [
     "visp_file_load", "visp_file_destroy", "visp_file_n_tensors", "visp_file_get_int", "visp_file_get_int_array", "visp_file_get_string", "visp_weights_from_file",
     "visp_graph_create", "visp_graph_destroy", "visp_graph_add_weight", "visp_graph_find_weight", "visp_graph_input",
     "visp_graph_op", "visp_graph_set_name", "visp_graph_get_tensor", "visp_graph_output", "visp_graph_tensor_info", "visp_graph_read_constant",
-    "visp_graph_allocate", "visp_graph_use_hip_graph", "visp_graph_compute", "visp_graph_tensor_set", "visp_graph_tensor_get", "visp_graph_describe",
+    "visp_graph_allocate", "visp_graph_set_fused_models", "visp_graph_use_hip_graph", "visp_graph_compute", "visp_graph_tensor_set", "visp_graph_tensor_get", "visp_graph_describe",
 ]
 KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
@@ -254,6 +254,7 @@ def init() -> ctypes.CDLL:
     lib.visp_graph_tensor_set.argtypes = [c_void_p, c_int32, c_void_p, c_size_t]
     lib.visp_graph_tensor_get.argtypes = [c_void_p, c_int32, c_void_p, c_size_t, c_int32]
     lib.visp_graph_describe.argtypes = [c_void_p, c_char_p, c_int64, POINTER(c_int64)]
+    lib.visp_graph_set_fused_models.argtypes = [c_void_p, c_int32]
     for name in C_API_SYMBOLS[15:]:
         getattr(lib, name).restype = c_int32
     lib.visp_depthany_pipeline_destroy.restype = None

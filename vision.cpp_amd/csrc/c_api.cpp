@@ -403,10 +403,7 @@ int32_t visp_depthany_use_graph(visp_model* m, int32_t enable) {
     return handle_errors([&]() {
         depthany_model& dm = as_depthany(m);
         dm.use_graph = enable != 0;
-        if (!enable && dm.ws.graph_exec) {
-            vx_graph_destroy(dm.ws.graph_exec);
-            dm.ws.graph_exec = nullptr;
-        }
+        if (!enable) depthany_drop_captured_steps(dm);
     });
 }
 
@@ -414,12 +411,9 @@ int32_t visp_depthany_set_schedule(visp_model* m, int32_t schedule) {
     return handle_errors([&]() {
         depthany_model& dm = as_depthany(m);
         if (schedule < -1 || schedule > 1) throw except("visp_depthany_set_schedule: unknown schedule %d (-1 = auto, 0 = GEMM launches, 1 = token-stationary block kernel)", schedule);
-        if (schedule == 1 && !dm.weights.use_block) throw except("visp_depthany_set_schedule: the block kernel is built for embed dim 384 / mlp 1536 / head dim 64 only");
+        if (schedule == 1 && !dm.block_shape) throw except("visp_depthany_set_schedule: the block kernel is built for embed dim 384 / mlp 1536 / head dim 64 only");
         dm.schedule = schedule;
-        if (dm.ws.graph_exec) { // the captured launch sequence belongs to the other schedule
-            vx_graph_destroy(dm.ws.graph_exec);
-            dm.ws.graph_exec = nullptr;
-        }
+        depthany_drop_captured_steps(dm); // (steps are keyed by the schedule: the other one is lowered on first use)
     });
 }
 
@@ -428,10 +422,6 @@ int32_t visp_depthany_set_split(visp_model* m, int32_t n) {
         depthany_model& dm = as_depthany(m);
         if (n < 0 || n > 4) throw except("visp_depthany_set_split: %d sub-batches (0 = automatic, 1 = none, at most 4)", n);
         dm.split = n;
-        if (dm.ws.graph_exec) { // the captured launch sequence has the other split
-            vx_graph_destroy(dm.ws.graph_exec);
-            dm.ws.graph_exec = nullptr;
-        }
     });
 }
 
@@ -873,6 +863,13 @@ int32_t visp_graph_allocate(visp_graph* g, visp_device const* dev) {
 }
 int32_t visp_graph_use_hip_graph(visp_graph* g, int32_t enable) {
     return handle_errors([&]() { as_graph(g).use_hip_graph = enable != 0; });
+}
+int32_t visp_graph_set_fused_models(visp_graph* g, int32_t enable) {
+    return handle_errors([&]() {
+        graph& gr = as_graph(g);
+        if (gr.allocated) throw except("visp_graph_set_fused_models: the graph is already allocated");
+        gr.fused_models = enable != 0;
+    });
 }
 int32_t visp_graph_compute(visp_graph* g) {
     return handle_errors([&]() { graph_compute(as_graph(g)); });

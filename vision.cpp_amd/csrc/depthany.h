@@ -8,6 +8,7 @@
 #include <array>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -54,8 +55,8 @@ dino_params dino_detect_params(model_file const&);                        // din
 depthany_params depthany_detect_params(model_file const&);                // depth-anything.cpp:119-128
 i32x2 depthany_image_extent(i32x2 extent, depthany_params const&);        // depth-anything.cpp:112-117
 
-// One GEMM-shaped weight in the packed arena: f16 [N][K] (both padded for the kernel's tiles,
-// pads are zero) + optional f32 bias [N].
+// One GEMM-shaped weight in a packed arena: f16 [N][K] (both padded for the kernel's tiles, pads are zero) + optional f32 bias [N]
+// (the model loaders that pack for hand schedules: tinyvit.cpp, swin.cpp, birefnet.cpp)
 struct packed_gemm {
     size_t w = 0, b = SIZE_MAX; // byte offsets into the arena
     size_t dw = SIZE_MAX;       // 3x3 convs with Cin % 32 == 0, Cout in {32, 64}: the same kernel as vx_dconv3x3_f16 slabs
@@ -65,51 +66,11 @@ struct packed_gemm {
 };
 struct packed_vec { size_t off = SIZE_MAX; int n = 0; }; // f32 vector
 
-struct dino_layer_weights {
-    packed_vec ln1_w, ln1_b, ln2_w, ln2_b, lambda1, lambda2;
-    packed_gemm qkv, out, fc1, fc2;
-    // operands of the token-stationary block kernel (kernels_block16.hip), when the model has its shape: weight slab streams
-    // (out-proj + mlp; qkv) and the per-feature vectors bo|lambda1|ln2.w|ln2.b|b1|b2|lambda2 and ln1.w|ln1.b|bqkv
-    size_t blk_mlp = SIZE_MAX, blk_qkv = SIZE_MAX, vec_mlp = SIZE_MAX, vec_qkv = SIZE_MAX;
-};
-struct fusion_weights {
-    packed_gemm proj, rl1_c1, rl1_c2, rl2_c1, rl2_c2;
-};
-struct depthany_weights {
-    packed_gemm patch;
-    packed_vec cls, pos; // f32 [D], [T0, D]
-    int pos_tokens = 0;
-    std::vector<dino_layer_weights> layers;
-    packed_vec final_ln_w, final_ln_b;
-    bool use_block = false;   // embed dim 384 / mlp 1536 / head dim 64: one launch per layer between two attentions
-    size_t vec_tap = SIZE_MAX; // final layernorm w|b for the block kernel's tap
-    std::array<packed_gemm, 4> re_proj;
-    packed_gemm re_up0, re_up1, re_down3; // convT k4s4, convT k2s2, conv3x3 s2
-    std::array<int, 4> neck_c{};          // real channel counts of the reassembled maps
-    std::array<packed_gemm, 4> neck_conv;
-    std::array<fusion_weights, 4> fusion;
-    int fusion_c = 0, head_c = 0;
-    packed_gemm head1, head2;
-    packed_vec head3_w;
-    size_t head2_frag = SIZE_MAX; // head.conv2 as register-resident MFMA fragments (kernels_headconv.hip), when it is 32 -> 32
-    float head3_b = 0;
-    size_t head3_b_off = 0;
-};
-
 struct device_buffer { void* ptr = nullptr; size_t bytes = 0; };
 
 struct capture_entry { void* dev = nullptr; int64_t shape[4] = {1, 1, 1, 1}; bool f16 = true; };
 
 struct timing_entry { std::string name; float ms = 0; int launches = 0; double flops = 0, bytes = 0; };
-
-struct depthany_workspace {
-    int B = 0, W = 0, H = 0;
-    device_buffer arena;
-    // named sub-buffers (device pointers into arena)
-    std::map<std::string, void*> buf;
-    std::map<std::string, size_t> bytes; // size of each sub-buffer (all but "pos" are image-major: bytes / B per image)
-    void* graph_exec = nullptr;
-};
 
 // every model handle starts with its family (the C ABI's handles are untyped: c-api.cpp:193 any_model)
 enum model_family_id : int32_t { family_sam = 0, family_birefnet, family_depth_anything, family_migan, family_esrgan, family_count };
@@ -119,29 +80,33 @@ struct model_base {
 };
 
 struct depthany_pipeline;
-struct depthany_model : model_base { // vision.h:339-347 counterpart
-    depthany_model() : model_base(family_depth_anything) {}
+struct depthany_step; // the lowered graphs of one (batch, extent, schedule, split): csrc/depthany.cpp
+struct weight_store;  // csrc/graph.h
+struct depthany_model : model_base { // vision.h:339-347 counterpart: {backend, weights, params, graph, input, output}
+    depthany_model();
     backend_device const* backend = nullptr;
     depthany_params params;
-    depthany_weights weights;
-    device_buffer weight_arena;
-    bool owns_weights = true; // false for an executor cloned from another model (depthany_clone_executor): the arena is borrowed
+    std::shared_ptr<weight_store> store; // the model's tensors by name + their device images per consumer role, all in one arena (shared by cloned executors)
+    device_buffer weight_arena;          // that arena: what rank 0 broadcasts and the other ranks receive (not owned here: the store frees it)
     bool weights_uploaded = false;
-    depthany_workspace ws;
+    bool block_shape = false; // embed dim 384 / mlp 1536 / head dim 64: the encoder groups lower to the token-stationary block kernel
+    std::vector<std::unique_ptr<depthany_step>> steps; // a few lowered shapes, least recently used first out
+    device_buffer host_io;    // device staging of the blocking host entry
     bool use_graph = false, captures = false, timing = false;
     int split = 0; // sub-batches of a step on parallel streams: 0 = automatic (3 from batch 24, 2 from batch 8; $VISP_SPLIT overrides), 1 = none, 2..4
     bool timing_split = false; // with timing: keep the step's sub-batch split (launches timed per stream while the other streams run)
     depthany_pipeline* shard_pipeline = nullptr; // visp_depthany_compute_sharded's overlapped host pipeline for this model (owned, lazily made)
-    int schedule = -1; // encoder schedule: -1 auto (block kernel where the model has its shape), 0 GEMM launches, 1 block kernel
+    int schedule = -1; // lowering: -1 auto (node groups on the kernels written for them), 0 one launch per epilogue-fused node (GEMM launches), 1 = auto, refused where the model has not the block kernel's shape
     std::map<std::string, capture_entry> capture_bufs;
     std::vector<timing_entry> last_timing;
-    // the four reassemble/neck-conv branches are independent until the fusion stage: they run on side
-    // streams (fork/join by events, captured into the hipGraph as parallel branches)
+    // side streams of the sub-batches (fork / join by events, captured into the hipGraph as parallel branches)
     void* aux_stream[3] = {nullptr, nullptr, nullptr};
     void* fork_event = nullptr;
     void* join_event[3] = {nullptr, nullptr, nullptr};
     ~depthany_model();
 };
+// drops the captured hipGraphs (a setting that changes what a step launches was changed)
+void depthany_drop_captured_steps(depthany_model&);
 
 enum load_flags { load_default = 0, load_no_upload = 1 };
 depthany_model* depthany_load_model(char const* filepath, backend_device const& dev, int flags = load_default);

@@ -23,7 +23,7 @@ T round_up(T x, T m) { return (x + m - 1) / m * m; }
 
 const char* const op_names[gop_count] = {"input", "weight", "linear", "layer_norm", "gelu", "relu", "scale", "add", "mul", "conv_2d",
                                          "conv_transpose_2d", "interpolate", "attention", "concat", "slice", "reshape", "repeat",
-                                         "patch_embed", "cont"};
+                                         "patch_embed", "cont", "image_u8_to_f32", "image_normalize"};
 
 std::string shape_str(const int64_t ne[4]) {
     char b[96];
@@ -196,6 +196,7 @@ graph::~graph() {
 }
 weight_store::~weight_store() {
     if (dev) vx_set_device(dev->index);
+    if (arena.ptr) vx_free(arena.ptr);
     for (void* p : allocs) vx_free(p);
 }
 
@@ -229,8 +230,9 @@ std::shared_ptr<weight_store> weights_from_file(model_file const& f) {
         gguf_tensor const& t = f.tensors[idx];
         if (t.type != GGML_F32 && t.type != GGML_F16) continue; // index tables etc. are not weights of this executor
         const int64_t n = t.n_elements();
-        tmp.resize((size_t)n);
-        if (t.type == GGML_F32) memcpy(tmp.data(), t.data, (size_t)n * 4);
+        tmp.assign((size_t)n, 0.0f);
+        if (!t.data) ws->no_data = true; // header-only read (a rank that receives the packed arena by broadcast): shapes only
+        else if (t.type == GGML_F32) memcpy(tmp.data(), t.data, (size_t)n * 4);
         else
             for (int64_t i = 0; i < n; ++i) tmp[i] = f16_to_f32(reinterpret_cast<const uint16_t*>(t.data)[i]);
         int64_t ne[4] = {t.ne[0], t.ne[1], t.ne[2], t.ne[3]};
@@ -289,7 +291,7 @@ int graph_add_weight(graph& g, char const* name, int32_t dtype, const int64_t ne
 
 int graph_input(graph& g, int32_t dtype, const int64_t ne[4], char const* name) {
     require_building(g, "graph_input");
-    if (dtype != gdt_f32 && dtype != gdt_f16) throw except("graph_input: dtype %d (0 = f32, 1 = f16)", dtype);
+    if (dtype != gdt_f32 && dtype != gdt_f16 && dtype != gdt_u8) throw except("graph_input: dtype %d (0 = f32, 1 = f16, 24 = u8 image bytes)", dtype);
     graph_node n;
     n.op = gop_input;
     n.dtype = dtype;
@@ -326,7 +328,7 @@ void graph_output(graph& g, int t, char const* name) {
 int graph_add(graph& g, int32_t op, const int* src, int n_src, const int64_t* ip, int n_ip, const float* fp, int n_fp) {
     require_building(g, "graph_add");
     if (op <= gop_weight || op >= gop_count) throw except("graph_add: op %d is not a node op", op);
-    if (n_src < 1 || n_src > 4 || n_ip < 0 || n_ip > 12 || n_fp < 0 || n_fp > 2) throw except("graph_add(%s): bad argument counts", graph_op_name(op));
+    if (n_src < 1 || n_src > 4 || n_ip < 0 || n_ip > 12 || n_fp < 0 || n_fp > 8) throw except("graph_add(%s): bad argument counts", graph_op_name(op));
     graph_node n;
     n.op = op;
     n.n_src = n_src;
@@ -465,7 +467,7 @@ int graph_add(graph& g, int32_t op, const int* src, int n_src, const int64_t* ip
             graph_node const &x = S(0), &w = S(1);
             const int64_t ps = n.ip[0];
             if (!w.constant) throw except("patch_embed: the kernel must be a model weight");
-            if (x.dtype != gdt_f32) throw except("patch_embed: the input image tensor is f32 (the tensor the reference uploads)");
+            if (x.dtype != gdt_f32) throw except("patch_embed: the input image tensor is f32 (the tensor the reference uploads, or image_u8_to_f32 of a u8 input)");
             if (ps <= 0 || w.ne[1] != ps || w.ne[2] != ps || w.ne[0] != x.ne[0]) throw except("patch_embed: kernel %s does not match patch size %lld and input %s", shape_str(w.ne).c_str(), (long long)ps, shape_str(x.ne).c_str());
             if (x.ne[1] % ps || x.ne[2] % ps) throw except("patch_embed: extent %lldx%lld is not a multiple of the patch size %lld", (long long)x.ne[1], (long long)x.ne[2], (long long)ps);
             n.ne[0] = w.ne[3];
@@ -473,10 +475,24 @@ int graph_add(graph& g, int32_t op, const int* src, int n_src, const int64_t* ip
             n.ne[2] = x.ne[2] / ps;
             n.ne[3] = x.ne[3];
         } break;
+        case gop_image_u8_to_f32: {
+            need_src(1, 1);
+            graph_node const& x = S(0);
+            if (x.op != gop_input || x.dtype != gdt_u8 || x.ne[0] != 3) throw except("image_u8_to_f32: the operand is a u8 input tensor [3, W, H, N]");
+            if (n_fp != 6) throw except("image_u8_to_f32: six float parameters (mean r g b, 1 / std r g b)");
+            same_shape();
+            n.dtype = gdt_f32;
+        } break;
+        case gop_image_normalize: {
+            need_src(1, 1);
+            if (S(0).constant || S(0).dtype != gdt_f32 || S(0).ne[0] != 1) throw except("image_normalize: the operand is a one-channel f32 map [1, W, H, N]");
+            same_shape();
+            n.dtype = gdt_f32;
+        } break;
         default: throw except("graph_add: op %d", op);
     }
     // f32 tensors exist as inputs only; an f32 operand anywhere else would need kernels this executor does not have
-    if (op != gop_patch_embed)
+    if (op != gop_patch_embed && op != gop_image_u8_to_f32 && op != gop_image_normalize)
         for (int i = 0; i < n_src; ++i) {
             const bool head_tail = (op == gop_relu || op == gop_scale) && S(i).op != gop_input;
             if (!S(i).constant && S(i).dtype != gdt_f16 && !head_tail) throw except("%s: operand %d is f32; only patch_embed reads the f32 input tensor", nm, i);
@@ -537,13 +553,25 @@ struct lowering {
         n.buffer = new_buffer(n.n_bytes(), n.is_output || n.op == gop_input);
     }
     void emit(std::string desc, std::vector<int> reads, std::vector<int> writes, std::function<void(void*)> run) {
-        g.launches.push_back({std::move(desc), std::move(run)});
+        graph_launch l;
+        l.desc = std::move(desc);
+        l.run = std::move(run);
+        g.launches.push_back(std::move(l));
         io.emplace_back(std::move(reads), std::move(writes));
+    }
+    void tag(const char* group, double flops = 0, double bytes = 0) { // timing group and algorithmic work of the launch emitted last
+        graph_launch& l = g.launches.back();
+        l.group = group;
+        l.flops = flops;
+        l.bytes = bytes;
     }
     // device pointer of a buffer at run time (offsets are assigned after the launch list is complete)
     std::function<char*()> ptr(int buf) {
         graph* gp = &g;
-        return [gp, buf]() { return static_cast<char*>(gp->arena.ptr) + gp->buffers[buf].offset; };
+        return [gp, buf]() {
+            graph_buffer const& b = gp->buffers[buf];
+            return b.external ? static_cast<char*>(b.external) : static_cast<char*>(gp->arena.ptr) + b.offset;
+        };
     }
 
     // device image of constant t in `role`: model weights are cached in the weight store (shared by every graph over the model),
@@ -558,7 +586,9 @@ struct lowering {
         void* d = nullptr;
         // only images made from NAMED model weights alone are shared: a derived image whose other operand is a constant folded inside this
         // graph ("#<node>": a node index means nothing to another graph) stays with the graph
-        if (n.op == gop_weight && g.dev && with.find('#') == std::string::npos) {
+        const bool shareable = n.op == gop_weight && with.find('#') == std::string::npos;
+        if (shareable && !g.dev) d = make(true); // planning: upload() only counts what the store would take
+        else if (shareable) {
             auto skey = std::make_pair(with.empty() ? n.name : n.name + "|" + with, role);
             std::lock_guard<std::mutex> lock(g.store->mutex); // graphs over one store may be allocated from several threads
             auto sit = g.store->packs.find(skey);
@@ -570,11 +600,23 @@ struct lowering {
     }
     void* upload(const void* host, size_t bytes, bool to_store) {
         g.const_bytes += bytes;
-        if (!g.dev) return nullptr;
+        if (!g.dev) {
+            if (to_store) g.plan_store_bytes += round_up<size_t>(bytes + 256, 256);
+            return nullptr;
+        }
         void* d = nullptr;
-        VX(vx_malloc(&d, bytes + 256));
-        if (to_store) { g.store->allocs.push_back(d); g.store->device_bytes += bytes; }
-        else g.const_allocs.push_back(d);
+        weight_store& ws = *g.store;
+        if (to_store && ws.arena.ptr && ws.arena_used + round_up<size_t>(bytes + 256, 256) <= ws.arena.bytes) { // the model's one arena, in lowering order
+            d = static_cast<char*>(ws.arena.ptr) + ws.arena_used;
+            ws.arena_used += round_up<size_t>(bytes + 256, 256);
+            ws.device_bytes += bytes;
+        } else {
+            if (to_store && ws.no_data) throw except("graph: this rank holds no weight data (the arena came by broadcast) and the image it needs is not part of the arena");
+            VX(vx_malloc(&d, bytes + 256));
+            if (to_store) { ws.allocs.push_back(d); ws.device_bytes += bytes; }
+            else g.const_allocs.push_back(d);
+        }
+        if (to_store && ws.no_data) return d; // laid out, filled by the broadcast
         VX(vx_memcpy_h2d(d, host, bytes, g.dev->stream));
         VX(vx_stream_sync(g.dev->stream)); // the host image is a temporary
         return d;
@@ -665,8 +707,8 @@ struct lowering {
     int sole_consumer(int t) const { return uses[t] == 1 && !g.nodes[t].is_output && consumers[t].size() == 1 ? consumers[t][0] : -1; }
 
     // epilogue fusion behind a matrix product: [gelu | relu] then [+ residual]
-    struct epilogue { int act = 0; int res = -1; int last = -1; int scale = -1; };
-    epilogue fuse_epilogue(int t, bool allow_gelu, bool allow_scale = false) {
+    struct epilogue { int act = 0; int res = -1; int res2 = -1; int last = -1; int scale = -1; };
+    epilogue fuse_epilogue(int t, bool allow_gelu, bool allow_scale = false, bool allow_two = false) {
         epilogue e;
         e.last = t;
         int c = sole_consumer(t);
@@ -690,19 +732,21 @@ struct lowering {
             e.last = c;
             c = sole_consumer(c);
         }
-        if (c >= 0 && g.nodes[c].op == gop_add && e.act != 1) {
+        // up to two residual adds (dpt::residual_conv's skip, then feature_fusion's x0 + ..., depth-anything.cpp:15-33)
+        for (int round = 0; round < 2 && c >= 0 && g.nodes[c].op == gop_add && e.act != 1; ++round) {
             graph_node const& a = g.nodes[c];
             const int other = root(a.src[0]) == root(e.last) ? a.src[1] : a.src[0];
             graph_node const& o = g.nodes[other];
             bool same = !o.constant && o.dtype == gdt_f16 && root(other) != root(t) && root(other) < t; // already computed when this launch runs
             for (int i = 0; i < 4; ++i) same = same && o.ne[i] == g.nodes[t].ne[i];
-            if (same && g.nodes[root(other)].buffer >= 0) {
-                e.res = other;
-                skip[c] = 1;
-                g.nodes[c].alias_of = t;
-                if (g.nodes[c].is_output) g.nodes[t].is_output = true;
-                e.last = c;
-            }
+            if (!(same && g.nodes[root(other)].buffer >= 0)) break;
+            if (round == 1 && !allow_two) break;
+            (round == 0 ? e.res : e.res2) = other;
+            skip[c] = 1;
+            g.nodes[c].alias_of = t;
+            if (g.nodes[c].is_output) g.nodes[t].is_output = true;
+            e.last = c;
+            c = sole_consumer(c);
         }
         return e;
     }
@@ -757,6 +801,7 @@ struct lowering {
         const float* bias2 = const_f32(g.nodes[c2].src[2]);
         const float* w3 = const_f32(g.nodes[c3].src[1]);
         const float b3 = g.nodes[c3].n_src == 3 ? g.nodes[g.nodes[c3].src[2]].values()[0] : 0.0f;
+        if (g.nodes[c3].n_src == 3) (void)const_f32(g.nodes[c3].src[2]); // (a kernel argument by value; its image makes the scalar part of the model's arena)
         const int xbuf = buf_of(up.src[0]);
         for (int f : {t, c2, r1, r2}) skip[f] = 1;
         if (last != r2) skip[last] = 1;
@@ -773,6 +818,7 @@ struct lowering {
         snprintf(d, sizeof d, "head_tail[resize %dx%d -> %dx%d, conv3x3 32->32, relu, conv1x1 -> 1, relu%s] B=%d <- %s", ws, hs, W, H, scale != 1.0f ? ", scale" : "", B,
                  g.nodes[wt].name.c_str());
         emit(d, {xbuf}, {obuf}, [=](void* st) { VX(vx_headconv_bil_f16(xp(), frag, bias2, w3, b3, scale, reinterpret_cast<float*>(op()), B, H, W, hs, ws, st)); });
+        tag("head_conv2+3", 2.0 * B * H * W * 32.0 * (288 + 1), (double)B * ((double)hs * ws * 64 + (double)H * W * 4));
         return true;
     }
 
@@ -793,6 +839,7 @@ struct lowering {
         }
         const float* w = const_f32(n.src[1]);
         const float bias = n.n_src == 3 ? g.nodes[n.src[2]].values()[0] : 0.0f;
+        if (n.n_src == 3) (void)const_f32(n.src[2]);
         const int xbuf = buf_of(n.src[0]);
         materialise(t);
         const int obuf = n.buffer;
@@ -801,6 +848,65 @@ struct lowering {
         std::string who = n.name.empty() ? g.nodes[n.src[1]].name : n.name;
         emit(std::string("conv1x1_to_1") + (relu ? "[relu]" : "") + (scale != 1.0f ? "[scale]" : "") + " M=" + std::to_string(M) + " C=" + std::to_string(C) + " <- " + who, {xbuf}, {obuf},
              [=](void* st) { VX(vx_conv1x1_to1_f32(xp(), w, bias, relu, scale, reinterpret_cast<float*>(op()), M, C, st)); });
+        tag("head_out", 2.0 * M * C, (double)M * (C * 2 + 4));
+    }
+
+    // timing group of a matrix product from the weight's name (the groups the model entries and bench.py report)
+    static std::string group_of(std::string const& who, graph_node const& n, int stride) {
+        auto has = [&](const char* k) { return who.find(k) != std::string::npos; };
+        if (has("reassemble") && has("projection")) return "neck_proj";
+        if (has("reassemble") && has("resize")) return n.op == gop_conv_transpose_2d ? "neck_convT" : (stride > 1 ? "neck_conv_s2" : "neck_resize");
+        if (has("neck.convs")) return "neck_convs";
+        if (has("residual_layer")) return "fusion_rcu";
+        if (has("fusion_stage") && has("projection")) return "fusion_proj";
+        if (has("head.conv1")) return "head_conv1";
+        if (has("head.conv")) return "head_conv2+3";
+        return n.op == gop_linear ? "gemm" : "conv";
+    }
+
+    // ---- inputs that a consumer reads in place instead of through a copy / a resize launch (g.fused_models)
+    struct sliced_rows { int src; int64_t begin, rows, stride; };  // rows [begin, begin + rows) of every group of `stride` rows of src
+    std::map<int, sliced_rows> sliced_in;                           // slice node -> what its (sole, plain-GEMM) reader addresses directly
+    struct resized_map { int buf; int hs, ws; };                    // the bilinear (align_corners) resize of [.., ws, hs, B] in `buf`
+    std::map<int, resized_map> resized_in;                          // interpolate / projected node -> what its (sole) conv reader interpolates itself
+    std::map<int, int> row_stride;                                  // node -> elements between rows when its buffer is padded for a GEMM reader
+
+    int plain_gemm_reader(int t) const { // the sole reader of t (through single-reader views) if it reads t's rows as a plain GEMM A operand
+        int c = sole_consumer(t);
+        while (c >= 0 && (g.nodes[c].op == gop_reshape || g.nodes[c].op == gop_cont)) c = sole_consumer(c);
+        if (c < 0 || root_view(g.nodes[c].src[0]) != t) return -1;
+        graph_node const& n = g.nodes[c];
+        if (n.op == gop_linear || n.op == gop_conv_transpose_2d) return c;
+        if (n.op == gop_conv_2d && n.dtype == gdt_f16) {
+            graph_node const& w = g.nodes[n.src[1]];
+            if (w.ne[1] == 1 && w.ne[2] == 1 && n.ip[0] == 1 && n.ip[1] == 0) return c;
+        }
+        return -1;
+    }
+    int root_view(int v) const { // the node behind reshape / cont views (before aliases are assigned)
+        while (g.nodes[v].op == gop_reshape || g.nodes[v].op == gop_cont) v = g.nodes[v].src[0];
+        return v;
+    }
+    bool dconv_shape(graph_node const& n, graph_node const& x, graph_node const& w) const {
+        static const bool off = getenv("VISP_NO_DCONV") != nullptr;
+        return g.fused_models && !off && n.op == gop_conv_2d && n.dtype == gdt_f16 && w.ne[1] == 3 && w.ne[2] == 3 && n.ip[0] == 1 && n.ip[1] == 1 && x.ne[0] % 16 == 0 &&
+               (w.ne[3] == 32 || w.ne[3] == 64) && n.ne[1] >= 16;
+    }
+    // the LDS-ring conv's operand: slabs [cin pad 32 / 32][9 taps][cout][32] f16, 16-byte groups swizzled (kernels_dconv.hip)
+    void* pack_dconv(int wt, int cin, int cout, int* d_cin) {
+        const int dc = round_up(cin, 32);
+        *d_cin = dc;
+        return cached(wt, 6, [&](bool st) {
+            std::vector<uint16_t> h((size_t)dc * 9 * cout, 0);
+            const float* w = g.nodes[wt].values(); // [cout][ky][kx][cin]
+            for (int n = 0; n < cout; ++n)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int c = 0; c < cin; ++c) {
+                        const size_t row = ((size_t)(c / 32) * 9 + tap) * cout + n;
+                        h[row * 32 + (size_t)(((c % 32) / 8) ^ ((n >> 2) & 3)) * 8 + c % 8] = f32_to_f16(w[((size_t)n * 9 + tap) * cin + c]);
+                    }
+            return upload(h.data(), h.size() * 2, st);
+        });
     }
 
     void gemm_like(int t) {
@@ -809,6 +915,7 @@ struct lowering {
         const int xs = n.src[0], wt = n.src[1], bt = n.n_src == 3 ? n.src[2] : -1;
         graph_node const& x = g.nodes[xs];
         std::string who = n.name.empty() ? g.nodes[wt].name : n.name;
+        if (g.nodes[wt].op == gop_weight && !g.nodes[wt].name.empty()) who = g.nodes[wt].name; // groups are keyed on the weight's name
         vx_gemm_args a;
         memset(&a, 0, sizeof a);
         packed_operand p;
@@ -817,24 +924,39 @@ struct lowering {
         bool conv = false;
         epilogue e;
         e.last = t;
+        int stride = 1;
+        // the A rows of a plain product: in place from a sliced source, from a padded producer, or padded by a copy
+        auto plain_rows = [&](int K, int Kp) {
+            const int v = root_view(xs);
+            if (auto it = sliced_in.find(v); it != sliced_in.end()) {
+                a.a_group = (int)it->second.rows; a.a_group_stride = (int)it->second.stride; a.a_row_off = (int)it->second.begin;
+                a.lda = K;
+                kind += "[rows " + std::to_string(it->second.begin) + ".. of " + std::to_string(it->second.stride) + "]";
+                return buf_of(it->second.src);
+            }
+            if (auto it = row_stride.find(v); it != row_stride.end() && it->second == Kp) { a.lda = Kp; return buf_of(xs); }
+            a.lda = Kp;
+            return padded_rows(xs, K, Kp, a.M, who);
+        };
         if (n.op == gop_linear) {
             e = fuse_epilogue(t, true, true);
             p = pack_rows(wt, bt, (int)n.ne[0], e.scale);
             a.M = (int)(x.n_elements() / x.ne[0]);
-            xbuf = padded_rows(xs, p.k_real, p.K, a.M, who);
-            a.lda = p.K;
             kind = "gemm";
+            xbuf = plain_rows(p.k_real, p.K);
         } else if (n.op == gop_conv_2d) {
             graph_node const& w = g.nodes[wt];
-            p = pack_rows(wt, bt, (int)n.ne[0]);
-            const int kw = (int)w.ne[1], kh = (int)w.ne[2], stride = (int)n.ip[0], pad = (int)n.ip[1];
+            const int kw = (int)w.ne[1], kh = (int)w.ne[2], pad = (int)n.ip[1];
+            stride = (int)n.ip[0];
             a.M = (int)(n.ne[1] * n.ne[2] * n.ne[3]);
             if (kw == 1 && kh == 1 && stride == 1 && pad == 0) { // 1x1: a plain product on the pixel rows (nn.cpp:76-81)
-                xbuf = padded_rows(xs, p.k_real, p.K, a.M, who);
-                a.lda = p.K;
+                p = pack_rows(wt, bt, (int)n.ne[0]);
                 kind = "gemm(conv1x1)";
+                xbuf = plain_rows(p.k_real, p.K);
             } else {
                 if (x.ne[0] % 8) throw except("conv_2d %s: Cin = %lld must be a multiple of 8", who.c_str(), (long long)x.ne[0]);
+                if (dconv_shape(n, x, w)) return dconv(t, who);
+                p = pack_rows(wt, bt, (int)n.ne[0]);
                 xbuf = buf_of(xs);
                 a.conv_kh = kh; a.conv_kw = kw; a.conv_stride = stride; a.conv_pad = pad;
                 a.conv_H = (int)x.ne[2]; a.conv_W = (int)x.ne[1]; a.conv_Cin = (int)x.ne[0];
@@ -847,38 +969,167 @@ struct lowering {
             const int s = (int)n.ip[0];
             p = pack_conv_transpose(wt, bt, s);
             a.M = (int)(x.ne[1] * x.ne[2] * x.ne[3]);
-            xbuf = padded_rows(xs, p.k_real, p.K, a.M, who);
-            a.lda = p.K;
-            a.ps_s = s; a.ps_Cout = (int)n.ne[0]; a.ps_H = (int)x.ne[2]; a.ps_W = (int)x.ne[1];
             kind = "gemm+pixel_shuffle(s" + std::to_string(s) + ")";
+            xbuf = plain_rows(p.k_real, p.K);
+            a.ps_s = s; a.ps_Cout = (int)n.ne[0]; a.ps_H = (int)x.ne[2]; a.ps_W = (int)x.ne[1];
         }
         if (n.ne[0] % 8) throw except("%s %s: %lld output channels; the f16 epilogues store 8 at a time", graph_op_name(n.op), who.c_str(), (long long)n.ne[0]);
         a.W = p.w; a.bias = p.bias; a.N = p.N; a.K = p.K; a.n_valid = n.op == gop_conv_transpose_2d ? p.n_real : (int)n.ne[0];
         a.ldo = n.ne[0];
         if (n.op == gop_conv_transpose_2d) a.epi = VX_EPI_PIXSHUF;
         else {
-            if (n.op != gop_linear) e = fuse_epilogue(t, true);
+            if (n.op != gop_linear) e = fuse_epilogue(t, true, false, true);
             a.epi = e.res >= 0 ? VX_EPI_F16_ADD : (e.act == 1 ? VX_EPI_F16_GELU : (e.act == 2 ? VX_EPI_F16_RELU : VX_EPI_F16));
             a.relu = e.res >= 0 && e.act == 2;
         }
-        materialise(t);
+        // rows of a width that is no multiple of the GEMM's 64-wide k tile, read by one plain product only: written with the padded row
+        // stride that reader wants (the pad columns are exact zeros: zero weights, zero bias), no pad_rows copy in between
+        size_t out_bytes = n.n_bytes();
+        if (g.fused_models && a.epi == VX_EPI_F16 && n.op != gop_conv_transpose_2d && n.ne[0] % 64 != 0 && !n.is_output && p.N >= round_up((int)n.ne[0], 64) && plain_gemm_reader(t) >= 0) {
+            const int Kp = round_up((int)n.ne[0], 64);
+            row_stride[t] = Kp;
+            a.ldo = Kp;
+            a.n_valid = Kp;
+            out_bytes = (size_t)(n.n_elements() / n.ne[0]) * Kp * 2;
+        }
+        n.buffer = new_buffer(out_bytes, n.is_output || n.op == gop_input);
         const int obuf = n.buffer;
         std::vector<int> reads = {xbuf};
-        std::function<char*()> rp;
+        std::function<char*()> rp, rp2;
         if (e.res >= 0) { reads.push_back(buf_of(e.res)); rp = ptr(buf_of(e.res)); }
+        if (e.res2 >= 0) { reads.push_back(buf_of(e.res2)); rp2 = ptr(buf_of(e.res2)); }
         const bool halo = conv && a.conv_kh == 3 && a.conv_kw == 3 && a.conv_stride == 1 && a.conv_pad == 1 && a.conv_W >= 96;
-        char d[256];
-        snprintf(d, sizeof d, "%s%s%s%s%s%s M=%d N=%d K=%d <- %s", kind.c_str(), e.scale >= 0 ? "[*scale]" : "", e.act ? "[" : "", act_name(e.act), e.act ? "]" : "",
-                 e.res >= 0 ? "[+res]" : "", a.M, (int)n.ne[0], p.k_real, who.c_str());
+        char d[320];
+        snprintf(d, sizeof d, "%s%s%s%s%s%s%s M=%d N=%d K=%d <- %s", kind.c_str(), e.scale >= 0 ? "[*scale]" : "", e.act ? "[" : "", act_name(e.act), e.act ? "]" : "",
+                 e.res >= 0 ? "[+res]" : "", e.res2 >= 0 ? "[+res]" : "", a.M, (int)n.ne[0], p.k_real, who.c_str());
         auto xp = ptr(xbuf), op = ptr(obuf);
         emit(d, reads, {obuf}, [=](void* st) {
             vx_gemm_args r = a;
             r.A = xp();
             r.out = op();
             if (rp) r.res1 = rp();
+            if (rp2) r.res2 = rp2();
             if (halo && vx_conv3x3_supported(&r)) VX(vx_conv3x3_f16(&r, st));
             else VX(vx_gemm_f16(&r, st));
         });
+        tag(group_of(who, n, stride).c_str(), 2.0 * a.M * (double)p.n_real * p.k_real, (double)a.M * (p.k_real + n.ne[0]) * 2 + (double)p.N * p.K * 2);
+    }
+
+    // 3x3 / stride 1 / pad 1 with Cin % 16 == 0 and 32 or 64 output channels: the persistent LDS-ring conv (kernels_dconv.hip), with the
+    // ReLU of a relu -> conv chain applied to the fragments, ReLU or up to two residual maps in the epilogue, and -- where the input is the
+    // bilinear (align_corners) resize of a smaller map read by this conv only -- the resize done by the conv's halo loader
+    void dconv(int t, std::string const& who) {
+        graph_node& n = g.nodes[t];
+        const int xs = n.src[0], wt = n.src[1], bt = n.n_src == 3 ? n.src[2] : -1;
+        graph_node const& x = g.nodes[xs];
+        const int cin = (int)x.ne[0], cout = (int)n.ne[0], H = (int)n.ne[2], W = (int)n.ne[1], B = (int)n.ne[3];
+        epilogue e = fuse_epilogue(t, false, false, true);
+        if (e.act == 2 && e.res >= 0) throw except("graph: internal: relu between a conv and its residual add is not a dconv epilogue");
+        vx_dconv_args d;
+        memset(&d, 0, sizeof d);
+        int d_cin = 0;
+        d.w = pack_dconv(wt, cin, cout, &d_cin);
+        d.bias = bt >= 0 ? const_f32(bt) : nullptr;
+        d.cin = d_cin; d.cout = cout;
+        d.x_pix = cin; d.x_plane = 32;
+        d.B = B; d.H = H; d.W = W;
+        d.epi = VX_DC_F16;
+        d.act = e.act == 2 ? 2 : 0;
+        d.a_relu = relu_on_load[t];
+        d.s1 = d.s2 = 1.0f;
+        d.res1_pix = d.res2_pix = d.out_pix = cout;
+        d.res1_plane = d.res2_plane = d.out_plane = 32;
+        int xbuf;
+        std::string kind = "dconv3x3";
+        if (auto it = resized_in.find(xs); it != resized_in.end()) {
+            xbuf = it->second.buf;
+            d.bil_hs = it->second.hs; d.bil_ws = it->second.ws;
+            kind += "[resize " + std::to_string(it->second.ws) + "x" + std::to_string(it->second.hs) + " in the loader]";
+        } else xbuf = buf_of(xs);
+        if (d.a_relu) kind += "[relu-in]";
+        materialise(t);
+        const int obuf = n.buffer;
+        std::vector<int> reads = {xbuf};
+        std::function<char*()> rp, rp2;
+        if (e.res >= 0) { reads.push_back(buf_of(e.res)); rp = ptr(buf_of(e.res)); }
+        if (e.res2 >= 0) { reads.push_back(buf_of(e.res2)); rp2 = ptr(buf_of(e.res2)); }
+        char desc[320];
+        snprintf(desc, sizeof desc, "%s%s%s%s M=%d N=%d K=%d <- %s", kind.c_str(), e.act == 2 ? "[relu]" : "", e.res >= 0 ? "[+res]" : "", e.res2 >= 0 ? "[+res]" : "", B * H * W, cout,
+                 9 * cin, who.c_str());
+        auto xp = ptr(xbuf), op = ptr(obuf);
+        emit(desc, reads, {obuf}, [=](void* st) {
+            vx_dconv_args r = d;
+            r.x = xp();
+            r.out = op();
+            if (rp) r.res1 = rp();
+            if (rp2) r.res2 = rp2();
+            VX(vx_dconv3x3_f16(&r, st));
+        });
+        tag(group_of(who, n, 1).c_str(), 2.0 * B * H * W * (double)cout * 9 * cin, (double)B * H * W * (cin + cout) * 2);
+    }
+
+    // interpolate (bilinear, align_corners) read by ONE consumer:
+    //   * conv 1x1 (+ bias): the two commute (the bilinear weights of a pixel sum to one), so the projection runs on the small map -- a
+    //     quarter of the products and no full-resolution intermediate (depth-anything.cpp:36-40) -- and the resize follows;
+    //   * conv 3x3 with 32 output channels that the LDS-ring kernel can feed from the small map: no resize launch at all.
+    // Returns true when the node needs no launch of its own.
+    bool resize_into_reader(int t) {
+        if (!g.fused_models) return false;
+        graph_node const& up = g.nodes[t];
+        if ((up.ip[2] & 255) != 1 || !(up.ip[2] & 256) || up.is_output) return false;
+        const int c = sole_consumer(t);
+        if (c < 0 || g.nodes[c].op != gop_conv_2d || g.nodes[c].src[0] != t || g.nodes[c].dtype != gdt_f16) return false;
+        graph_node const& x = g.nodes[up.src[0]];
+        graph_node& cn = g.nodes[c];
+        graph_node const& w = g.nodes[cn.src[1]];
+        const int hs = (int)x.ne[2], ws = (int)x.ne[1], H = (int)up.ne[2], W = (int)up.ne[1], B = (int)x.ne[3];
+        static const bool no_bil = getenv("VISP_NO_BIL_FUSE") != nullptr;
+        auto loader_can = [&](graph_node const& conv, graph_node const& cw, int cin) {
+            return !no_bil && dconv_shape(conv, g.nodes[conv.src[0]], cw) && cw.ne[3] == 32 && cin % 32 == 0 && !relu_on_load[&conv - g.nodes.data()] &&
+                   vx_dconv_bilinear_supported(32, H, W, hs, ws);
+        };
+        if (w.ne[1] == 3 && w.ne[2] == 3) {
+            if (!loader_can(cn, w, (int)x.ne[0])) return false;
+            resized_in[t] = {buf_of(up.src[0]), hs, ws};
+            return true;
+        }
+        if (!(w.ne[1] == 1 && w.ne[2] == 1 && cn.ip[0] == 1 && cn.ip[1] == 0) || cn.ne[0] % 8 || x.ne[0] % 64) return false;
+        // the projection on the small map
+        const int bt = cn.n_src == 3 ? cn.src[2] : -1, cout = (int)cn.ne[0];
+        packed_operand p = pack_rows(cn.src[1], bt, cout);
+        const int64_t M = (int64_t)B * hs * ws;
+        const int sbuf = new_buffer((size_t)M * cout * 2);
+        const int xbuf = buf_of(up.src[0]);
+        vx_gemm_args a;
+        memset(&a, 0, sizeof a);
+        a.lda = p.K; a.W = p.w; a.bias = p.bias; a.M = (int)M; a.N = p.N; a.K = p.K; a.n_valid = cout; a.ldo = cout; a.epi = VX_EPI_F16;
+        auto xp = ptr(xbuf), sp = ptr(sbuf);
+        std::string who = g.nodes[cn.src[1]].name;
+        emit("gemm(conv1x1 before its resize) M=" + std::to_string(M) + " N=" + std::to_string(cout) + " K=" + std::to_string(p.k_real) + " <- " + who, {xbuf}, {sbuf}, [=](void* st) {
+            vx_gemm_args r = a;
+            r.A = xp(); r.out = sp();
+            VX(vx_gemm_f16(&r, st));
+        });
+        tag(group_of(who, cn, 1).c_str(), 2.0 * M * (double)cout * p.k_real, (double)M * (p.k_real + cout) * 2);
+        skip[t] = 1;
+        skip[c] = 1;
+        // ... and its resize: by the next conv's loader where that is the only reader, else by the resize kernel into the conv node's buffer
+        const int c2 = cn.is_output ? -1 : sole_consumer(c);
+        if (c2 >= 0 && g.nodes[c2].op == gop_conv_2d && g.nodes[c2].src[0] == c) {
+            graph_node const& w2 = g.nodes[g.nodes[c2].src[1]];
+            if (w2.ne[1] == 3 && w2.ne[2] == 3 && loader_can(g.nodes[c2], w2, cout)) {
+                resized_in[c] = {sbuf, hs, ws};
+                return true;
+            }
+        }
+        materialise(c);
+        const int obuf = cn.buffer;
+        auto op = ptr(obuf);
+        char d[128];
+        snprintf(d, sizeof d, "bilinear_ac %dx%d -> %dx%d C=%d", ws, hs, W, H, cout);
+        emit(d, {sbuf}, {obuf}, [=](void* st) { VX(vx_bilinear_ac_f16(sp(), op(), B, hs, ws, cout, H, W, st)); });
+        tag("bilinear", 0, (double)B * ((double)hs * ws + (double)H * W) * cout * 2);
+        return true;
     }
 
     void patch_embed(int t) {
@@ -966,6 +1217,7 @@ struct lowering {
             r.A = xp(); r.q = qp(); r.k = kp(); r.vt = vp();
             VX(vx_gemm_f16(&r, st));
         });
+        tag("gemm_qkv", 2.0 * a.M * (double)p.N * p.k_real, (double)a.M * (p.k_real + p.N) * 2);
         qkv_bufs[att] = hb;
     }
 
@@ -995,6 +1247,333 @@ struct lowering {
         char d[128];
         snprintf(d, sizeof d, "attention B=%lld heads=%lld T=%lld", (long long)B, (long long)H, (long long)Tq);
         emit(d, {hb[0], hb[1], hb[2]}, {obuf}, [=](void* st) { VX(vx_attention_f16(qp(), kp(), vp(), op(), (int)B, (int)H, (int)Tq, st)); });
+        tag("attention", 4.0 * B * H * (double)Tq * Tq * 64, (double)B * H * Tq * 64 * 2 * 4);
+    }
+
+
+    // ---- fused model group 1: the DINOv2 encoder (dino.cpp:10-110) -----------------------------------------------------------------------
+    // prepare_tokens (patch_embed -> reshape -> concat with the cls constant -> + position constant) followed by a chain of dino::layer
+    // groups  x -> LN1 -> q|k|v -> attention -> out-proj * lambda1 + x -> LN2 -> fc1 -> gelu -> fc2 * lambda2 + x1 [-> final LN taps]
+    // at the block kernel's widths (384 / 1536 / heads of 64) lowers to what csrc/kernels_block16.hip was written for: the residual stream
+    // as ONE f32 buffer, per layer one attention launch and one token-stationary block launch (out-proj .. fc2 of layer i, the taps' final
+    // LayerNorm, LN1 + QKV of layer i + 1), the first layer's LN1 + QKV as the kernel's QKV-only instance. Every interior node must be
+    // read inside the group only; the token tensor and the layer outputs may be graph outputs (they are copied out of the stream as f32).
+    struct enc_layer {
+        int ln1 = -1, lin[3] = {-1, -1, -1}, att = -1, o = -1, s1 = -1, x1 = -1, ln2 = -1, f1 = -1, ge = -1, f2 = -1, s2 = -1, x2 = -1;
+        int lam1 = -1, lam2 = -1;
+        std::vector<int> taps;
+    };
+    struct enc_chain {
+        bool ok = false;
+        int img = -1, u8 = -1, pe = -1, resh = -1, cat = -1, tok = -1, cls = -1, pos = -1, first = -1;
+        std::vector<int> views;
+        std::vector<enc_layer> layers;
+    } enc;
+
+    int through_views(int v, std::vector<int>* seen = nullptr) const { // the producer behind single-reader reshape / cont views
+        while (g.nodes[v].op == gop_reshape || g.nodes[v].op == gop_cont) {
+            if (uses[v] != 1 || g.nodes[v].is_output) return -1;
+            if (seen) seen->push_back(v);
+            v = g.nodes[v].src[0];
+        }
+        return v;
+    }
+    bool match_layer(int att, enc_layer& L) const {
+        auto it = qkv_lin.find(att);
+        if (it == qkv_lin.end()) return false;
+        for (int i = 0; i < 3; ++i) L.lin[i] = it->second[i];
+        L.att = att;
+        L.ln1 = g.nodes[L.lin[0]].src[0];
+        graph_node const& ln1 = g.nodes[L.ln1];
+        if (ln1.op != gop_layer_norm || uses[L.ln1] != 3 || ln1.is_output || ln1.ne[0] != 384) return false;
+        if (g.nodes[att].ne[0] != 384 || g.nodes[att].is_output) return false;
+        auto sole = [&](int t, int op) { const int c = sole_consumer(t); return c >= 0 && g.nodes[c].op == op ? c : -1; };
+        auto scaled = [&](int t, int& lam) { // mul by a 384-element constant behind t
+            const int c = sole(t, gop_mul);
+            if (c < 0 || root(g.nodes[c].src[0]) != t || !g.nodes[g.nodes[c].src[1]].constant || g.nodes[g.nodes[c].src[1]].n_elements() != 384) return -1;
+            lam = g.nodes[c].src[1];
+            return c;
+        };
+        auto residual = [&](int t, int x) { // add(x, t), either order
+            const int c = sole(t, gop_add);
+            if (c < 0) return -1;
+            const int a = g.nodes[c].src[0], b = g.nodes[c].src[1];
+            return ((a == x && b == t) || (a == t && b == x)) ? c : -1;
+        };
+        const int x = ln1.src[0];
+        if ((L.o = sole(att, gop_linear)) < 0 || g.nodes[L.o].src[0] != att || g.nodes[L.o].ne[0] != 384) return false;
+        if ((L.s1 = scaled(L.o, L.lam1)) < 0 || (L.x1 = residual(L.s1, x)) < 0) return false;
+        if (uses[L.x1] != 2 || g.nodes[L.x1].is_output) return false;
+        for (int c : consumers[L.x1])
+            if (g.nodes[c].op == gop_layer_norm && g.nodes[c].src[0] == L.x1) L.ln2 = c;
+        if (L.ln2 < 0 || g.nodes[L.ln2].is_output || g.nodes[L.ln2].fp[0] != ln1.fp[0]) return false;
+        if ((L.f1 = sole(L.ln2, gop_linear)) < 0 || g.nodes[L.f1].ne[0] != 1536 || (L.ge = sole(L.f1, gop_gelu)) < 0) return false;
+        if ((L.f2 = sole(L.ge, gop_linear)) < 0 || g.nodes[L.f2].ne[0] != 384) return false;
+        if ((L.s2 = scaled(L.f2, L.lam2)) < 0 || (L.x2 = residual(L.s2, L.x1)) < 0) return false;
+        for (int t : {L.o, L.s1, L.f1, L.ge, L.f2, L.s2})
+            if (g.nodes[t].is_output) return false;
+        return true;
+    }
+    void find_encoder_chain() {
+        if (!g.fused_models || !vx_dino_block_supported(384, 1536, 64)) return;
+        std::vector<enc_layer> found;
+        for (auto const& kv : qkv_lin) { // std::map: attention nodes in node order = layer order
+            enc_layer L;
+            if (match_layer(kv.first, L)) found.push_back(L);
+        }
+        if (found.empty()) return;
+        // a chain: layer l + 1 normalises what layer l produced; x2's other readers are the final-LayerNorm taps
+        std::vector<enc_layer> chain;
+        for (auto& L : found) {
+            const int x = g.nodes[L.ln1].src[0];
+            if (!chain.empty() && x != chain.back().x2) return; // two encoders / a branch: not this pattern
+            chain.push_back(L);
+        }
+        for (size_t l = 0; l < chain.size(); ++l) {
+            enc_layer& L = chain[l];
+            int known = 0;
+            for (int c : consumers[L.x2]) {
+                if (l + 1 < chain.size() && (c == chain[l + 1].ln1 || c == chain[l + 1].x1)) { ++known; continue; }
+                if (g.nodes[c].op == gop_layer_norm && g.nodes[c].src[0] == L.x2) { L.taps.push_back(c); ++known; continue; }
+                return;
+            }
+            if (known != uses[L.x2]) return;
+        }
+        int tap_w = -1, tap_b = -1;
+        float eps = g.nodes[chain[0].ln1].fp[0];
+        for (auto& L : chain) {
+            if (g.nodes[L.ln1].fp[0] != eps) return;
+            for (int t : L.taps) {
+                if (tap_w < 0) { tap_w = g.nodes[t].src[1]; tap_b = g.nodes[t].src[2]; }
+                if (g.nodes[t].src[1] != tap_w || g.nodes[t].src[2] != tap_b || g.nodes[t].fp[0] != eps) return; // one shared final LayerNorm
+            }
+        }
+        // prepare_tokens in front of the first layer
+        enc_chain e;
+        e.tok = g.nodes[chain[0].ln1].src[0];
+        graph_node const& tok = g.nodes[e.tok];
+        if (tok.op != gop_add || uses[e.tok] != 2 || !g.nodes[tok.src[1]].constant) return;
+        e.pos = tok.src[1];
+        e.cat = tok.src[0];
+        graph_node const& cat = g.nodes[e.cat];
+        const int64_t D = tok.ne[0], T = tok.ne[1], B = tok.ne[2];
+        if (cat.op != gop_concat || cat.ip[0] != 1 || sole_consumer(e.cat) != e.tok || g.nodes[e.pos].n_elements() != D * T || tok.ne[3] != 1) return;
+        if (!g.nodes[cat.src[0]].constant || g.nodes[cat.src[0]].ne[1] != 1) return;
+        e.cls = cat.src[0];
+        if (sole_consumer(cat.src[1]) != e.cat) return;
+        e.pe = through_views(cat.src[1], &e.views);
+        if (e.pe < 0 || g.nodes[e.pe].op != gop_patch_embed || uses[e.pe] != 1 || g.nodes[e.pe].is_output) return;
+        graph_node const& pe = g.nodes[e.pe];
+        if (pe.ne[0] != D || pe.ne[1] * pe.ne[2] + 1 != T || pe.ne[3] != B) return;
+        e.img = pe.src[0];
+        if (g.nodes[e.img].op == gop_image_u8_to_f32 && sole_consumer(e.img) == e.pe) { e.u8 = g.nodes[e.img].src[0]; }
+        e.layers = std::move(chain);
+        e.first = e.u8 >= 0 ? e.img : e.pe;
+        e.ok = true;
+        enc = std::move(e);
+        for (auto const& L : enc.layers) qkv_first.erase(std::min({L.lin[0], L.lin[1], L.lin[2]})); // these attentions are not lowered one by one
+    }
+
+    float* vec_cached(int key_node, int role, std::string const& with, std::function<std::vector<float>()> make_host) {
+        return static_cast<float*>(cached(key_node, role, [&](bool st) { std::vector<float> v = make_host(); return upload(v.data(), v.size() * 4, st); }, with));
+    }
+    const float* values_or_null(int t) const { return t >= 0 ? g.nodes[t].values() : nullptr; }
+    static void put(std::vector<float>& v, const float* src, size_t n) { // n floats (zeros if the tensor is absent)
+        if (src) v.insert(v.end(), src, src + n); else v.insert(v.end(), n, 0.0f);
+    }
+    std::string wname(int t) const { return t >= 0 ? (g.nodes[t].op == gop_weight && !g.nodes[t].name.empty() ? g.nodes[t].name : "#" + std::to_string(t)) : std::string("-"); }
+
+    void emit_encoder() {
+        enc_chain const& e = enc;
+        graph_node const& tok = g.nodes[e.tok];
+        graph_node const& pe = g.nodes[e.pe];
+        const int D = 384, HID = 1536, NH = 6;
+        const int T = (int)tok.ne[1], B = (int)tok.ne[2], Pn = T - 1;
+        const long M = (long)B * T, MP = (long)B * Pn;
+        const int ps = (int)pe.ip[0], Wimg = (int)g.nodes[e.img].ne[1], Himg = (int)g.nodes[e.img].ne[2];
+        const float eps = g.nodes[enc.layers[0].ln1].fp[0];
+        auto bias_of = [&](int lin) { return g.nodes[lin].n_src == 3 ? g.nodes[lin].src[2] : -1; };
+        std::vector<int> all = {e.pe, e.cat, e.tok};
+        if (e.u8 >= 0) all.push_back(e.img);
+        all.insert(all.end(), e.views.begin(), e.views.end());
+
+        // ---- tokens: patches (u8 -> f16 with the normalisation folded in, or from the f32 image), cls rows, patch GEMM whose epilogue adds
+        // bias + position embedding and writes f32 token rows
+        packed_operand p = pack_rows(pe.src[1], pe.n_src == 3 ? pe.src[2] : -1, D);
+        const int Kp = p.K;
+        const int pbuf = new_buffer((size_t)MP * Kp * 2), xbuf = new_buffer((size_t)M * D * 4);
+        auto pp = ptr(pbuf), xp = ptr(xbuf);
+        if (e.u8 >= 0) {
+            const int ibuf = buf_of(e.u8);
+            auto ip = ptr(ibuf);
+            graph_node const& im = g.nodes[e.img];
+            std::array<float, 3> mean{im.fp[0], im.fp[1], im.fp[2]}, istd{im.fp[3], im.fp[4], im.fp[5]};
+            emit("preprocess_patches " + std::to_string(ps) + "x" + std::to_string(ps) + " M=" + std::to_string(MP), {ibuf}, {pbuf}, [=](void* st) {
+                VX(vx_preprocess_patches(reinterpret_cast<const uint8_t*>(ip()), pp(), B, Himg, Wimg, ps, Kp, mean.data(), istd.data(), st));
+            });
+            tag("preprocess", 0, (double)B * Himg * Wimg * 3 + (double)MP * Kp * 2);
+        } else {
+            const int ibuf = buf_of(e.img);
+            auto ip = ptr(ibuf);
+            const int C = (int)g.nodes[e.img].ne[0];
+            emit("im2col_patches " + std::to_string(ps) + "x" + std::to_string(ps) + " M=" + std::to_string(MP), {ibuf}, {pbuf},
+                 [=](void* st) { VX(vx_im2col_patches_f32(reinterpret_cast<const float*>(ip()), pp(), B, Himg, Wimg, C, ps, Kp, st)); });
+            tag("preprocess", 0, (double)B * Himg * Wimg * C * 4 + (double)MP * Kp * 2);
+        }
+        const float* cls = const_f32(e.cls);
+        const float* pos = const_f32(e.pos);
+        emit("cls_rows B=" + std::to_string(B), {}, {xbuf}, [=](void* st) { VX(vx_write_cls_rows(reinterpret_cast<float*>(xp()), cls, pos, B, T, D, st)); });
+        tag("preprocess");
+        {
+            vx_gemm_args a;
+            memset(&a, 0, sizeof a);
+            a.lda = Kp; a.W = p.w; a.bias = p.bias; a.M = (int)MP; a.N = p.N; a.K = p.K; a.n_valid = D;
+            a.epi = VX_EPI_TOKENS; a.ldo = D; a.pos = pos; a.tokens_P = Pn;
+            emit("gemm[tokens f32: + bias + pos] M=" + std::to_string(MP) + " N=384 K=" + std::to_string(p.k_real) + " <- " + g.nodes[pe.src[1]].name, {pbuf}, {xbuf}, [=](void* st) {
+                vx_gemm_args r = a;
+                r.A = pp(); r.out = xp();
+                VX(vx_gemm_f16(&r, st));
+            });
+            tag("patch_embed", 2.0 * MP * D * p.k_real, (double)MP * Kp * 2 + (double)M * D * 4);
+        }
+        auto copy_out = [&](int node, const char* what) { // a graph output inside the group: the residual stream as it stands, f32
+            graph_node& n = g.nodes[node];
+            n.dtype = gdt_f32;
+            materialise(node);
+            const int ob = n.buffer;
+            auto op = ptr(ob);
+            const size_t bytes = (size_t)M * D * 4;
+            emit(std::string("copy_f32 ") + what, {xbuf}, {ob}, [=](void* st) { VX(vx_memcpy_d2d(op(), xp(), bytes, st)); });
+            tag("capture");
+        };
+        if (tok.is_output) copy_out(e.tok, "tokens");
+
+        // ---- per layer: attention + one block launch
+        const int qb = new_buffer((size_t)M * D * 2), kb = new_buffer((size_t)M * D * 2), vb = new_buffer((size_t)M * D * 2), ab = new_buffer((size_t)M * D * 2);
+        auto qp = ptr(qb), kp = ptr(kb), vp = ptr(vb), ap = ptr(ab);
+        const float q_scale = g.nodes[enc.layers[0].att].fp[0] * 1.4426950408889634f; // the attention kernel works in the exp2 domain
+        auto pack_mlp = [&](enc_layer const& L) -> void* {
+            const int wo = g.nodes[L.o].src[1], w1 = g.nodes[L.f1].src[1], w2 = g.nodes[L.f2].src[1];
+            return cached(wo, 40, [&](bool st) {
+                // LayerScale folded into the two residual products (W' = f16(lambda[n] * W[n, :])): the residual stream stays in the accumulators
+                std::vector<uint16_t> a((size_t)D * D), b((size_t)HID * D), c((size_t)D * HID), out(vx_dino_block_mlp_bytes() / 2);
+                const float *ho = g.nodes[wo].values(), *h1 = g.nodes[w1].values(), *h2 = g.nodes[w2].values(), *l1 = g.nodes[L.lam1].values(), *l2 = g.nodes[L.lam2].values();
+                for (int n = 0; n < D; ++n) {
+                    for (int k = 0; k < D; ++k) a[(size_t)n * D + k] = f32_to_f16(f16_to_f32(f32_to_f16(ho[(size_t)n * D + k])) * l1[n]);
+                    for (int k = 0; k < HID; ++k) c[(size_t)n * HID + k] = f32_to_f16(f16_to_f32(f32_to_f16(h2[(size_t)n * HID + k])) * l2[n]);
+                }
+                for (size_t i = 0; i < b.size(); ++i) b[i] = f32_to_f16(h1[i]);
+                VX(vx_dino_block16_pack_mlp(a.data(), b.data(), c.data(), out.data()));
+                return upload(out.data(), out.size() * 2, st);
+            }, wname(w1) + "|" + wname(w2) + "|*" + wname(L.lam1) + "|*" + wname(L.lam2));
+        };
+        auto pack_qkv_block = [&](enc_layer const& L) -> void* {
+            return cached(g.nodes[L.lin[0]].src[1], 41, [&](bool st) {
+                std::vector<uint16_t> rows((size_t)3 * D * D), out(vx_dino_block_qkv_bytes() / 2);
+                for (int i = 0; i < 3; ++i) {
+                    const float* h = g.nodes[g.nodes[L.lin[i]].src[1]].values();
+                    for (size_t j = 0; j < (size_t)D * D; ++j) rows[(size_t)i * D * D + j] = f32_to_f16(h[j]);
+                }
+                VX(vx_dino_block16_pack_qkv(rows.data(), out.data()));
+                return upload(out.data(), out.size() * 2, st);
+            }, wname(g.nodes[L.lin[1]].src[1]) + "|" + wname(g.nodes[L.lin[2]].src[1]));
+        };
+        auto vec_mlp = [&](enc_layer const& L) {
+            const int bo = bias_of(L.o), b1 = bias_of(L.f1), b2 = bias_of(L.f2);
+            return vec_cached(g.nodes[L.o].src[1], 42, wname(bo) + "|" + wname(b1) + "|" + wname(b2) + "|" + wname(g.nodes[L.ln2].src[1]) + "|*" + wname(L.lam1) + "|*" + wname(L.lam2), [&]() {
+                std::vector<float> v;
+                const float *l1 = g.nodes[L.lam1].values(), *l2 = g.nodes[L.lam2].values();
+                put(v, values_or_null(bo), D);
+                for (int n = 0; n < D; ++n) v[n] *= l1[n];
+                put(v, l1, D);
+                put(v, g.nodes[g.nodes[L.ln2].src[1]].values(), D);
+                put(v, g.nodes[g.nodes[L.ln2].src[2]].values(), D);
+                put(v, values_or_null(b1), HID);
+                const size_t at = v.size();
+                put(v, values_or_null(b2), D);
+                for (int n = 0; n < D; ++n) v[at + n] *= l2[n];
+                put(v, l2, D);
+                return v;
+            });
+        };
+        auto vec_qkv = [&](enc_layer const& L) {
+            return vec_cached(g.nodes[L.ln1].src[1], 43, wname(g.nodes[L.ln1].src[2]) + "|" + wname(bias_of(L.lin[0])) + "|" + wname(bias_of(L.lin[1])) + "|" + wname(bias_of(L.lin[2])), [&]() {
+                std::vector<float> v;
+                put(v, g.nodes[g.nodes[L.ln1].src[1]].values(), D);
+                put(v, g.nodes[g.nodes[L.ln1].src[2]].values(), D);
+                for (int i = 0; i < 3; ++i) put(v, values_or_null(bias_of(L.lin[i])), D);
+                return v;
+            });
+        };
+        float* vec_tap = nullptr;
+        for (auto const& L : enc.layers)
+            if (!L.taps.empty() && !vec_tap) {
+                const int t = L.taps[0];
+                vec_tap = vec_cached(g.nodes[t].src[1], 44, wname(g.nodes[t].src[2]), [&]() {
+                    std::vector<float> v;
+                    put(v, g.nodes[g.nodes[t].src[1]].values(), D);
+                    put(v, g.nodes[g.nodes[t].src[2]].values(), D);
+                    return v;
+                });
+            }
+        auto block = [&](const enc_layer* mlp, const enc_layer* qkv, int feat_buf, const char* group, std::string const& who) {
+            vx_dino_block_args a;
+            memset(&a, 0, sizeof a);
+            a.M = (int)M; a.T = T; a.H = NH; a.q_scale = q_scale; a.eps = eps;
+            double flops = 0, bytes = (double)M * D * 4;
+            std::vector<int> reads = {xbuf}, writes = {xbuf};
+            if (mlp) {
+                a.w_mlp = pack_mlp(*mlp); a.vec_mlp = vec_mlp(*mlp);
+                flops += 2.0 * M * D * (D + 2.0 * HID);
+                bytes += (double)M * D * (2 + 4);
+                reads.push_back(ab);
+            }
+            if (qkv) {
+                a.w_qkv = pack_qkv_block(*qkv); a.vec_qkv = vec_qkv(*qkv);
+                flops += 2.0 * M * D * 3.0 * D;
+                bytes += (double)M * D * 2 * 3;
+                writes.insert(writes.end(), {qb, kb, vb});
+            }
+            std::function<char*()> fp;
+            if (feat_buf >= 0) { a.vec_tap = vec_tap; fp = ptr(feat_buf); bytes += (double)M * D * 2; writes.push_back(feat_buf); }
+            const bool has_mlp = mlp != nullptr, has_qkv = qkv != nullptr;
+            emit(std::string("dino_block[") + (has_mlp ? "out-proj + mlp" : "") + (feat_buf >= 0 ? " + tap" : "") + (has_qkv ? (has_mlp ? " + next ln1 + qkv" : "ln1 + qkv") : "") + "] M=" + std::to_string(M) + " <- " + who,
+                 reads, writes, [=](void* st) {
+                     vx_dino_block_args r = a;
+                     r.x = reinterpret_cast<float*>(xp());
+                     if (has_mlp) r.att = ap();
+                     if (has_qkv) { r.q = qp(); r.k = kp(); r.v = vp(); }
+                     if (fp) r.feat = fp();
+                     VX(vx_dino_block16_f16(&r, st));
+                 });
+            tag(group, flops, bytes);
+        };
+        block(nullptr, &enc.layers[0], -1, "block_qkv0", g.nodes[g.nodes[enc.layers[0].lin[0]].src[1]].name);
+        for (size_t l = 0; l < enc.layers.size(); ++l) {
+            enc_layer const& L = enc.layers[l];
+            emit("attention B=" + std::to_string(B) + " heads=" + std::to_string(NH) + " T=" + std::to_string(T), {qb, kb, vb}, {ab},
+                 [=](void* st) { VX(vx_attention_f16(qp(), kp(), vp(), ap(), B, NH, T, st)); });
+            tag("attention", 4.0 * B * NH * (double)T * T * 64, (double)M * D * 2 * 4);
+            int feat = -1;
+            for (int t : L.taps) {
+                materialise(t);
+                if (feat < 0) feat = g.nodes[t].buffer;
+            }
+            block(&L, l + 1 < enc.layers.size() ? &enc.layers[l + 1] : nullptr, feat, "block", g.nodes[g.nodes[L.o].src[1]].name);
+            for (size_t i = 1; i < L.taps.size(); ++i) { // further taps that name this layer: the same rows
+                const int ob = g.nodes[L.taps[i]].buffer;
+                auto fp = ptr(feat), op = ptr(ob);
+                const size_t bytes = (size_t)M * D * 2;
+                emit("copy tap", {feat}, {ob}, [=](void* st) { VX(vx_memcpy_d2d(op(), fp(), bytes, st)); });
+                tag("block");
+            }
+            if (g.nodes[L.x2].is_output) copy_out(L.x2, "layer output");
+            for (int t : {L.ln1, L.lin[0], L.lin[1], L.lin[2], L.att, L.o, L.s1, L.x1, L.ln2, L.f1, L.ge, L.f2, L.s2, L.x2}) all.push_back(t);
+            for (int i = 0; i < 3; ++i)
+                for (int v = g.nodes[L.att].src[i]; v != L.lin[i]; v = g.nodes[v].src[0]) all.push_back(v);
+            for (int t : L.taps) all.push_back(t);
+        }
+        for (int t : all) skip[t] = 1;
     }
 
     void copy_op(int t) {
@@ -1068,8 +1647,10 @@ struct lowering {
             }
         }
         find_qkv_groups();
+        find_encoder_chain();
         for (int t = 0; t < N; ++t) {
             graph_node& n = g.nodes[t];
+            if (enc.ok && t == enc.first) emit_encoder();
             if (auto it = qkv_first.find(t); it != qkv_first.end() && !skip[t]) fused_qkv(it->second);
             if (!needed[t] || skip[t]) continue;
             if (n.constant) {
@@ -1146,9 +1727,11 @@ struct lowering {
                     const float eps = n.fp[0];
                     emit("layer_norm rows=" + std::to_string(rows) + " C=" + std::to_string(C) + (who.empty() ? "" : " <- " + who), {xbuf}, {obuf},
                          [=](void* st) { VX(vx_layernorm_f16(xp(), w, b, op(), rows, C, eps, 0, 0, 0, st)); });
+                    tag("layernorm", 0, (double)rows * C * 4);
                 } break;
                 case gop_interpolate: {
                     if (!n.is_output && head_tail(t)) break;
+                    if (resize_into_reader(t)) break;
                     graph_node const& x = g.nodes[n.src[0]];
                     if ((n.ip[2] & 255) != 1 || !(n.ip[2] & 256)) throw except("interpolate: mode %lld on activations is not built (bilinear | align_corners is; bicubic on constants)", (long long)n.ip[2]);
                     if (x.ne[0] % 8) throw except("interpolate: %lld channels (a multiple of 8)", (long long)x.ne[0]);
@@ -1160,9 +1743,46 @@ struct lowering {
                     char d[128];
                     snprintf(d, sizeof d, "bilinear_ac %dx%d -> %dx%d C=%d", W, H, OW, OH, C);
                     emit(d, {xbuf}, {obuf}, [=](void* st) { VX(vx_bilinear_ac_f16(xp(), op(), B, H, W, C, OH, OW, st)); });
+                    tag("bilinear", 0, (double)B * ((double)H * W + (double)OH * OW) * C * 2);
                 } break;
-                case gop_concat:
+                case gop_image_u8_to_f32: { // not read by a fused patch embedding: the f32 image itself
+                    graph_node const& x = g.nodes[n.src[0]];
+                    const int xbuf = buf_of(n.src[0]);
+                    materialise(t);
+                    const int obuf = n.buffer;
+                    auto xp = ptr(xbuf), op = ptr(obuf);
+                    const int B = (int)x.ne[3], H = (int)x.ne[2], W = (int)x.ne[1];
+                    std::array<float, 3> mean{n.fp[0], n.fp[1], n.fp[2]}, istd{n.fp[3], n.fp[4], n.fp[5]};
+                    emit("image_u8_to_f32 " + shape_str(x.ne), {xbuf}, {obuf},
+                         [=](void* st) { VX(vx_preprocess_f32(reinterpret_cast<const uint8_t*>(xp()), reinterpret_cast<float*>(op()), B, H, W, mean.data(), istd.data(), st)); });
+                    tag("preprocess", 0, (double)B * H * W * 15);
+                } break;
+                case gop_image_normalize: {
+                    graph_node const& x = g.nodes[n.src[0]];
+                    const int xbuf = buf_of(n.src[0]);
+                    materialise(t);
+                    const int obuf = n.buffer, mbuf = new_buffer((size_t)x.ne[3] * 8);
+                    auto xp = ptr(xbuf), op = ptr(obuf), mp = ptr(mbuf);
+                    const int B = (int)x.ne[3];
+                    const int64_t px = x.ne[1] * x.ne[2];
+                    emit("image_normalize B=" + std::to_string(B), {xbuf}, {obuf, mbuf}, [=](void* st) {
+                        VX(vx_minmax_normalize(reinterpret_cast<const float*>(xp()), reinterpret_cast<float*>(op()), reinterpret_cast<float*>(mp()), B, px, st));
+                    });
+                    tag("normalize", 0, (double)B * px * 12);
+                } break;
                 case gop_slice:
+                    // rows [b, e) of every image's token block, read by one plain product only (dpt::neck drops the cls token, depth-anything.cpp:50):
+                    // the GEMM's A rows are addressed in the source, no copy
+                    if (g.fused_models && !n.is_output && plain_gemm_reader(t) >= 0 && n.ip[0] == 0 && n.ne[0] == g.nodes[n.src[0]].ne[0] && n.ne[0] % 64 == 0 && n.ip[5] == 1 &&
+                        n.ne[2] == g.nodes[n.src[0]].ne[2] && n.ip[6] == 0 && n.ne[3] == g.nodes[n.src[0]].ne[3] && n.ip[9] == 0 && g.nodes[n.src[0]].ne[3] == 1 &&
+                        row_stride.find(root_view(n.src[0])) == row_stride.end()) {
+                        sliced_in[t] = {n.src[0], n.ip[3], n.ne[1], g.nodes[n.src[0]].ne[1]};
+                        n.alias_of = n.src[0];
+                        break;
+                    }
+                    copy_op(t);
+                    break;
+                case gop_concat:
                 case gop_repeat: copy_op(t); break;
                 default: throw except("graph_allocate: %s is not lowered", graph_op_name(n.op));
             }
@@ -1324,6 +1944,24 @@ void graph_tensor_get(graph& g, int t, void* data, size_t bytes, bool as_f32) {
     VX(vx_stream_sync(g.dev->stream));
     float* out = static_cast<float*>(data);
     for (size_t i = 0; i < h.size(); ++i) out[i] = f16_to_f32(h[i]);
+}
+
+void graph_bind_external(graph& g, int t, void* ptr) {
+    if (!g.allocated) throw except("graph_bind_external: call compute_graph_allocate first");
+    check_tensor(g, t, "graph_bind_external");
+    int r = t;
+    while (g.nodes[r].alias_of >= 0) r = g.nodes[r].alias_of;
+    graph_node const& n = g.nodes[r];
+    if (n.buffer < 0 || !g.buffers[n.buffer].persistent) throw except("graph_bind_external: tensor %d is not an input or output of the graph", t);
+    g.buffers[n.buffer].external = ptr;
+}
+void* graph_tensor_device_ptr(graph& g, int t) {
+    require_device(g, "graph_tensor_device_ptr");
+    char* p = tensor_ptr(g, t, "graph_tensor_device_ptr");
+    int r = t;
+    while (g.nodes[r].alias_of >= 0) r = g.nodes[r].alias_of;
+    graph_buffer const& b = g.buffers[g.nodes[r].buffer];
+    return b.external ? b.external : p;
 }
 
 std::string graph_describe(graph const& g) {

@@ -48,11 +48,14 @@ enum graph_op : int32_t {
     gop_repeat,           // x; i0..i3 = ne (source dims 1 or equal)   dino.cpp:38-40
     gop_patch_embed,      // x f32 [C, W, H, N], w conv weight, (b); i0 = patch size            nn.cpp:166-180
     gop_cont,             // a view: every tensor of this executor is contiguous
+    // extensions for callers that keep images in HBM (the batched entries of this library); the reference does both steps on the host
+    gop_image_u8_to_f32,  // x u8 [3, W, H, N] -> f32: (x / 255 - f0..f2) * f3..f5     image.cpp:215-255 as depthany_process_input calls it
+    gop_image_normalize,  // x f32 [1, W, H, N] -> f32: per-image min-max to [0, 1]     image.cpp:537-582 (depthany_process_output)
     gop_count
 };
 const char* graph_op_name(int32_t op);
 
-constexpr int32_t gdt_f32 = 0, gdt_f16 = 1; // ggml type ids
+constexpr int32_t gdt_f32 = 0, gdt_f16 = 1, gdt_u8 = 24; // ggml type ids (24 = I8: one byte per element; image inputs)
 
 struct graph_node {
     int32_t op = gop_input;
@@ -61,7 +64,7 @@ struct graph_node {
     int src[4] = {-1, -1, -1, -1};
     int n_src = 0;
     int64_t ip[12] = {0};
-    float fp[2] = {0, 0};
+    float fp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::string name;
     bool is_output = false;
     bool constant = false;        // a weight, or computed from weights alone: evaluated on the host when the node is made
@@ -72,18 +75,21 @@ struct graph_node {
     int alias_of = -1;            // shares the buffer of that node (views, fused activations)
     int buffer = -1;              // index into graph::buffers (materialised nodes)
     int64_t n_elements() const { return ne[0] * ne[1] * ne[2] * ne[3]; }
-    size_t n_bytes() const { return (size_t)n_elements() * (dtype == gdt_f16 ? 2 : 4); }
+    size_t n_bytes() const { return (size_t)n_elements() * (dtype == gdt_f16 ? 2 : (dtype == gdt_u8 ? 1 : 4)); }
 };
 
 struct graph_buffer {
     size_t bytes = 0, offset = 0;
     int first = 0, last = 0; // launch indices of the first writer and the last reader
     bool persistent = false; // inputs and outputs
+    void* external = nullptr; // graph_bind_external: an input / output that lives in the caller's memory instead of the arena
 };
 
 struct graph_launch {
     std::string desc; // e.g. "gemm[gelu] M=43840 N=1536 K=384 <- layer0.mlp.fc1": what tests and `describe` show
     std::function<void(void* stream)> run;
+    std::string group; // timing group (per-group HIP-event times of the model entries: "block", "attention", "fusion_rcu", ...)
+    double flops = 0, bytes = 0; // algorithmic work of the launch (2 x MACs; operand bytes), for the roofline lines
 };
 
 // model_weights (ml.h:126-149): the tensors of a model by name, f32 on the host, and -- once a graph over them has been allocated on a
@@ -100,6 +106,12 @@ struct weight_store {
     std::map<std::pair<std::string, int>, void*> packs;     // (name, role) -> device image
     std::vector<void*> allocs;
     size_t device_bytes = 0;
+    // One device arena for every image (optional; depthany's loader sizes it from a planning pass): images are then bump-allocated in
+    // lowering order, which is the same on every rank -- the arena IS the model on the device, one RCCL broadcast moves it. no_data: the
+    // tensors came from a header-only read (zeros on the host): images are laid out but not uploaded (the broadcast fills them).
+    device_buffer arena;
+    size_t arena_used = 0;
+    bool no_data = false;
     std::mutex mutex;                                       // guards dev / packs / allocs / device_bytes
     ~weight_store();
 };
@@ -120,11 +132,16 @@ struct graph {
     std::vector<graph_buffer> buffers;
     std::vector<graph_launch> launches;
     size_t arena_bytes = 0, sum_bytes = 0; // with recycling / if every buffer had its own storage
+    size_t plan_store_bytes = 0;           // planning only (no device): bytes of weight images this graph would add to the shared store
     device_buffer arena;
     std::vector<void*> const_allocs;       // packed weights and constants (device)
     size_t const_bytes = 0;
     bool use_hip_graph = false;
     void* graph_exec = nullptr;
+    // fused_models: the lowering may replace whole node groups by the kernels written for them (the dino::layer group -> attention + one
+    // token-stationary block launch with an f32 residual stream, interpolate -> conv 3x3 -> the resizing halo loader, ...). false: one
+    // launch per (epilogue-fused) node on f16 activations -- what visp_depthany_set_schedule(model, 0) selects.
+    bool fused_models = true;
     ~graph();
 };
 
@@ -140,6 +157,10 @@ void graph_allocate(graph&, backend_device const* dev); // dev == null: lower an
 void graph_compute(graph&);
 void graph_tensor_set(graph&, int t, const void* data, size_t bytes);            // the tensor's own dtype
 void graph_tensor_get(graph&, int t, void* data, size_t bytes, bool as_f32);     // as_f32: converted on the host
+// an input or output tensor lives at `ptr` (device memory of the caller, at least the tensor's size) instead of in the graph's arena;
+// may be called again with another pointer between computes (not while a captured hipGraph of this graph is in use)
+void graph_bind_external(graph&, int t, void* ptr);
+void* graph_tensor_device_ptr(graph&, int t);                                    // where an input / output tensor lives
 std::string graph_describe(graph const&); // one line per launch, then the arena summary
 
 } // namespace visp

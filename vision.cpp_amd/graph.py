@@ -18,9 +18,9 @@ import numpy as np
 from . import _lib as lib
 from ._lib import check, get_lib
 
-F32, F16 = 0, 1
+F32, F16, U8 = 0, 1, 24
 (OP_LINEAR, OP_LAYER_NORM, OP_GELU, OP_RELU, OP_SCALE, OP_ADD, OP_MUL, OP_CONV_2D, OP_CONV_TRANSPOSE_2D, OP_INTERPOLATE, OP_ATTENTION,
- OP_CONCAT, OP_SLICE, OP_RESHAPE, OP_REPEAT, OP_PATCH_EMBED, OP_CONT) = range(2, 19)
+ OP_CONCAT, OP_SLICE, OP_RESHAPE, OP_REPEAT, OP_PATCH_EMBED, OP_CONT, OP_IMAGE_U8_TO_F32, OP_IMAGE_NORMALIZE) = range(2, 21)
 SCALE_MODE_BILINEAR, SCALE_MODE_BICUBIC, SCALE_FLAG_ALIGN_CORNERS = 1, 2, 256  # ggml's values (ml.cpp:782-788)
 SLICE_ALL = (0, 2**62, 1)
 
@@ -145,6 +145,11 @@ class Graph:
         return out
 
     # ---- execution
+    def set_fused_models(self, enable: bool):
+        """Before allocate(). True (default): the lowering may map whole node groups onto the kernels written for them; False: one launch per
+        epilogue-fused node on f16 activations."""
+        check(self._api.visp_graph_set_fused_models(self._handle, int(enable)))
+
     def allocate(self):
         check(self._api.visp_graph_allocate(self._handle, self._device._handle if self._device is not None else None))
 
