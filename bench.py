@@ -294,7 +294,7 @@ def main():
             "config": {"workload": "Depth-Anything-V2-Small f16 (DINOv2-S ViT) 518x518 batch=32 per MI355X (BASELINE.json configs[1])",
                        "images_per_gpu_per_step": B, "global_batch": world * B, "weights": "random-init synthetic GGUF (seed 0)",
                        "parallelism": f"dp{world} (image shards, no data-path collective)", "hip_graph": not args.no_graph,
-                       "encoder_schedule": "gemm launches" if args.schedule == 0 else "attention + token-stationary block kernel per layer, 3 sub-batches on parallel streams"},
+                       "encoder_schedule": "graph executor: one launch per epilogue-fused node (GEMM launches)" if args.schedule == 0 else "graph executor: node groups lowered onto attention + token-stationary block kernel per layer, LDS-ring convs, head kernel; 3 sub-batch graphs on parallel streams"},
             "value_soak": soak,
             "value_incl_h2d_d2h": incl,
             "model_tflops": round(value * GFLOP_PER_IMAGE / 1e3, 2),
@@ -317,7 +317,7 @@ def main():
                                    "avg_launch_ms": round(per_launch_ms, 4), "launches_per_step": dom["launches"]}
             # HBM traffic and MFMA-busy % per launch of that kernel from the PMC passes (rocprofv3 --pmc, one counter set per
             # pass, on tools/bench_block.py --pmc = the same launch shapes; units and corrections in tools/pmc_summary.py)
-            pmc = next((q for q in (ROOT / "profiles" / d / "traffic.json" for d in ("r03_pmc", "r02_pmc", "r01_pmc")) if q.exists()), ROOT / "profiles" / "none")
+            pmc = next((q for q in (ROOT / "profiles" / d / "traffic.json" for d in ("r04_pmc", "r03_pmc", "r02_pmc", "r01_pmc")) if q.exists()), ROOT / "profiles" / "none")
             if pmc.exists():
                 ks = json.loads(pmc.read_text())["kernels"]
                 # one entry per launch shape ("block@343wg"): this object describes the unsplit batch-32 launch (the timing pass runs

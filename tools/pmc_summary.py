@@ -2,12 +2,11 @@
 """Turns the rocprofv3 --pmc passes of tools/profile_round.sh (one counter set per pass, kernel trace only, target
 tools/bench_block.py --pmc: the north-star launch shapes B = 32, T = 1370, D = 384) into per-kernel figures per launch:
 
-  * HBM traffic = FETCH_SIZE + WRITE_SIZE. Both counters are in KiB (MI355X_MICROARCH.md, HBM section). On gfx950
-    FETCH_SIZE tallies a 128-byte read request as 64 bytes, so it is DOUBLED for kernels whose reads are wide coalesced
-    streams (attention: K/V/Q tiles by 16 B per lane, 1 KiB per wave instruction). The block kernel reads its token rows
-    as 32-byte segments of 32 different rows per wave instruction (a lane owns a token column); its requests are not
-    128-byte ones and the raw counter already equals the algorithmic bytes: the QKV-only instance reads x once
-    (32 x 1370 x 384 x 4 = 67.3 MB) and FETCH_SIZE reports 67.5 MB. WRITE_SIZE is exact.
+  * HBM traffic = FETCH_SIZE + WRITE_SIZE. Both counters are in KiB (MI355X_MICROARCH.md, HBM section). On gfx950 FETCH_SIZE tallies a 128-byte
+    read request as 64 bytes, so it is DOUBLED. Round 4 settled this for the block kernel too (round 3 left it un-doubled because the raw
+    counter happened to sit near the row bytes): TCC_EA0_RDREQ_32B = 0 and TCC_EA0_RDREQ x 128 B = the residual / attention rows + eight
+    first-touch copies of the 3.4 MB weight stream (one per XCD L2) at 118, 247 and 343 workgroups (profiles/r04_pmc_block_l2/): every fabric
+    read of these kernels is a 128-byte request -- the LDS-DMA weight stream and the 16-byte-per-lane row loads alike. WRITE_SIZE is exact.
   * MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs). SQ_VALU_MFMA_BUSY_CYCLES counts 32
     per v_mfma_f32_32x32x16_f16 summed over the chip (block kernel: 151.7 M = 32 x 4.74 M MFMAs = 155.1 GFLOP / 32768);
     GRBM_GUI_ACTIVE is summed over the 8 XCDs.
@@ -20,8 +19,8 @@ from collections import defaultdict
 from pathlib import Path
 
 GROUPS = {"dino_block16_kernel<true, true": "block", "dino_block16_kernel<false, true": "block_qkv0",
-          "dino_block_kernel<true, true": "block", "dino_block_kernel<false, true": "block_qkv0", "attention_kernel": "attention"}
-FETCH_X2 = {"attention": True, "block": False, "block_qkv0": False}
+          "attention_kernel": "attention"}
+FETCH_X2 = {"attention": True, "block": True, "block_qkv0": True}
 
 
 def collect(path):

@@ -436,10 +436,15 @@ void depthany_weights_ready(depthany_model& m) {
     weight_store& ws = *m.store;
     for (const char* name : {"backbone.embeddings.position_embeddings", "backbone.embeddings.cls_token", "head.conv3.bias"}) {
         auto t = ws.tensors.find(name);
-        auto p = ws.packs.find({name, 0});
         if (t == ws.tensors.end()) throw except("depthany: tensor %s is missing", name);
-        if (p == ws.packs.end()) throw except("depthany: the arena holds no f32 image of %s", name);
-        VX(vx_memcpy_d2h(t->second.data.data(), p->second, t->second.data.size() * 4, m.backend->stream));
+        std::vector<float>& host = t->second.data;
+        if (auto p = ws.packs.find({name, 0}); p != ws.packs.end()) { // its f32 image
+            VX(vx_memcpy_d2h(host.data(), p->second, host.size() * 4, m.backend->stream));
+        } else if (auto q = ws.packs.find({name, 1}); q != ws.packs.end()) { // its f16 image (what the per-node lowering concatenates into the tokens)
+            std::vector<uint16_t> h(host.size());
+            VX(vx_memcpy_d2h(h.data(), q->second, h.size() * 2, m.backend->stream));
+            for (size_t i = 0; i < h.size(); ++i) host[i] = f16_to_f32(h[i]);
+        } else throw except("depthany: the arena holds no image of %s", name);
     }
     ws.no_data = true; // (stays: every other image this rank has is the one in the arena)
     m.weights_uploaded = true;

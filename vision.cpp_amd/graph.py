@@ -161,7 +161,7 @@ class Graph:
 
     def set(self, t: Tensor, array: np.ndarray):
         dtype, ne, _ = self.info(t)
-        a = np.ascontiguousarray(array, dtype=np.float32 if dtype == F32 else np.float16)
+        a = np.ascontiguousarray(array, dtype={F32: np.float32, U8: np.uint8}.get(dtype, np.float16))
         if a.size != int(np.prod(ne)):
             raise ValueError(f"tensor {t} takes {int(np.prod(ne))} elements, got {a.size}")
         check(self._api.visp_graph_tensor_set(self._handle, t.index, a.ctypes.data_as(c_void_p), a.nbytes))
