@@ -387,3 +387,44 @@ def test_image_scale_upsample_against_an_independent_f64_evaluation():
         da = np.abs(gota[..., 3] - np.rint(np.clip(a_out[..., 0], 0, 1) * 255.0))
         dc = np.abs(gota[..., :3] - np.rint(col))[a_out[..., 0] > 0.05]
         assert da.max() <= 1 and dc.max() <= 2 and dc.mean() < 0.06, (da.max(), dc.max(), dc.mean())
+
+
+def test_model_file_surface_and_null_pointers(tmp_path):
+    """visp_file_* = the reference's model_file (ml.h:85-103, ml.cpp:206-254): key/values by name, i32 only for get_int, exact-length i32 arrays,
+    a missing key named in the error; and the graph entries report a null out pointer instead of writing through it."""
+    import ctypes as C
+
+    api = L.get_lib()
+    path = synth.write_gguf(tmp_path / "m.gguf", synth.MINI, seed=1)
+    f = C.c_void_p()
+    L.check(api.visp_file_load(L.path_to_char_p(path), C.byref(f)))
+    n, v = C.c_int64(), C.c_int32()
+    L.check(api.visp_file_n_tensors(f, C.byref(n)))
+    assert n.value > 100
+    L.check(api.visp_file_get_int(f, b"dino.embed_dim", C.byref(v)))
+    assert v.value == synth.MINI.embed_dim
+    arr = (C.c_int32 * 4)()
+    L.check(api.visp_file_get_int_array(f, b"depthanything.feature_layers", arr, 4))
+    assert list(arr) == list(synth.MINI.feature_layers)
+    need = C.c_int64()
+    L.check(api.visp_file_get_string(f, b"general.architecture", None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    L.check(api.visp_file_get_string(f, b"general.architecture", buf, need.value, None))
+    assert buf.value == b"depthanything"
+    assert api.visp_file_get_int(f, b"dino.no_such_key", C.byref(v)) == 0 and b"dino.no_such_key" in api.visp_get_last_error()
+    assert api.visp_file_get_int_array(f, b"depthanything.feature_layers", arr, 3) == 0  # wrong length
+    assert api.visp_file_get_int(None, b"x", C.byref(v)) == 0 and b"null" in api.visp_get_last_error()
+    w = C.c_void_p()
+    L.check(api.visp_weights_from_file(f, C.byref(w)))
+    g = C.c_void_p()
+    L.check(api.visp_graph_create(w, C.byref(g)))
+    for call in (lambda: api.visp_graph_find_weight(g, b"head.conv1.weight", None), lambda: api.visp_graph_get_tensor(g, b"x", None),
+                 lambda: api.visp_graph_input(g, 0, (C.c_int64 * 4)(3, 14, 14, 1), b"in", None),
+                 lambda: api.visp_graph_op(g, 5, (C.c_int32 * 1)(0), 1, None, 0, None, 0, None)):
+        assert call() == 0 and b"null" in api.visp_get_last_error()
+    idx = C.c_int32()
+    L.check(api.visp_graph_find_weight(g, b"head.conv1.weight", C.byref(idx)))
+    assert api.visp_graph_read_constant(g, idx.value, None, 1 << 30) == 0 and b"null" in api.visp_get_last_error()
+    api.visp_graph_destroy(g)
+    api.visp_weights_destroy(w)
+    api.visp_file_destroy(f)

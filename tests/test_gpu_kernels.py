@@ -254,6 +254,35 @@ def test_attention_lagging_reference_fast_path_and_its_fallback():
         api().vx_attention_set_fast_limit(-1.0)
 
 
+def test_attention_row_sum_of_a_peaked_row():
+    """The softmax denominator of a peaked row: one key scores ~9 log2 units above 1369 others (a real checkpoint's cls / register-like
+    rows). The tile row sums are packed-f16 add trees (VISP_ATTN_RS = 1), accumulated in f32: the small P's must not be swallowed next to
+    the large one. V marks the peak key in channel 0 and the small keys in channel 1, so the output IS the two softmax masses; both the
+    fast path and the forced full path are held to 1.5e-3 of the f64 softmax (the f16 output rounding alone is 5e-4)."""
+    rng = np.random.default_rng(41)
+    T, peak = 1370, 777
+    q = _h(_rand(rng, 1, T, 64) * 0.05)
+    k = _h(_rand(rng, 1, T, 64) * 0.05)
+    q[0, :, 0], k[0, :, 0] = 4.0, 0.0
+    k[0, peak, 0] = 9.0 / LOG2E / (4.0 * 0.125)       # + 9 in the exp2 domain for every query
+    q, k = _h(q), _h(k)
+    v = np.zeros((1, T, 64), np.float32)
+    v[0, :, 1] = 1.0
+    v[0, peak, 0], v[0, peak, 1] = 1.0, 0.0
+    s = (q[0].astype(np.float64) @ k[0].astype(np.float64).T) * 0.125
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    want = p @ v[0].astype(np.float64)
+    assert 0.15 < want[:, 0].mean() < 0.45            # the peak holds a fraction, the 1369 small keys the rest
+    try:
+        for limit in (-1.0, 0.0):
+            api().vx_attention_set_fast_limit(limit)
+            got = _attn(q[0], k[0], v[0], T)
+            assert np.abs(got[:, :2] - want[:, :2]).max() < 1.5e-3, limit
+    finally:
+        api().vx_attention_set_fast_limit(-1.0)
+
+
 def test_attention_reference_point_follows_a_slowly_rising_maximum():
     """Scores that climb by ~3 (exp2 domain) per 64-key tile: no single tile trips the limit at once, the lag accumulates until
     one does; and a row whose scores keep FALLING after the first tile (P shrinks to f16 subnormals against the stale
