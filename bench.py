@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=10.0, help="soak: after the K timed steps keep stepping for this long and report that rate too (0 = skip)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the upload + compute + download (host pipeline) figure")
     ap.add_argument("--schedule", type=int, default=-1, help="depthany encoder schedule: -1 = the library's default (block kernel), 0 = GEMM launches, 1 = token-stationary block kernel")
+    ap.add_argument("--fp8", action="store_true", help="sam workload only, opt-in: the transformer stages' MLPs on the e4m3 matrix instruction (BASELINE.json configs[4]); reports the embedding error next to the rate")
     ap.add_argument("--cpu-images", type=int, default=32, help="bounded CPU-baseline sample (about 10 s at 16 threads)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (one GPU's share of the host)")
     ap.add_argument("--profile-groups", action="store_true", help="print the per-kernel-group table to stderr")
@@ -533,6 +534,15 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
     def step():
         model.sam_encode_batch_device(src.data_ptr(), B, out.data_ptr(), stream)
 
+    fp8_err = None
+    if args.fp8:  # opt-in (configs[4] "fp8 GGUF weights on CDNA4 fp8 MFMA"): the stage MLPs on the e4m3 matrix instruction; the f16 result first, for the error
+        step()
+        torch.cuda.synchronize()
+        ref = out[:8].clone()
+        model.sam_set_fp8_mlp(True)
+        step()
+        torch.cuda.synchronize()
+        fp8_err = float((out[:8] - ref).abs().mean() / ref.abs().mean())
     groups = []
     if rank == 0:
         step()
@@ -578,14 +588,18 @@ def run_sam(args, torch, dist, rank, world, device_index, barrier, api):
         "step_ms_device": {"mean": round(float(np.mean(step_ms)), 3), "std": round(float(np.std(step_ms)), 3), "min": round(float(np.min(step_ms)), 3),
                            "note": "rank 0, HIP events at the step boundaries of the same timed region"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic",
+        "dtype": "f16 (stage MLPs e4m3)" if args.fp8 else "f16", "data": "synthetic",
         "config": {"workload": f"MobileSAM TinyViT encoder 1024x1024 f16, batch={B} per MI355X (BASELINE.json configs[4] names fp8 weights and a "
-                               "1k-image batch over 8 GPUs: this row is the f16 encoder, image shards per rank)",
+                               "1k-image batch over 8 GPUs: this row is the f16 encoder, image shards per rank)" + (
+                                   " -- with --fp8: the transformer stages' MLPs on the block-scaled e4m3 matrix instruction (opt-in, never the default)" if args.fp8 else ""),
                    "images_per_gpu_per_step": B, "global_batch": world * B, "weights": "random-init synthetic GGUF (seed 3)",
                    "parallelism": f"dp{world} (image shards, no data-path collective)"},
         "model_gflop_per_image": round(gflop, 2) if gflop else None,
         "model_tflops": round(value * gflop / 1e3, 2) if gflop else None,
     }
+    if fp8_err is not None:
+        res["fp8_mlp"] = {"embedding_mean_abs_diff_over_mean_abs_vs_f16": round(fp8_err, 4),
+                          "note": "e4m3 weights per output channel + e4m3 activations per token in fc1 / fc2 of every transformer block; tests/test_fp8_decision.py: mask IoU below the bar"}
     if groups:
         tot = sum(g["ms"] for g in groups)
         # the profile is flat (no group above 12 %): the roofline object describes the step's longest single launch among the

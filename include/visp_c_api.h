@@ -199,6 +199,10 @@ VISP_API int32_t visp_sam_read_masks(visp_model* m, float* masks, int64_t capaci
  * stream = hipStream_t or NULL (NULL: the device's stream, synchronised before returning) */
 VISP_API int32_t visp_sam_encode_batch_device(visp_model* m, void const* rgb, int32_t batch, void* out, void* stream);
 VISP_API int32_t visp_sam_encode_batch_host(visp_model* m, uint8_t const* rgb, int32_t batch, float* out);
+/* opt-in, never the default (BASELINE.json configs[4]: "fp8 GGUF weights on CDNA4 fp8 MFMA"; the reference has no fp8 type): the MLPs of the transformer
+ * stages run on the block-scaled e4m3 matrix instruction -- weights quantised per output channel (on first use, from the f16 weights), activations per
+ * token. Changes the embedding by several percent of its scale (tests/test_fp8_decision.py, tests/test_gpu_tinyvit.py): a measurement, not a recommendation. */
+VISP_API int32_t visp_sam_set_fp8_mlp(visp_model* m, int32_t enable);
 VISP_API int32_t visp_sam_weights_arena(visp_model* m, void** device_ptr, size_t* n_bytes);
 VISP_API int32_t visp_sam_weights_ready(visp_model* m);
 /* test hook as for depth_anything: "patch_embed", "layer_0" .. "layer_3" = the stage outputs of the last batch, f16 -> f32 */

@@ -300,6 +300,27 @@ VX_API int vx_dino_block16_pack_mlp(const void* wo, const void* w1, const void* 
 VX_API int vx_dino_block16_pack_qkv(const void* wqkv, void* out);
 VX_API int vx_dino_block16_f16(const vx_dino_block_args* args, void* stream);
 
+/* ---- e4m3 GEMM on the block-scaled matrix instruction (kernels_gemm_fp8.hip), opt-in: BASELINE.json configs[4] "fp8 GGUF weights on CDNA4 fp8 MFMA".
+ * The reference has no fp8 tensor type; the format is this backend's own: OCP e4m3 values + ONE f32 scale per row (per output channel of a weight,
+ * per token of an activation), K padded to a multiple of 128 with zeros:
+ *   out f16 [M, ldo] = act( a_scale[m] * w_scale[n] * sum_k A8[m, k] * W8[n, k] + bias[n] ) [+ res]   (linear + bias [+ GELU] [+ residual], nn.cpp:6-12, mobile-sam.cpp MLP);
+ * n_valid and ldo multiples of 8 */
+typedef struct {
+    const void* A; const float* a_scale; /* e4m3 [M][Kp], f32 [M] (vx_quantize_rows_e4m3) */
+    const void* W; const float* w_scale; /* e4m3 [N][Kp], f32 [N] (vx_quantize_rows_e4m3_host), N % 128 == 0 */
+    const float* bias;                   /* f32 [N] or NULL */
+    int M, N, Kp, n_valid;               /* columns >= n_valid are not stored */
+    void* out; int64_t ldo;
+    int act;                             /* 0 none, 1 tanh-GELU */
+    const void* res;                     /* f16 [M, ldo] added to the result, or NULL (the MLP's residual, mobile-sam.cpp:150-160) */
+} vx_gemm_fp8_args;
+VX_API int vx_gemm_fp8_supported(int N, int K);
+VX_API int vx_gemm_fp8(const vx_gemm_fp8_args* args, void* stream);
+/* f16 rows [M][ldx] (first K columns) -> e4m3 rows [M][Kp] + scale[m] = absmax / 448 (device) */
+VX_API int vx_quantize_rows_e4m3(const void* x_f16, int64_t ldx, void* q, float* scale, int M, int K, int Kp, void* stream);
+/* host code: f32 rows [N][K] -> e4m3 [N][Kp] (round to nearest even, saturating at 448) + scale[n] */
+VX_API int vx_quantize_rows_e4m3_host(const float* w, int N, int K, int Kp, void* q_out, float* scale_out);
+
 /* ---- LayerNorm (nn.cpp:14-19): x f32 [M,C] -> y f16 [M,C]; biased variance, eps in sqrt --- */
 VX_API int vx_layernorm_f32_f16(const float* x, const float* w, const float* b, void* y, int M, int C,
                                 float eps, void* stream);

@@ -260,6 +260,29 @@ def test_encoder_batch_16(sam):
     assert np.array_equal(m.sam_encode_batch(imgs[5:6])[0], got[5])
 
 
+def test_encoder_fp8_mlp_is_opt_in_and_costs_what_the_oracle_said(sam):
+    """BASELINE.json configs[4] names "fp8 GGUF weights on CDNA4 fp8 MFMA". visp_sam_set_fp8_mlp(model, 1) runs the transformer stages' MLPs on the
+    block-scaled e4m3 matrix instruction (weights per output channel, activations per token). The embedding then differs from the f16 path by
+    percents of its scale -- the order the CPU what-if measured (tests/test_fp8_decision.py: 7-8 % with e4m3 weights AND activations in all four
+    GEMMs; here only the MLP pair is quantised) -- while the f16 path is untouched: off again, the results are bit-identical to before."""
+    from visioncpp_amd import synth
+    m = sam["model"]
+    imgs = synth.images(2, 1024, 1024, seed=77)
+    base = m.sam_encode_batch(imgs)
+    m.sam_set_fp8_mlp(True)
+    try:
+        got = m.sam_encode_batch(imgs)
+        again = m.sam_encode_batch(imgs)
+    finally:
+        m.sam_set_fp8_mlp(False)
+    assert np.isfinite(got).all() and np.array_equal(got, again)
+    scale = float(np.abs(base).mean())
+    err = float(np.abs(got - base).mean()) / scale
+    print(f"e4m3 MLPs: mean |embedding - f16 embedding| = {err * 100:.2f} % of the mean magnitude")
+    assert 0.003 < err < 0.12  # present and bounded: quantisation noise, not a wrong product
+    assert np.array_equal(m.sam_encode_batch(imgs), base)
+
+
 def test_encoder_batch_128_properties(sam):
     """BASELINE.json configs[4]'s per-GPU share (a 1k-image batch over 8 GPUs = 128 images of 1024 x 1024 per step, the bench's
     batch): size-independent properties -- finite, duplicated images give duplicated embeddings, any image alone gives the same

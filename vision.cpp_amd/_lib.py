@@ -70,6 +70,11 @@ class GemmArgs(ctypes.Structure):  # == vx_gemm_args
     ]
 
 
+class GemmFp8Args(ctypes.Structure):  # == vx_gemm_fp8_args
+    _fields_ = [("A", c_void_p), ("a_scale", c_void_p), ("W", c_void_p), ("w_scale", c_void_p), ("bias", c_void_p), ("M", c_int), ("N", c_int), ("Kp", c_int),
+                ("n_valid", c_int), ("out", c_void_p), ("ldo", c_int64), ("act", c_int), ("res", c_void_p)]
+
+
 class DinoBlockArgs(ctypes.Structure):  # == vx_dino_block_args
     _fields_ = [
         ("att", c_void_p), ("x", c_void_p), ("w_mlp", c_void_p), ("vec_mlp", c_void_p), ("w_qkv", c_void_p), ("vec_qkv", c_void_p),
@@ -100,7 +105,7 @@ C_API_SYMBOLS = [
     "visp_esrgan_tile_layout", "visp_esrgan_compute_batch_device", "visp_esrgan_compute_batch_host",
     "visp_esrgan_generate_host", "visp_esrgan_enable_timing", "visp_esrgan_read_timing",
     "visp_sam_encode", "visp_sam_read_embedding", "visp_sam_encode_batch_device", "visp_sam_encode_batch_host",
-    "visp_sam_weights_arena", "visp_sam_weights_ready", "visp_sam_enable_timing", "visp_sam_read_timing",
+    "visp_sam_set_fp8_mlp", "visp_sam_weights_arena", "visp_sam_weights_ready", "visp_sam_enable_timing", "visp_sam_read_timing",
     "visp_sam_enable_captures", "visp_sam_read_capture", "visp_sam_compute", "visp_sam_read_masks", "visp_image_scale", "visp_image_u8_to_f32", "visp_image_normalize", "visp_gguf_validate",
     "visp_birefnet_image_extent", "visp_birefnet_compute_batch_device", "visp_birefnet_compute_batch_host",
     "visp_swin_load", "visp_swin_output_dims", "visp_swin_encode_batch_device", "visp_swin_encode_batch_host", "visp_swin_enable_captures",
@@ -115,7 +120,7 @@ KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
     "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_malloc_host", "vx_free_host", "vx_memcpy_h2d_async", "vx_memcpy_d2h_async", "vx_event_sync", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
     "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_stream_wait_event", "vx_graph_begin_capture",
-    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_gemm_pick_k_splits", "vx_conv3x3_supported", "vx_conv3x3_f16",
+    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_gemm_pick_k_splits", "vx_gemm_fp8_supported", "vx_gemm_fp8", "vx_quantize_rows_e4m3", "vx_quantize_rows_e4m3_host", "vx_conv3x3_supported", "vx_conv3x3_f16",
     "vx_attention_f16", "vx_attention_set_fast_limit", "vx_attention_set_stamps",
     "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",
@@ -202,6 +207,7 @@ def init() -> ctypes.CDLL:
     lib.visp_sam_encode_batch_device.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
     lib.visp_sam_encode_batch_host.argtypes = [c_void_p, c_void_p, c_int32, c_void_p]
     lib.visp_sam_weights_arena.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]
+    lib.visp_sam_set_fp8_mlp.argtypes = [c_void_p, c_int32]
     lib.visp_sam_weights_ready.argtypes = [c_void_p]
     lib.visp_sam_compute.argtypes = [c_void_p, POINTER(c_int32), c_int32, POINTER(ImageView), POINTER(c_void_p)]
     lib.visp_sam_read_masks.argtypes = [c_void_p, c_void_p, c_int64, POINTER(ctypes.c_float)]
@@ -283,6 +289,10 @@ def init() -> ctypes.CDLL:
     lib.vx_graph_launch.argtypes = [c_void_p, c_void_p]
     lib.vx_graph_destroy.argtypes = [c_void_p]
     lib.vx_gemm_f16.argtypes = [POINTER(GemmArgs), c_void_p]
+    lib.vx_gemm_fp8_supported.argtypes = [c_int, c_int]
+    lib.vx_gemm_fp8.argtypes = [POINTER(GemmFp8Args), c_void_p]
+    lib.vx_quantize_rows_e4m3.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.vx_quantize_rows_e4m3_host.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.vx_gemm_pick_k_splits.argtypes = [c_int, c_int, c_int]
     lib.vx_conv3x3_supported.argtypes = [POINTER(GemmArgs)]
     lib.vx_conv3x3_f16.argtypes = [POINTER(GemmArgs), c_void_p]

@@ -605,6 +605,10 @@ int32_t visp_sam_encode_batch_host(visp_model* m, uint8_t const* rgb, int32_t ba
     return handle_errors([&]() { sam_encode_batch_host(as_sam(m), rgb, batch, out); });
 }
 
+int32_t visp_sam_set_fp8_mlp(visp_model* m, int32_t enable) {
+    return handle_errors([&]() { sam_set_fp8_mlp(as_sam(m), enable != 0); });
+}
+
 int32_t visp_sam_enable_captures(visp_model* m, int32_t enable) {
     return handle_errors([&]() { as_sam(m).captures = enable != 0; });
 }

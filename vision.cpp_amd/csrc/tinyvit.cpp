@@ -183,7 +183,44 @@ void sam_weights_ready(sam_model& m) {
     m.weights_uploaded = true;
 }
 
+// e4m3 images of the stage MLPs' weights: read back from the packed f16 arena (what is on every rank), quantised on the host per output channel
+void sam_set_fp8_mlp(sam_model& m, bool enable) {
+    if (!enable || m.fp8_arena.ptr) { m.fp8_mlp = enable; return; }
+    if (!m.weights_uploaded) throw except("sam: weights have not been uploaded");
+    device_turn turn(*m.backend);
+    std::vector<uint8_t> host;
+    auto put = [&](size_t bytes) { const size_t off = (host.size() + 255) / 256 * 256; host.resize(off + bytes, 0); return off; };
+    const uint8_t* wa = static_cast<const uint8_t*>(m.weight_arena.ptr);
+    auto quantise = [&](packed_gemm const& g) {
+        std::vector<uint16_t> h16((size_t)g.N * g.K);
+        VX(vx_memcpy_d2h(h16.data(), wa + g.w, h16.size() * 2, m.backend->stream));
+        std::vector<float> rows((size_t)g.n_real * g.k_real);
+        for (int n = 0; n < g.n_real; ++n)
+            for (int k = 0; k < g.k_real; ++k) rows[(size_t)n * g.k_real + k] = f16_to_f32(h16[(size_t)n * g.K + k]);
+        fp8_linear f;
+        f.N = (g.n_real + 127) / 128 * 128;
+        f.Kp = (g.k_real + 127) / 128 * 128;
+        f.w = put((size_t)f.N * f.Kp);
+        f.s = put((size_t)f.N * 4);
+        VX(vx_quantize_rows_e4m3_host(rows.data(), g.n_real, g.k_real, f.Kp, host.data() + f.w, reinterpret_cast<float*>(host.data() + f.s)));
+        for (int n = g.n_real; n < f.N; ++n) reinterpret_cast<float*>(host.data() + f.s)[n] = 1.0f; // pad rows: zero bytes, any finite scale
+        return f;
+    };
+    for (int l = 1; l < 4; ++l)
+        for (tv_block_weights& b : m.weights.blocks[l]) {
+            b.fc1_e4m3 = quantise(b.fc1);
+            b.fc2_e4m3 = quantise(b.fc2);
+        }
+    VX(vx_malloc(&m.fp8_arena.ptr, host.size()));
+    m.fp8_arena.bytes = host.size();
+    VX(vx_memcpy_h2d(m.fp8_arena.ptr, host.data(), host.size(), m.backend->stream));
+    VX(vx_stream_sync(m.backend->stream));
+    m.fp8_mlp = true;
+}
+
 sam_model::~sam_model() {
+    vx_free(fp8_arena.ptr);
+    vx_free(fp8_ws.ptr);
     vx_free(ws.ptr);
     vx_free(embed.ptr);
     vx_free(dec_ws.ptr);
@@ -261,6 +298,29 @@ struct tv_exec {
         a.epi = epi; a.out = out; a.ldo = g.n_real;
         mark(group, 2.0 * a.M * g.n_real * g.k_real, (double)B * H * W * Cpix * 2 + (double)a.M * g.n_real * 2);
         VX(vx_gemm_f16(&a, stream));
+    }
+    // out f16 [M, n_out] = act(A W^T + b) [+ res] with A f16 [M, k_in] quantised to e4m3 rows first (scratch: m.fp8_ws)
+    void fp8_linear_launch(fp8_linear const& f, packed_gemm const& g, const void* A, long M, int k_in, void* out, int n_out, int act, const void* res, const char* group) {
+        const size_t need = (size_t)M * f.Kp + (size_t)M * 4 + 512;
+        if (m.fp8_ws.bytes < need) {
+            VX(vx_stream_sync(stream));
+            vx_free(m.fp8_ws.ptr);
+            m.fp8_ws = {};
+            VX(vx_malloc(&m.fp8_ws.ptr, need));
+            m.fp8_ws.bytes = need;
+        }
+        uint8_t* q = static_cast<uint8_t*>(m.fp8_ws.ptr);
+        float* qs = reinterpret_cast<float*>(q + ((size_t)M * f.Kp + 255) / 256 * 256);
+        const uint8_t* fa = static_cast<const uint8_t*>(m.fp8_arena.ptr);
+        mark("quantise_e4m3", 0, (double)M * k_in * 3);
+        VX(vx_quantize_rows_e4m3(A, k_in, q, qs, (int)M, k_in, f.Kp, stream));
+        vx_gemm_fp8_args a;
+        memset(&a, 0, sizeof a);
+        a.A = q; a.a_scale = qs; a.W = fa + f.w; a.w_scale = reinterpret_cast<const float*>(fa + f.s);
+        a.bias = g.b == SIZE_MAX ? nullptr : reinterpret_cast<const float*>(wa + g.b);
+        a.M = (int)M; a.N = f.N; a.Kp = f.Kp; a.n_valid = n_out; a.out = out; a.ldo = n_out; a.act = act; a.res = res;
+        mark(group, 2.0 * M * g.n_real * g.k_real, (double)M * (g.k_real + 2.0 * g.n_real));
+        VX(vx_gemm_fp8(&a, stream));
     }
     void capture(const char* name, const void* src, int B, int res, int C) {
         if (!m.captures) return;
@@ -361,8 +421,14 @@ void sam_encode_batch_device(sam_model& m, void const* rgb_dev, int B, void* out
             ex.dw(b.local_conv, t2, t3, B, res, res, 1, false, "depthwise");
             ex.mark("layernorm", 0, (double)T * C * 4);
             VX(vx_layernorm_f16(t3, ex.fptr(b.mlp_ln_w), ex.fptr(b.mlp_ln_b), t1, T, C, 1e-5f, 0, 0, 0, s));
+            if (m.fp8_mlp) { // opt-in: both products on the e4m3 matrix instruction, activations quantised per token in between
+                const int hid = b.fc1.n_real;
+                ex.fp8_linear_launch(b.fc1_e4m3, b.fc1, t1, T, C, t2, hid, 1, nullptr, "gemm_fc1_e4m3");
+                ex.fp8_linear_launch(b.fc2_e4m3, b.fc2, t2, T, hid, x, C, 0, t3, "gemm_fc2_e4m3");
+            } else {
             ex.gemm(b.fc1, t1, T, C, t2, VX_EPI_F16_GELU, nullptr, "gemm_fc1");
             ex.gemm(b.fc2, t2, T, b.fc1.n_real, x, VX_EPI_F16_ADD, t3, "gemm_fc2");
+            }
         }
         if (L.downsample) patch_merging(Wt.merge[l]);
         ex.capture(("layer_" + std::to_string(l)).c_str(), x, B, res, C);

@@ -18,9 +18,12 @@ struct tiny_vit_params { // mobile-sam.h:16-37
 struct packed_dw { size_t w = 0, b = 0; int C = 0; };   // depthwise 3x3: f16 [9][C] + f32 bias [C]
 struct tv_mbconv_weights { packed_gemm conv1, conv3; packed_dw conv2; size_t conv3_frag = SIZE_MAX; }; // conv3_frag: vx_mbconv_pack_w3 image
 struct tv_merge_weights { packed_gemm conv1, conv3; packed_dw conv2; int stride = 2; };
+// opt-in e4m3 image of a linear weight (kernels_gemm_fp8.hip): rows [N pad 128][K pad 128] + one f32 scale per row, offsets into sam_model::fp8_arena
+struct fp8_linear { size_t w = SIZE_MAX, s = SIZE_MAX; int N = 0, Kp = 0; };
 struct tv_block_weights {
     packed_vec attn_ln_w, attn_ln_b, bias; // bias: attention_biases_indexed packed f16 (vx_window_attention_pack_bias), n = f16 count
     packed_gemm qkv, proj, fc1, fc2;
+    fp8_linear fc1_e4m3, fc2_e4m3;
     packed_dw local_conv;
     packed_vec mlp_ln_w, mlp_ln_b;
 };
@@ -76,10 +79,16 @@ struct sam_model : model_base { // vision.h sam_model counterpart (encoder part)
     device_buffer embed;          // image embedding of the last sam_encode: f32 [64, 64, 256] (NHWC)
     i32x2 image_extent = {{0, 0}}; // extent of the image passed to sam_encode (vision.h sam_model::image_extent)
     bool timing = false, captures = false;
+    // BASELINE.json configs[4] ("fp8 GGUF weights on CDNA4 fp8 MFMA"), opt-in and never the default: the MLPs of the transformer stages
+    // (mobile-sam.cpp:150-160: fc1 + gelu, fc2 + residual -- 39 % of the encoder's time) on the block-scaled e4m3 matrix instruction, activations
+    // quantised per token on the way in. The decision on accuracy stands (tests/test_fp8_decision.py: mask IoU below the bar); this is the measured form of it.
+    bool fp8_mlp = false;
+    device_buffer fp8_arena, fp8_ws;
     std::vector<timing_entry> last_timing;
     std::map<std::string, capture_entry> capture_bufs;
     ~sam_model();
 };
+void sam_set_fp8_mlp(sam_model&, bool enable); // builds the e4m3 weight images on first use (from the f16 weights on the device)
 
 sam_model* sam_load_model(char const* filepath, backend_device const& dev, int flags = load_default);
 void sam_weights_ready(sam_model&);

@@ -150,6 +150,11 @@ class Model:
     def use_graph(self, enable: bool = True):
         check(self._api.visp_depthany_use_graph(self._handle, int(enable)))
 
+    def sam_set_fp8_mlp(self, enable: bool = True):
+        """MobileSAM encoder, opt-in: the transformer stages' MLPs on the e4m3 matrix instruction (BASELINE.json configs[4]); several percent of
+        embedding error (tests/test_fp8_decision.py rejected it for masks). Never the default."""
+        check(self._api.visp_sam_set_fp8_mlp(self._handle, int(enable)))
+
     def set_schedule(self, schedule: int):
         """-1 = automatic (the default: the token-stationary block kernel where the model has its shape, embed dim 384 / mlp 1536 /
         head dim 64, otherwise GEMM launches); 0 = GEMM launches per op group; 1 = block kernel per layer."""
