@@ -151,6 +151,6 @@ def test_fp8_tinyvit_mask_iou_on_the_config_that_names_it():
             ious.append(_iou(m_q, m_ref))
         res[name] = (rel, float(np.mean(ious)), float(np.min(ious)))
         print(f"\nfp8 what-if, MobileSAM TinyViT-5M 1024x1024, {name}: embedding mean |err| / mean |ref| = {rel:.3f}, mask IoU mean {np.mean(ious):.4f} min {np.min(ious):.4f}")
-    # the decision: below the IoU >= 0.99 bar in both forms -> no fp8 kernel for configs[4]
+    # the decision: below the IoU >= 0.99 bar in both forms -> fp8 is never the default for configs[4] (round 4 built the kernel as an opt-in to measure it)
     assert res["weights + activations e4m3"][2] < 0.99 and res["weights e4m3"][2] < 0.99, "e4m3 TinyViT met the IoU bar: revisit DESIGN.md section 8"
     assert res["weights + activations e4m3"][0] > res["weights e4m3"][0] > 0.005
