@@ -303,6 +303,29 @@ void bind_parts(depthany_step& s, const void* rgb, void* out, void* raw) {
 
 // the parts' launch lists on parallel streams (part 0 on `stream`, the others on the model's side streams, forked and joined by events);
 // with timing on, HIP events around every launch on its own stream, summed per group
+#ifdef VISP_TIMING_ABLATIONS
+// diagnostic builds only (make ABLATE=1): VISP_ABLATE_LAUNCHES="a-b,c,d-e" skips those indices of every part's launch list (results invalid): what
+// a group of launches costs END TO END in the overlapped step
+bool ablated_launch(int l) {
+    static const std::vector<std::pair<int, int>> ranges = [] {
+        std::vector<std::pair<int, int>> r;
+        const char* e = getenv("VISP_ABLATE_LAUNCHES");
+        while (e && *e) {
+            char* end = nullptr;
+            const int a = (int)strtol(e, &end, 10);
+            int b = a;
+            if (*end == '-') b = (int)strtol(end + 1, &end, 10);
+            r.emplace_back(a, b);
+            e = *end ? end + 1 : end;
+        }
+        return r;
+    }();
+    for (auto const& ab : ranges)
+        if (l >= ab.first && l <= ab.second) return true;
+    return false;
+}
+#endif
+
 void run_parts(depthany_model& m, depthany_step& s, void* stream) {
     const bool timed = m.timing;
     struct stamp { void* ev; int part, launch; };
@@ -321,6 +344,9 @@ void run_parts(depthany_model& m, depthany_step& s, void* stream) {
         graph& g = *s.parts[(size_t)j].g;
         for (int l = 0; l < (int)g.launches.size(); ++l) {
             if (timed) mark(j, l, strm);
+#ifdef VISP_TIMING_ABLATIONS
+            if (ablated_launch(l)) continue;
+#endif
             g.launches[(size_t)l].run(strm);
         }
         if (timed) mark(j, -1, strm);
