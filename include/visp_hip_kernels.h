@@ -176,6 +176,20 @@ VX_API int vx_dconv3x3_f16(const vx_dconv_args* args, void* stream);
 /* sets the kernels' dynamic-LDS attribute (call once per process before capturing launches into a hipGraph) */
 VX_API int vx_dconv_prepare(void);
 
+/* ---- one launch per DPT residual unit on small maps (depth-anything.cpp:15-33; kernels_rcu.hip) -------------
+ *   out = P( conv2( relu( conv1( relu(x) ) + b1 ) ) + b2 + x [+ res2] ),  P = identity or the 1x1 projection wp (+ bp)
+ * x, res2, out: f16 NHWC [B, H, W, 64]; biases f32 [64] or NULL. w1, w2: f16 [9 taps][64 n][64 c], wp: f16 [64 n][64 c], every (tap, n) row of
+ * 128 bytes with its eight 16-byte groups stored at position g ^ ((n >> 1) & 7) (the linear LDS image of a tap's slab).
+ * The intermediate map stays in LDS. H, W <= 96 (vx_rcu_supported); larger maps are the LDS-ring conv's. */
+typedef struct {
+    const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
+    const void* res2; const void* wp; const float* bp;
+    void* out;
+    int B, H, W;
+} vx_rcu_args;
+VX_API int vx_rcu_supported(int H, int W);
+VX_API int vx_rcu_fused_f16(const vx_rcu_args* args, void* stream);
+
 /* tile_layout (include/visp/image.h:163-181, src/visp/image.cpp:612-651) */
 typedef struct { int image_w, image_h, overlap_x, overlap_y, n_x, n_y, tile_w, tile_h; } vx_tile_layout;
 /* image_u8_to_f32 with tile offset for every tile (vision.cpp:236-241) -> one plane f16 [B*n_tiles, tile_h, tile_w, 32]

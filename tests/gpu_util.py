@@ -166,3 +166,15 @@ def dconv(x_dev, n_planes, cin, B, H, W, w: np.ndarray, bias, *, up2=False, act=
     if rgb:
         return ob.to_numpy(np.float32, (B, H, W, 3))
     return from_planes(ob.to_numpy(np.float16, (out_planes, B, H, W, 32)))
+
+
+def pack_rcu(w: np.ndarray) -> np.ndarray:
+    """[64, kh, kw, 64] float -> f16 [taps][64 n][64 c] with the 16-byte groups of row n at position g ^ ((n >> 1) & 7) (kernels_rcu.hip's slab image)."""
+    n, kh, kw, c = w.shape
+    assert n == 64 and c == 64
+    t = w.astype(np.float16).transpose(1, 2, 0, 3).reshape(kh * kw, 64, 8, 8)  # [tap][n][group][8]
+    out = np.empty_like(t)
+    for row in range(64):
+        for g in range(8):
+            out[:, row, g ^ ((row >> 1) & 7)] = t[:, row, g]
+    return np.ascontiguousarray(out.reshape(kh * kw, 64, 64))

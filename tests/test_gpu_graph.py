@@ -129,12 +129,14 @@ def test_conv_2d_node(device, cin, cout, k, stride, pad, H, W):
     assert rel(got, ref.numpy()) < 2e-3
 
 
-def test_residual_conv_unit_fuses_and_matches(device):
-    """dpt::residual_conv (depth-anything.cpp:15-23) = two launches of the LDS-ring conv: [relu-in][relu], then [+res] -- with feature_fusion's
-    outer add as a second residual of the same epilogue -- and the 1x1 projection BEFORE the bilinear align_corners resize it commutes with
-    (depth-anything.cpp:25-42): six launches for the whole fusion stage."""
+@pytest.mark.parametrize("hw", [(37, 37), (148, 40)])
+def test_residual_conv_unit_fuses_and_matches(device, hw):
+    """dpt::residual_conv (depth-anything.cpp:15-23) with feature_fusion's outer add (:28-31) and the 1x1 projection BEFORE the bilinear
+    align_corners resize it commutes with (:36-40). On a map of at most 96 x 96: one launch per residual unit (kernels_rcu.hip; the second one
+    applies the projection), three launches for the stage. On a larger one: two launches of the LDS-ring conv per unit ([relu-in][relu], then
+    [+res], the outer add as a second residual of the same epilogue), six for the stage."""
     rng = np.random.default_rng(5)
-    C, H, W, B = 64, 37, 37, 2
+    C, (H, W), B = 64, hw, 2
     x0, x1 = h(rng.standard_normal((B, H, W, C))), h(rng.standard_normal((B, H, W, C)))
     names = ["residual_layer1.convolution1", "residual_layer1.convolution2", "residual_layer2.convolution1", "residual_layer2.convolution2"]
     w = {n: h(rng.standard_normal((C, 3, 3, C)) / math.sqrt(9 * C)) for n in names}
@@ -146,11 +148,15 @@ def test_residual_conv_unit_fuses_and_matches(device):
     g.add_weight("f.projection.weight", wp); g.add_weight("f.projection.bias", bp, G.F32)
     m = G.ModelRef(g)
     a, c = g.input((C, W, H, B), G.F16, "x0"), g.input((C, W, H, B), G.F16, "x1")
-    y = g.output(G.dpt_feature_fusion(m["f"], a, c, (74, 74)), "y")
+    y = g.output(G.dpt_feature_fusion(m["f"], a, c, (2 * W, 2 * H)), "y")
     (got,) = run(g, {a: x0, c: x1}, [y])
     d = g.describe()
-    assert d.count("dconv3x3[relu-in][relu]") == 2 and d.count("dconv3x3[+res][+res]") == 1 and d.count("dconv3x3[+res] M=") == 1
-    assert "gemm(conv1x1 before its resize)" in d and "bilinear_ac 37x37 -> 74x74 C=64" in d and "launches=6" in d
+    if max(hw) <= 96:
+        assert d.count("residual_unit[relu, conv3x3, relu, conv3x3, + x, + x0]") == 1 and d.count("residual_unit[relu, conv3x3, relu, conv3x3, + x, conv1x1 before its resize]") == 1
+        assert "gemm(conv1x1 before its resize)" not in d and f"bilinear_ac {W}x{H} -> {2 * W}x{2 * H} C=64" in d and "launches=3" in d
+    else:
+        assert d.count("dconv3x3[relu-in][relu]") == 2 and d.count("dconv3x3[+res][+res]") == 1 and d.count("dconv3x3[+res] M=") == 1
+        assert "gemm(conv1x1 before its resize)" in d and f"bilinear_ac {W}x{H} -> {2 * W}x{2 * H} C=64" in d and "launches=6" in d
 
     def conv(v, n):
         return F.conv2d(v, t(w[n]).permute(0, 3, 1, 2), t(b[n]), padding=1)
@@ -161,7 +167,7 @@ def test_residual_conv_unit_fuses_and_matches(device):
 
     v0, v1 = t(x0).permute(0, 3, 1, 2), t(x1).permute(0, 3, 1, 2)
     r = rcu(t(h((v0 + rcu(v1, "residual_layer1")).numpy())), "residual_layer2")
-    up = t(h(F.interpolate(r, size=(74, 74), mode="bilinear", align_corners=True).numpy()))
+    up = t(h(F.interpolate(r, size=(2 * H, 2 * W), mode="bilinear", align_corners=True).numpy()))
     ref = F.conv2d(up, t(wp).permute(0, 3, 1, 2), t(bp)).permute(0, 2, 3, 1)
     assert rel(got, ref.numpy()) < 4e-3
 

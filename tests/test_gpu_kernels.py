@@ -29,7 +29,7 @@ def _release_buffers():
     release()
 
 
-from gpu_util import api, dev, empty, gemm, pad_vec, pad_weight, rel_err, release, sync  # noqa: E402
+from gpu_util import api, dev, empty, gemm, pack_rcu, pad_vec, pad_weight, rel_err, release, sync  # noqa: E402
 
 F16_TOL = 4e-3  # one f16 rounding of the output (2^-11) plus f16-rounded operands over K <= 1536
 
@@ -560,3 +560,53 @@ def test_headconv_limits():
     assert lib.vx_headconv_bil_f16(x.ptr, x.ptr, x.ptr, x.ptr, 0.0, 1.0, x.ptr, 1, 518, 518, 400, 400, None) == 0
     assert b"source patch" in lib.vx_last_error()
     release()
+
+
+def _rcu_oracle(x, w1, b1, w2, b2, res2=None, wp=None, bp=None):
+    """dpt::residual_conv (depth-anything.cpp:15-23) [+ feature_fusion's x0 (:28-31)] [+ the 1x1 out_conv (:39)], intermediates rounded to f16
+    where the device stores f16."""
+    mid = _h(np.maximum(oracle.conv2d_nhwc(np.maximum(x, 0), w1, b1, 1, 1), 0))
+    y = _h(_h(oracle.conv2d_nhwc(mid, w2, b2, 1, 1)) + x)
+    if res2 is not None:
+        y = _h(y + res2)
+    if wp is not None:
+        y = oracle.conv2d_nhwc(y, wp, bp, 1, 0)
+    return y
+
+
+@pytest.mark.parametrize("hw", [(19, 19), (37, 37), (74, 74), (50, 37), (8, 5), (1, 1), (96, 21)])
+@pytest.mark.parametrize("mode", ["rcu", "rcu+res", "rcu+proj", "rcu+res+proj"])
+def test_rcu_fused(hw, mode):
+    """One launch per residual unit (kernels_rcu.hip): relu -> conv3x3 -> relu -> conv3x3 -> + x [+ x0] [-> conv1x1], the intermediate map in LDS,
+    against the oracle's convs -- map extents that tile evenly, raggedly (edge tiles beyond the map), and maps smaller than one tile."""
+    rng = np.random.default_rng(hw[0] * 131 + hw[1] + len(mode))
+    B, (Hh, Ww), Cc = 3, hw, 64
+    x = _h(_rand(rng, B, Hh, Ww, Cc))
+    w1, b1 = _h(_rand(rng, Cc, 3, 3, Cc, scale=(9 * Cc) ** -0.5)), _rand(rng, Cc, scale=0.1)
+    w2, b2 = _h(_rand(rng, Cc, 3, 3, Cc, scale=(9 * Cc) ** -0.5)), _rand(rng, Cc, scale=0.1)
+    res2 = _h(_rand(rng, B, Hh, Ww, Cc)) if "res" in mode else None
+    wp, bp = (_h(_rand(rng, Cc, 1, 1, Cc, scale=Cc ** -0.5)), _rand(rng, Cc, scale=0.1)) if "proj" in mode else (None, None)
+    assert api().vx_rcu_supported(Hh, Ww) == 1
+    keep = [dev(x.astype(np.float16)), dev(pack_rcu(w1)), dev(b1), dev(pack_rcu(w2)), dev(b2)]
+    a = L.RcuArgs()
+    a.x, a.w1, a.b1, a.w2, a.b2 = (k.ptr for k in keep)
+    if res2 is not None:
+        keep.append(dev(res2.astype(np.float16)))
+        a.res2 = keep[-1].ptr
+    if wp is not None:
+        keep += [dev(pack_rcu(wp)), dev(bp)]
+        a.wp, a.bp = keep[-2].ptr, keep[-1].ptr
+    out = empty(B * Hh * Ww * Cc * 2)
+    a.out, a.B, a.H, a.W = out.ptr, B, Hh, Ww
+    L.vx_check(api().vx_rcu_fused_f16(C.byref(a), None))
+    sync()
+    got = out.to_numpy(np.float16, (B, Hh, Ww, Cc)).astype(np.float32)
+    want = _rcu_oracle(x, w1, b1, w2, b2, res2, wp, bp)
+    assert rel_err(got, want) < F16_TOL
+
+
+def test_rcu_fused_limits():
+    assert api().vx_rcu_supported(148, 148) == 0 and api().vx_rcu_supported(0, 5) == 0
+    a = L.RcuArgs()
+    a.B, a.H, a.W = 1, 148, 148
+    assert api().vx_rcu_fused_f16(C.byref(a), None) == 0 and b"not built" in api().vx_last_error()

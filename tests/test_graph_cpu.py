@@ -106,16 +106,17 @@ def planned_fused(tmp_path_factory):  # node groups mapped onto the kernels writ
 
 
 def test_depth_anything_node_groups_lower_to_the_model_kernels(planned_fused):
-    """The default lowering of the same 567 nodes: 62 launches -- the launch list of the hand-written step this library measured in rounds 1-3,
-    now derived from the graph. dino.cpp:10-110: prepare_tokens = patches + cls rows + one GEMM whose epilogue writes f32 token rows; the
+    """The default lowering of the same 567 nodes: 54 launches -- the launch list of the hand-written step this library measured in rounds 1-3,
+    now derived from the graph (62 launches), with one launch per residual unit on the 19^2 / 37^2 / 74^2 maps since round 4. dino.cpp:10-110: prepare_tokens = patches + cls rows + one GEMM whose epilogue writes f32 token rows; the
     first layer's LN1 + QKV, then per layer ONE attention and ONE token-stationary block launch (out-proj, both residuals, MLP, the taps'
     final LayerNorm, the next layer's LN1 + QKV). depth-anything.cpp:15-96: the cls-token slice is row addressing in the projection GEMM,
     the 48 / 96-channel projections are written with the padded rows their conv_transpose reads, every 3x3 / stride-1 conv is the LDS-ring
-    kernel with ReLU-in / ReLU / two residual maps in its epilogue, the fusion projection runs BEFORE its resize, head.conv1 resizes in
-    its halo loader, the head's tail is one kernel."""
+    kernel with ReLU-in / ReLU / two residual maps in its epilogue -- except dpt::residual_conv on maps of at most 96 x 96, which is ONE launch
+    (relu, conv, relu, conv, + x [+ feature_fusion's other addend] [+ the 1x1 projection]) with the intermediate map in LDS --, the fusion
+    projection runs BEFORE its resize, head.conv1 resizes in its halo loader, the head's tail is one kernel."""
     g, img, out = planned_fused
     lines = g.describe().strip().splitlines()
-    assert g.summary()["launches"] == len(lines) - 1 == 62
+    assert g.summary()["launches"] == len(lines) - 1 == 54
     assert lines[0].startswith("im2col_patches 14x14 M=2738") and lines[1] == "cls_rows B=2" and lines[2].startswith("gemm[tokens f32: + bias + pos] M=2738 N=384 K=588")
     assert lines[3].startswith("dino_block[ln1 + qkv] M=2740")
     assert [l.split(" M=")[0] for l in lines[4:28]] == ["attention B=2 heads=6 T=1370", "dino_block[out-proj + mlp + next ln1 + qkv]"] * 2 + \
@@ -125,8 +126,10 @@ def test_depth_anything_node_groups_lower_to_the_model_kernels(planned_fused):
     assert text.count("gemm(conv1x1)[rows 1.. of 1370] M=2738") == 4 and not any(l.startswith(("slice", "pad_rows")) for l in lines)
     assert text.count("gemm+pixel_shuffle") == 2 and "conv3x3s2 M=722 N=384 K=3456" in text
     assert text.count("dconv3x3 M=") == 4                                            # neck.convs (no bias, no activation)
-    assert text.count("dconv3x3[relu-in][relu]") == 7 and text.count("dconv3x3[+res][+res]") == 3 and text.count("dconv3x3[+res] M=") == 4
-    assert text.count("gemm(conv1x1 before its resize)") == 4 and text.count("bilinear_ac") == 3
+    # fusion stages 0-2 (19^2, 37^2, 74^2): five residual units, three of them with the stage's projection; stage 3 (148^2) stays on the LDS-ring conv
+    assert text.count("residual_unit[relu, conv3x3, relu, conv3x3, + x, conv1x1 before its resize]") == 3 and text.count("residual_unit[relu, conv3x3, relu, conv3x3, + x, + x0]") == 2
+    assert text.count("dconv3x3[relu-in][relu]") == 2 and text.count("dconv3x3[+res][+res]") == 1 and text.count("dconv3x3[+res] M=") == 1
+    assert text.count("gemm(conv1x1 before its resize)") == 1 and text.count("bilinear_ac") == 3
     assert lines[-3].startswith("dconv3x3[resize 148x148 in the loader] M=175232 N=32 K=576 <- head.conv1.weight")
     assert lines[-2].startswith("head_tail[resize 296x296 -> 518x518, conv3x3 32->32, relu, conv1x1 -> 1, relu] B=2 <- head.conv2.weight")
     assert g.get_tensor("dino_layer_11").ne == (384, 1370, 2, 1)

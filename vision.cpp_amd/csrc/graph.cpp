@@ -889,8 +889,9 @@ struct lowering {
     }
     bool dconv_shape(graph_node const& n, graph_node const& x, graph_node const& w) const {
         static const bool off = getenv("VISP_NO_DCONV") != nullptr;
+        static const int min_w = getenv("VISP_DCONV_MIN_W") ? atoi(getenv("VISP_DCONV_MIN_W")) : 16; // A/B runs: narrower maps take the GEMM family's conv forms
         return g.fused_models && !off && n.op == gop_conv_2d && n.dtype == gdt_f16 && w.ne[1] == 3 && w.ne[2] == 3 && n.ip[0] == 1 && n.ip[1] == 1 && x.ne[0] % 16 == 0 &&
-               (w.ne[3] == 32 || w.ne[3] == 64) && n.ne[1] >= 16;
+               (w.ne[3] == 32 || w.ne[3] == 64) && n.ne[1] >= min_w;
     }
     // the LDS-ring conv's operand: slabs [cin pad 32 / 32][9 taps][cout][32] f16, 16-byte groups swizzled (kernels_dconv.hip)
     void* pack_dconv(int wt, int cin, int cout, int* d_cin) {
@@ -907,6 +908,103 @@ struct lowering {
                     }
             return upload(h.data(), h.size() * 2, st);
         });
+    }
+
+    // the residual-unit kernel's operand: [taps][64 n][64 c] f16, the 16-byte groups of row n at position g ^ ((n >> 1) & 7) (kernels_rcu.hip)
+    void* pack_rcu(int wt, int taps) {
+        return cached(wt, 7, [&](bool st) {
+            std::vector<uint16_t> h((size_t)taps * 64 * 64);
+            const float* w = g.nodes[wt].values(); // [n][ky][kx][c]
+            for (int n = 0; n < 64; ++n)
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int c = 0; c < 64; ++c)
+                        h[((size_t)tap * 64 + n) * 64 + (size_t)((c >> 3) ^ ((n >> 1) & 7)) * 8 + (c & 7)] = f32_to_f16(w[((size_t)n * taps + tap) * 64 + c]);
+            return upload(h.data(), h.size() * 2, st);
+        });
+    }
+    std::map<int, int> preprojected; // interpolate node -> buffer that already holds the 1x1 projection of its SOURCE (written by the residual-unit launch)
+
+    // dpt::residual_conv on a small map (depth-anything.cpp:15-23): relu -> conv3x3 -> relu -> conv3x3 -> + x, every link read by the next one only,
+    // [+ feature_fusion's other addend (:28-31)] [-> the 1x1 out_conv that commutes with the resize behind the unit (:36-40)]: ONE launch of
+    // kernels_rcu.hip with the intermediate map in LDS. t = the first conv (its ReLU is on its loader already). Returns false and leaves
+    // everything untouched when the pattern or the kernel's limits do not hold.
+    bool residual_unit(int t, std::string const& who) {
+        static const bool off = getenv("VISP_NO_RCU_FUSE") != nullptr;
+        graph_node& n = g.nodes[t];
+        const int xs = n.src[0];
+        graph_node const& x = g.nodes[xs];
+        const int H = (int)n.ne[2], W = (int)n.ne[1], B = (int)n.ne[3];
+        auto conv64 = [&](graph_node const& c) {
+            graph_node const& w = g.nodes[c.src[1]];
+            return c.op == gop_conv_2d && c.dtype == gdt_f16 && w.constant && w.ne[0] == 64 && w.ne[1] == 3 && w.ne[2] == 3 && w.ne[3] == 64 && c.ip[0] == 1 && c.ip[1] == 1 &&
+                   (c.n_src == 2 || g.nodes[c.src[2]].constant);
+        };
+        if (off || !g.fused_models || !relu_on_load[t] || !conv64(n) || x.ne[0] != 64 || n.is_output || resized_in.count(xs) || !vx_rcu_supported(H, W)) return false;
+        const int r1 = sole_consumer(t);
+        if (r1 < 0 || g.nodes[r1].op != gop_relu) return false;
+        const int c2 = sole_consumer(r1);
+        if (c2 < 0 || !conv64(g.nodes[c2]) || g.nodes[c2].src[0] != r1) return false;
+        const int a1 = sole_consumer(c2);
+        if (a1 < 0 || g.nodes[a1].op != gop_add) return false;
+        {
+            graph_node const& a = g.nodes[a1];
+            const int other = root(a.src[0]) == c2 ? a.src[1] : a.src[0];
+            if (root(other) != root(xs) || (root(a.src[0]) != c2 && root(a.src[1]) != c2)) return false; // the first addend must be the unit's own input
+        }
+        skip[r1] = 1;
+        g.nodes[r1].alias_of = t;
+        epilogue e = fuse_epilogue(c2, false, false, true);
+        if (e.act != 0 || e.res < 0 || root(e.res) != root(xs)) throw except("graph: internal: residual unit at %s did not fuse as expected", who.c_str());
+        skip[c2] = 1;
+        // the projection behind the unit's resize
+        int up = g.nodes[e.last].is_output ? -1 : sole_consumer(e.last), pj = -1;
+        if (up >= 0) {
+            graph_node const& u = g.nodes[up];
+            const bool bil = u.op == gop_interpolate && (u.ip[2] & 255) == 1 && (u.ip[2] & 256) && !u.is_output && root(u.src[0]) == c2;
+            pj = bil ? sole_consumer(up) : -1;
+            if (pj >= 0) {
+                graph_node const& c = g.nodes[pj];
+                graph_node const& w = g.nodes[c.src[1]];
+                if (!(c.op == gop_conv_2d && c.dtype == gdt_f16 && c.src[0] == up && w.constant && w.ne[0] == 64 && w.ne[1] == 1 && w.ne[2] == 1 && w.ne[3] == 64 && c.ip[0] == 1 && c.ip[1] == 0 &&
+                      (c.n_src == 2 || g.nodes[c.src[2]].constant)))
+                    pj = -1;
+            }
+        }
+        vx_rcu_args a;
+        memset(&a, 0, sizeof a);
+        a.w1 = pack_rcu(n.src[1], 9);
+        a.b1 = n.n_src == 3 ? const_f32(n.src[2]) : nullptr;
+        a.w2 = pack_rcu(g.nodes[c2].src[1], 9);
+        a.b2 = g.nodes[c2].n_src == 3 ? const_f32(g.nodes[c2].src[2]) : nullptr;
+        a.B = B; a.H = H; a.W = W;
+        const int xbuf = buf_of(xs);
+        std::vector<int> reads = {xbuf};
+        std::function<char*()> rp2;
+        if (e.res2 >= 0) { reads.push_back(buf_of(e.res2)); rp2 = ptr(buf_of(e.res2)); }
+        int obuf;
+        if (pj >= 0) {
+            a.wp = pack_rcu(g.nodes[pj].src[1], 1);
+            a.bp = g.nodes[pj].n_src == 3 ? const_f32(g.nodes[pj].src[2]) : nullptr;
+            obuf = new_buffer((size_t)B * H * W * 64 * 2);
+            preprojected[up] = obuf;
+        } else {
+            materialise(c2);
+            obuf = g.nodes[c2].buffer;
+        }
+        char d[320];
+        snprintf(d, sizeof d, "residual_unit[relu, conv3x3, relu, conv3x3, + x%s%s] %dx%d B=%d <- %s", e.res2 >= 0 ? ", + x0" : "", pj >= 0 ? ", conv1x1 before its resize" : "", W, H, B,
+                 who.c_str());
+        auto xp = ptr(xbuf), op = ptr(obuf);
+        emit(d, reads, {obuf}, [=](void* st) {
+            vx_rcu_args r = a;
+            r.x = xp();
+            r.out = op();
+            if (rp2) r.res2 = rp2();
+            VX(vx_rcu_fused_f16(&r, st));
+        });
+        const double px = (double)B * H * W;
+        tag("fusion_rcu", 2.0 * px * 64 * (576 * 2 + (pj >= 0 ? 64 : 0)), px * 64 * 2 * (2 + (e.res2 >= 0 ? 1 : 0)));
+        return true;
     }
 
     void gemm_like(int t) {
@@ -998,7 +1096,8 @@ struct lowering {
         std::function<char*()> rp, rp2;
         if (e.res >= 0) { reads.push_back(buf_of(e.res)); rp = ptr(buf_of(e.res)); }
         if (e.res2 >= 0) { reads.push_back(buf_of(e.res2)); rp2 = ptr(buf_of(e.res2)); }
-        const bool halo = conv && a.conv_kh == 3 && a.conv_kw == 3 && a.conv_stride == 1 && a.conv_pad == 1 && a.conv_W >= 96;
+        static const int halo_min_w = getenv("VISP_HALO_MIN_W") ? atoi(getenv("VISP_HALO_MIN_W")) : 96;
+        const bool halo = conv && a.conv_kh == 3 && a.conv_kw == 3 && a.conv_stride == 1 && a.conv_pad == 1 && a.conv_W >= halo_min_w;
         char d[320];
         snprintf(d, sizeof d, "%s%s%s%s%s%s%s M=%d N=%d K=%d <- %s", kind.c_str(), e.scale >= 0 ? "[*scale]" : "", e.act ? "[" : "", act_name(e.act), e.act ? "]" : "",
                  e.res >= 0 ? "[+res]" : "", e.res2 >= 0 ? "[+res]" : "", a.M, (int)n.ne[0], p.k_real, who.c_str());
@@ -1019,6 +1118,7 @@ struct lowering {
     // ReLU of a relu -> conv chain applied to the fragments, ReLU or up to two residual maps in the epilogue, and -- where the input is the
     // bilinear (align_corners) resize of a smaller map read by this conv only -- the resize done by the conv's halo loader
     void dconv(int t, std::string const& who) {
+        if (residual_unit(t, who)) return;
         graph_node& n = g.nodes[t];
         const int xs = n.src[0], wt = n.src[1], bt = n.n_src == 3 ? n.src[2] : -1;
         graph_node const& x = g.nodes[xs];
@@ -1094,23 +1194,28 @@ struct lowering {
             return true;
         }
         if (!(w.ne[1] == 1 && w.ne[2] == 1 && cn.ip[0] == 1 && cn.ip[1] == 0) || cn.ne[0] % 8 || x.ne[0] % 64) return false;
-        // the projection on the small map
+        // the projection on the small map (where the residual unit in front of the resize has not applied it already)
         const int bt = cn.n_src == 3 ? cn.src[2] : -1, cout = (int)cn.ne[0];
-        packed_operand p = pack_rows(cn.src[1], bt, cout);
         const int64_t M = (int64_t)B * hs * ws;
-        const int sbuf = new_buffer((size_t)M * cout * 2);
-        const int xbuf = buf_of(up.src[0]);
-        vx_gemm_args a;
-        memset(&a, 0, sizeof a);
-        a.lda = p.K; a.W = p.w; a.bias = p.bias; a.M = (int)M; a.N = p.N; a.K = p.K; a.n_valid = cout; a.ldo = cout; a.epi = VX_EPI_F16;
-        auto xp = ptr(xbuf), sp = ptr(sbuf);
-        std::string who = g.nodes[cn.src[1]].name;
-        emit("gemm(conv1x1 before its resize) M=" + std::to_string(M) + " N=" + std::to_string(cout) + " K=" + std::to_string(p.k_real) + " <- " + who, {xbuf}, {sbuf}, [=](void* st) {
-            vx_gemm_args r = a;
-            r.A = xp(); r.out = sp();
-            VX(vx_gemm_f16(&r, st));
-        });
-        tag(group_of(who, cn, 1).c_str(), 2.0 * M * (double)cout * p.k_real, (double)M * (p.k_real + cout) * 2);
+        int sbuf;
+        if (auto it = preprojected.find(t); it != preprojected.end()) sbuf = it->second;
+        else {
+            packed_operand p = pack_rows(cn.src[1], bt, cout);
+            sbuf = new_buffer((size_t)M * cout * 2);
+            const int xbuf = buf_of(up.src[0]);
+            vx_gemm_args a;
+            memset(&a, 0, sizeof a);
+            a.lda = p.K; a.W = p.w; a.bias = p.bias; a.M = (int)M; a.N = p.N; a.K = p.K; a.n_valid = cout; a.ldo = cout; a.epi = VX_EPI_F16;
+            auto xp = ptr(xbuf), sp0 = ptr(sbuf);
+            std::string who = g.nodes[cn.src[1]].name;
+            emit("gemm(conv1x1 before its resize) M=" + std::to_string(M) + " N=" + std::to_string(cout) + " K=" + std::to_string(p.k_real) + " <- " + who, {xbuf}, {sbuf}, [=](void* st) {
+                vx_gemm_args r = a;
+                r.A = xp(); r.out = sp0();
+                VX(vx_gemm_f16(&r, st));
+            });
+            tag(group_of(who, cn, 1).c_str(), 2.0 * M * (double)cout * p.k_real, (double)M * (p.k_real + cout) * 2);
+        }
+        auto sp = ptr(sbuf);
         skip[t] = 1;
         skip[c] = 1;
         // ... and its resize: by the next conv's loader where that is the only reader, else by the resize kernel into the conv node's buffer
