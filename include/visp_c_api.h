@@ -267,7 +267,8 @@ enum visp_graph_op {
     VISP_OP_CONT = 18,
     /* extensions for callers that keep images in HBM (the reference does both steps on the host): */
     VISP_OP_IMAGE_U8_TO_F32 = 19,  /* src x u8 input [3,W,H,N]; f0..f2 mean, f3..f5 1/std: (x / 255 - mean) / std        image.cpp:215-255 */
-    VISP_OP_IMAGE_NORMALIZE = 20   /* src x f32 [1,W,H,N]: per-image min-max to [0, 1]                                   image.cpp:537-582 */
+    VISP_OP_IMAGE_NORMALIZE = 20,  /* src x f32 [1,W,H,N]: per-image min-max to [0, 1]                                   image.cpp:537-582 */
+    VISP_OP_LEAKY_RELU = 21        /* f0 negative slope                                                                    ggml_leaky_relu, esrgan.cpp:17, 24 */
 };
 /* every f16 / f32 tensor of the file becomes a weight (model_load + model_transfer, ml.cpp:206-217, 449-516); conv kernels listed in
  * <arch>.conv2d_weights of a whcn file are presented as [Cin,kw,kh,Cout]. Device images are made when a graph that uses a tensor is

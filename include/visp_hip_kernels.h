@@ -387,7 +387,12 @@ VX_API int vx_copy_strided_f16(const void* src, void* dst, const int64_t ne[4], 
 VX_API int vx_binary_rows(int op, const void* a, int a_f32, const void* b, int b_f32, int64_t b_period, void* y, int y_f32, int64_t n, void* stream);
 /* op 0 tanh-GELU (ggml_gelu), 1 ReLU, 2 x * s; f16 */
 VX_API int vx_unary_f16(int op, const void* x, void* y, int64_t n, float s, void* stream);
+/* op: 0 gelu, 1 relu, 2 x * s, 3 leaky relu max(x, s x) */
 VX_API int vx_convert(const void* x, int x_f32, void* y, int y_f32, int64_t n, void* stream);
+/* ggml_interpolate(NEAREST) of an NHWC f16 map (ml.cpp:782-788; esrgan.cpp:15) */
+VX_API int vx_nearest_f16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, void* stream);
+/* f32 image [pixels][C <= 16] -> one 32-channel f16 plane: values, then what the f16 rounding dropped, then zeros (input of an image's first conv) */
+VX_API int vx_image_planes_f32(const float* x, void* y, int64_t n_pix, int C, void* stream);
 /* patch_embed's im2col (nn.cpp:166-180) on the f32 image tensor [B,H,W,C]: rows (b,py,px), k = (ky,kx,c), zero padded to Kp, f16 */
 /* 1x1 convolution to one channel: out f32 [M] = scale * act(sum_c x[m,c] w[c] + bias), x f16 [M][C] (depth-anything.cpp:91-95) */
 VX_API int vx_conv1x1_to1_f32(const void* x, const float* w, float bias, int relu, float scale, float* out, int64_t M, int C, void* stream);

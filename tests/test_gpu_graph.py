@@ -407,3 +407,69 @@ def test_graphs_over_one_model_share_the_device_weights(device, tmp_path):
         g.compute()
         want, _ = om.predict(params, img, {})
         assert float(np.abs(_norm(g.get(out)[0, ..., 0]) - _norm(want.reshape(H, W))).mean()) < 1e-3
+
+
+# ---- ESRGAN through the graph layer (esrgan.cpp:13-79): planar maps, concat as planes of one buffer -----------------------------------------
+
+def _esrgan_graph(device, path, cfg, shape):
+    g = G.Graph(device, G.Weights(path))
+    img = g.input(shape, G.F32, "image")
+    out = G.esrgan_generate(G.ModelRef(g), img, cfg.scale, cfg.num_blocks)
+    g.allocate()
+    return g, img, out
+
+
+@pytest.mark.parametrize("cfg_name,hw", [("ESRGAN_TINY", (56, 40)), ("ESRGAN_X4", (32, 48))])
+def test_esrgan_generate_through_the_graph(device, tmp_path, cfg_name, hw):
+    """The reference's esrgan_generate (esrgan.cpp:55-79) built node by node (conv_2d, leaky_relu, concat, scale, add, interpolate NEAREST) and lowered onto
+    the LDS-ring conv in its planar layout: the f32 image as a value | residue plane, every conv_block into the plane behind its input (concat is no
+    launch), conv5 * 0.2 + x with x from the halo, the rrdb's (.) * 0.2 + input as the second residual, the x2 resize in the up-conv's loader, the last
+    conv straight to f32 RGB -- the launch list of this library's hand schedule (csrc/esrgan.cpp), derived from the graph. Checked against the CPU
+    oracle (pinned to the reference's torch RRDBNet, tests/golden/make_golden_esrgan.py) and against the hand schedule on the same weights."""
+    O = oracle
+    cfg = getattr(synth, cfg_name)
+    path = tmp_path / "esrgan.gguf"
+    synth.write_esrgan_gguf(path, cfg, 7)
+    Hh, Ww = hw
+    B = 3
+    imgs = synth.images(B, Ww, Hh, seed=11).astype(np.float32) / np.float32(255.0)  # [B, H, W, 3]
+    g, img, out = _esrgan_graph(device, path, cfg, (3, Ww, Hh, B))
+    lines = g.describe().strip().splitlines()
+    n_up = int(math.log2(cfg.scale))
+    assert lines[0].startswith("image_planes") and "[f32 image]" in lines[1] and "[rgb f32]" in lines[-2]
+    assert len(lines) - 1 == 1 + 1 + 15 * cfg.num_blocks + 1 + n_up + 2  # image plane, first conv, 15 convs per rrdb, trunk, up-convs, hr conv + last conv
+    text = "\n".join(lines)
+    assert text.count("[*s + x]") == 3 * cfg.num_blocks and text.count("[*s + x][*s + res]") == cfg.num_blocks and text.count("[nearest x2 in the loader]") == n_up
+    assert "concat" not in text and "planes_to_nhwc" not in text
+    g.set(img, imgs)
+    g.compute()
+    got = g.get(out)
+    assert got.shape == (B, Hh * cfg.scale, Ww * cfg.scale, 3) and got.dtype == np.float32
+    sd = synth.esrgan_state_dict(cfg, 7)
+    tensors, conv2d = synth.esrgan_gguf_tensors(sd)
+    om = O.Model(tensors, conv2d, "whcn")
+    for i in range(B):
+        ref = O.esrgan_generate(om, cfg.scale, cfg.num_blocks, imgs[i])
+        assert np.abs(got[i] - ref).mean() < 1e-3 and np.abs(got[i] - ref).max() < 8e-3
+    m = vision.Model.load(path, device)
+    hand = m.esrgan_generate(imgs)
+    assert np.abs(got - hand).max() < 2e-3  # same kernels, same operands; the hand schedule's first conv is issued twice, nothing else differs
+
+
+def test_esrgan_nodes_outside_the_patterns(device):
+    """leaky_relu, interpolate NEAREST and a planar map read by something that is not the LDS-ring conv (here: a graph output and an add of two maps):
+    the generic launches and the planes -> NHWC copy."""
+    rng = np.random.default_rng(3)
+    C, H, W, B = 32, 9, 7, 2
+    x = h(rng.standard_normal((B, H, W, C)))
+    g = G.Graph(device)
+    m = G.ModelRef(g)
+    xi = g.input((C, W, H, B), G.F16)
+    a = G.leaky_relu(m, xi, 0.1)
+    b = G.interpolate(m, a, (W * 3, H * 2), G.SCALE_MODE_NEAREST)
+    ya, yb = g.output(a, "a"), g.output(b, "b")
+    got_a, got_b = run(g, {xi: x}, [ya, yb])
+    want_a = np.where(x > 0, x, 0.1 * x)
+    np.testing.assert_allclose(got_a, want_a, rtol=2e-3, atol=1e-3)
+    ref_b = F.interpolate(t(h(want_a)).permute(0, 3, 1, 2), size=(H * 2, W * 3), mode="nearest").permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(got_b, ref_b, rtol=2e-3, atol=1e-3)

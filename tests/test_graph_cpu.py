@@ -218,3 +218,30 @@ def test_fusion_respects_other_readers():
     lines = g.describe().splitlines()
     assert lines[0].startswith("gemm M=64 N=64") and lines[1].startswith("gelu n=4096") and lines[2].startswith("add n=4096")
     assert lines[3].startswith("relu n=4096") and lines[4].startswith("conv3x3[+res] M=64")
+
+
+def test_esrgan_lowers_to_the_planar_dense_block_schedule(tmp_path):
+    """esrgan_generate (esrgan.cpp:55-79) as a graph, planned without a device: no concat, no activation, no scale / add launch -- every one of them is a
+    plane address or an epilogue of the LDS-ring conv -- and the x2 nearest resize is the up-conv's loader."""
+    cfg = synth.ESRGAN_TINY
+    synth.write_esrgan_gguf(tmp_path / "e.gguf", cfg, 7)
+    g = G.Graph(None, G.Weights(tmp_path / "e.gguf"))
+    img = g.input((3, 40, 56, 3), G.F32, "image")
+    out = G.esrgan_generate(G.ModelRef(g), img, cfg.scale, cfg.num_blocks)
+    assert out.ne == (3, 80, 112, 3)
+    g.allocate()
+    lines = g.describe().strip().splitlines()
+    assert g.summary()["launches"] == len(lines) - 1 == 36
+    assert lines[0] == "image_planes [3, 40, 56, 3]" and lines[1].startswith("dconv3x3(planes)[f32 image] M=6720 N=64 K=27 <- model.0.weight")
+    rdb = [l.split(" M=")[0] for l in lines[2:17]]
+    assert rdb == (["dconv3x3(planes)[leaky_relu]"] * 4 + ["dconv3x3(planes)[*s + x]"]) * 2 + ["dconv3x3(planes)[leaky_relu]"] * 4 + ["dconv3x3(planes)[*s + x][*s + res]"]
+    assert [l.split(" <- ")[0].split(" K=")[1] for l in lines[2:7]] == ["576", "864", "1152", "1440", "1728"]  # a conv_block reads every plane written before it
+    assert lines[32].startswith("dconv3x3(planes)[*s + res] M=6720 N=64 K=576 <- model.1.sub.2.weight")          # trunk conv + the first conv's output
+    assert lines[33].startswith("dconv3x3(planes)[nearest x2 in the loader][leaky_relu] M=26880 N=64 K=576 <- model.3.weight")
+    assert lines[34].startswith("dconv3x3(planes)[leaky_relu] M=26880") and lines[35].startswith("dconv3x3(planes)[rgb f32] M=26880 N=3 K=576 <- model.7.weight")
+    # without the model-kernel groups the f32 image conv has no lowering: said so, not guessed
+    g2 = G.Graph(None, G.Weights(tmp_path / "e.gguf"))
+    g2.set_fused_models(False)
+    G.esrgan_generate(G.ModelRef(g2), g2.input((3, 40, 56, 1), G.F32, "image"), cfg.scale, cfg.num_blocks)
+    with pytest.raises(L.Error, match="Cin = 3 must be a multiple of 8|read before it is computed|f32"):
+        g2.allocate()

@@ -23,7 +23,7 @@ T round_up(T x, T m) { return (x + m - 1) / m * m; }
 
 const char* const op_names[gop_count] = {"input", "weight", "linear", "layer_norm", "gelu", "relu", "scale", "add", "mul", "conv_2d",
                                          "conv_transpose_2d", "interpolate", "attention", "concat", "slice", "reshape", "repeat",
-                                         "patch_embed", "cont", "image_u8_to_f32", "image_normalize"};
+                                         "patch_embed", "cont", "image_u8_to_f32", "image_normalize", "leaky_relu"};
 
 std::string shape_str(const int64_t ne[4]) {
     char b[96];
@@ -364,6 +364,7 @@ int graph_add(graph& g, int32_t op, const int* src, int n_src, const int64_t* ip
             break;
         case gop_gelu:
         case gop_relu:
+        case gop_leaky_relu:
         case gop_scale:
         case gop_cont:
             need_src(1, 1);
@@ -392,6 +393,8 @@ int graph_add(graph& g, int32_t op, const int* src, int n_src, const int64_t* ip
             if (n.ne[1] <= 0 || n.ne[2] <= 0) throw except("conv_2d: the kernel does not fit the input");
             // a 1x1 convolution to ONE channel is a model's final map (depth-anything.cpp:91-94): kept in f32, like the static schedule's output
             if (w.ne[3] == 1 && w.ne[1] == 1 && w.ne[2] == 1 && stride == 1 && pad == 0) n.dtype = gdt_f32;
+            // ... and so is a 3x3 convolution to an RGB image (esrgan.cpp:75)
+            if (w.ne[3] == 3 && w.ne[1] == 3 && w.ne[2] == 3 && stride == 1 && pad == 1) n.dtype = gdt_f32;
         } break;
         case gop_conv_transpose_2d: {
             need_src(2, 3);
@@ -495,7 +498,10 @@ int graph_add(graph& g, int32_t op, const int* src, int n_src, const int64_t* ip
     if (op != gop_patch_embed && op != gop_image_u8_to_f32 && op != gop_image_normalize)
         for (int i = 0; i < n_src; ++i) {
             const bool head_tail = (op == gop_relu || op == gop_scale) && S(i).op != gop_input;
-            if (!S(i).constant && S(i).dtype != gdt_f16 && !head_tail) throw except("%s: operand %d is f32; only patch_embed reads the f32 input tensor", nm, i);
+            // (a 3x3 conv on the f32 image of <= 16 channels: the first conv of an image-to-image network, esrgan.cpp:58)
+            const bool image_conv = op == gop_conv_2d && i == 0 && S(0).op == gop_input && S(0).ne[0] <= 16 && S(1).ne[1] == 3 && S(1).ne[2] == 3 && n.ip[0] == 1 && n.ip[1] == 1;
+            if (!S(i).constant && S(i).dtype != gdt_f16 && !head_tail && !image_conv)
+                throw except("%s: operand %d is f32; only patch_embed and an image's first 3x3 conv read the f32 input tensor", nm, i);
         }
 
     bool all_const = true;
@@ -535,8 +541,10 @@ struct lowering {
         while (g.nodes[t].alias_of >= 0) t = g.nodes[t].alias_of;
         return t;
     }
-    int buf_of(int t) const {
-        const int b = g.nodes[root(t)].buffer;
+    int buf_of(int t) {
+        const int r = root(t);
+        if (g.nodes[r].buffer < 0 && planar.count(r)) planar_to_nhwc(r); // a reader outside the LDS-ring conv: the map as NHWC, once
+        const int b = g.nodes[r].buffer;
         if (b < 0) throw except("graph: tensor %d (%s) is read before it is computed", t, graph_op_name(g.nodes[t].op));
         return b;
     }
@@ -910,6 +918,219 @@ struct lowering {
         });
     }
 
+    // ---- maps kept as 32-channel PLANES ([plane][B * H * W][32] f16) -- the layout the LDS-ring conv was built on for the ESRGAN dense blocks
+    // (kernels_dconv.hip; profiles/r04_esrgan_layout_experiment.txt: 5 % faster than NHWC). Layout is this lowering's choice: a map is planar when
+    // the conv that writes it read a planar map (or the f32 image), every reader that is such a conv takes it as it is, and any other reader gets
+    // an NHWC copy made on first use. A channel concat of planar maps is then no launch at all: the dense block [x | x1 | x2 | x3 | x4] of
+    // esrgan.cpp:27-41 is six planes of ONE buffer, x written by its producer into planes 0-1, every conv_block into the plane behind its input.
+    struct planar_map { int buf; int plane0; int n_planes; int64_t plane_elems; };
+    std::map<int, planar_map> planar;                 // ROOT node -> where it lives
+    std::map<int, std::pair<int, int>> placed;        // node a concat chain will read -> (buffer, first plane) reserved for it
+    std::map<int, int> up2_of;                        // interpolate(NEAREST, x2) node -> its (planar) source, resized by the reading conv's loader
+    std::map<int, int> image_plane;                   // f32 image input -> buffer of its value | residue plane
+
+    void planar_to_nhwc(int r) {
+        graph_node& n = g.nodes[r];
+        const planar_map pm = planar.at(r);
+        materialise(r);
+        const int obuf = n.buffer;
+        auto sp = ptr(pm.buf), op = ptr(obuf);
+        const int64_t npix = pm.plane_elems / 32, C = n.ne[0], off = (int64_t)pm.plane0 * pm.plane_elems;
+        std::array<int64_t, 4> A{32, npix, pm.n_planes, 1}, S{1, 32, pm.plane_elems, 0}, D{1, C, 32, 0};
+        emit("planes_to_nhwc " + shape_str(n.ne), {pm.buf}, {obuf}, [=](void* st) { VX(vx_copy_strided_f16(sp() + off * 2, op(), A.data(), S.data(), D.data(), 1.0f, st)); });
+    }
+    static bool is_conv3x3(graph_node const& c, graph_node const& w) {
+        return c.op == gop_conv_2d && w.constant && w.ne[1] == 3 && w.ne[2] == 3 && c.ip[0] == 1 && c.ip[1] == 1;
+    }
+    // the LDS-ring conv's operand with the input columns repeated (`dup`: an image plane carries value | residue) and the outputs padded to `cout_pad`
+    void* pack_dconv_ex(int wt, int cin, int dup, int cout, int cout_pad, int* d_cin) {
+        const int n_in = dup ? 2 * cin : cin, dc = round_up(n_in, 32);
+        *d_cin = dc;
+        return cached(wt, 8, [&](bool st) {
+            std::vector<uint16_t> h((size_t)dc * 9 * cout_pad, 0);
+            const float* w = g.nodes[wt].values(); // [cout][ky][kx][cin]
+            for (int n = 0; n < cout; ++n)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int c = 0; c < n_in; ++c) {
+                        const size_t row = ((size_t)(c / 32) * 9 + tap) * cout_pad + n;
+                        h[row * 32 + (size_t)(((c % 32) / 8) ^ ((n >> 2) & 3)) * 8 + c % 8] = f32_to_f16(w[((size_t)n * 9 + tap) * cin + c % cin]);
+                    }
+            return upload(h.data(), h.size() * 2, st);
+        }, "dup" + std::to_string(dup) + "pad" + std::to_string(cout_pad));
+    }
+    float* bias_padded(int bt, int n_pad) {
+        return static_cast<float*>(cached(bt, 9, [&](bool st) {
+            std::vector<float> b((size_t)n_pad, 0.0f);
+            for (int64_t i = 0; i < g.nodes[bt].n_elements() && i < n_pad; ++i) b[(size_t)i] = g.nodes[bt].values()[i];
+            return upload(b.data(), b.size() * 4, st);
+        }, "pad" + std::to_string(n_pad)));
+    }
+    // interpolate(NEAREST) to exactly twice the extent of a planar map, read by one 3x3 conv: the conv's loader does it (esrgan.cpp:13-19)
+    bool nearest_into_reader(int t) {
+        graph_node const& n = g.nodes[t];
+        const int xs = root(n.src[0]);
+        graph_node const& x = g.nodes[xs];
+        if (!g.fused_models || (n.ip[2] & 255) != 0 || n.is_output || !planar.count(xs) || n.ne[1] != 2 * x.ne[1] || n.ne[2] != 2 * x.ne[2]) return false;
+        const int c = sole_consumer(t);
+        if (c < 0 || g.nodes[c].src[0] != t || !is_conv3x3(g.nodes[c], g.nodes[g.nodes[c].src[1]])) return false;
+        up2_of[t] = xs;
+        return true;
+    }
+    // A 3x3 / stride 1 / pad 1 conv on a planar map (or on the f32 image, or on the x2 nearest resize of a planar map) through the LDS-ring conv in
+    // its native layout, with esrgan.cpp's epilogues: LeakyReLU 0.2 or ReLU, then up to two [* scale] + residual steps (conv5 * 0.2 + x, and
+    // (.) * 0.2 + the rrdb's input, esrgan.cpp:38-40, 49-50), the skip x taken from the halo when it is the conv's own first 64 input channels;
+    // the RGB conv writes the f32 image. Returns false (nothing changed) when the conv is not of this kind.
+    bool planar_conv(int t, std::string const& who) {
+        graph_node& n = g.nodes[t];
+        if (!g.fused_models || !is_conv3x3(n, g.nodes[n.src[1]]) || (n.n_src == 3 && !g.nodes[n.src[2]].constant)) return false;
+        const int xs = n.src[0], xr = root(xs);
+        graph_node const& x = g.nodes[xr];
+        const int cin = (int)g.nodes[xs].ne[0], cout = (int)n.ne[0], H = (int)n.ne[2], W = (int)n.ne[1], B = (int)n.ne[3];
+        const bool rgb = cout == 3 && n.dtype == gdt_f32;
+        if (!rgb && !((cout == 32 || cout == 64) && n.dtype == gdt_f16)) return false;
+        const int64_t npix = (int64_t)B * H * W;
+        planar_map in{};
+        int up2 = 0, dup = 0;
+        if (auto it = up2_of.find(xs); it != up2_of.end()) {
+            in = planar.at(it->second);
+            up2 = 1;
+        } else if (planar.count(xr)) {
+            in = planar.at(xr);
+        } else if (x.op == gop_input && x.dtype == gdt_f32 && cin <= 16) {
+            auto it = image_plane.find(xr);
+            if (it == image_plane.end()) {
+                const int ibuf = buf_of(xr), pbuf = new_buffer((size_t)npix * 32 * 2);
+                auto ip = ptr(ibuf), pp = ptr(pbuf);
+                emit("image_planes " + shape_str(x.ne), {ibuf}, {pbuf}, [=](void* st) { VX(vx_image_planes_f32(reinterpret_cast<const float*>(ip()), pp(), npix, cin, st)); });
+                tag("image_in", 0, (double)npix * (cin * 4 + 64));
+                it = image_plane.emplace(xr, pbuf).first;
+            }
+            in = {it->second, 0, 1, npix * 32};
+            dup = cin;
+        } else return false;
+        if (!dup && cin % 32) return false;
+
+        // ---- the epilogue chain
+        int act = 0, last = t;
+        float s1 = 1.0f, s2 = 1.0f;
+        int res[2] = {-1, -1};
+        std::vector<int> absorbed;
+        {
+            int c = rgb ? -1 : sole_consumer(t);
+            if (c >= 0 && (g.nodes[c].op == gop_relu || (g.nodes[c].op == gop_leaky_relu && g.nodes[c].fp[0] == 0.2f))) {
+                act = g.nodes[c].op == gop_relu ? 2 : 1;
+                absorbed.push_back(c);
+                last = c;
+                c = sole_consumer(c);
+            }
+            for (int round = 0; round < 2 && c >= 0; ++round) {
+                float sc = 1.0f;
+                int sn = -1, a = c;
+                if (g.nodes[c].op == gop_scale) { sn = c; sc = g.nodes[c].fp[0]; a = sole_consumer(c); }
+                if (a < 0 || g.nodes[a].op != gop_add) break;
+                graph_node const& an = g.nodes[a];
+                const int prev = sn >= 0 ? sn : last;
+                const int other = an.src[0] == prev ? an.src[1] : (an.src[1] == prev ? an.src[0] : -1);
+                if (other < 0 || !planar.count(root(other)) || g.nodes[other].n_elements() != n.n_elements() || g.nodes[other].ne[0] != cout) break;
+                (round == 0 ? s1 : s2) = sc;
+                res[round] = root(other);
+                if (sn >= 0) absorbed.push_back(sn);
+                absorbed.push_back(a);
+                last = a;
+                c = sole_consumer(a);
+            }
+        }
+        for (int c : absorbed) {
+            skip[c] = 1;
+            g.nodes[c].alias_of = t;
+            if (g.nodes[c].is_output) n.is_output = true;
+        }
+
+        vx_dconv_args d;
+        memset(&d, 0, sizeof d);
+        int d_cin = 0;
+        d.w = (dup || rgb) ? pack_dconv_ex(n.src[1], cin, dup, cout, rgb ? 32 : cout, &d_cin) : pack_dconv(n.src[1], cin, cout, &d_cin);
+        d.bias = n.n_src == 3 ? (rgb ? bias_padded(n.src[2], 32) : const_f32(n.src[2])) : nullptr;
+        d.cin = d_cin; d.cout = rgb ? 32 : cout;
+        d.up2 = up2;
+        d.B = B; d.H = H; d.W = W;
+        d.epi = rgb ? VX_DC_RGB_F32 : VX_DC_F16;
+        d.act = act;
+        d.s1 = s1; d.s2 = s2;
+        d.x_plane = in.plane_elems;
+        const int64_t x_off = (int64_t)in.plane0 * in.plane_elems;
+        std::vector<int> reads = {in.buf};
+        std::function<char*()> rp[2];
+        int64_t r_off[2] = {0, 0};
+        for (int i = 0; i < 2; ++i) {
+            if (res[i] < 0) continue;
+            planar_map const& rm = planar.at(res[i]);
+            if (i == 0 && !up2 && cout == 64 && rm.buf == in.buf && rm.plane0 == in.plane0 && in.n_planes >= 2 && s1 != 0.0f) { d.x_residual = 1; continue; } // x = the halo's first two planes
+            reads.push_back(rm.buf);
+            rp[i] = ptr(rm.buf);
+            r_off[i] = (int64_t)rm.plane0 * rm.plane_elems;
+            (i == 0 ? d.res1_plane : d.res2_plane) = rm.plane_elems;
+        }
+
+        // ---- where the result goes
+        int obuf;
+        int64_t o_off = 0;
+        if (rgb) {
+            materialise(t);
+            obuf = n.buffer;
+        } else {
+            planar_map om{-1, 0, cout / 32, npix * 32};
+            if (auto it = placed.find(last); it != placed.end()) { om.buf = it->second.first; om.plane0 = it->second.second; }
+            else {
+                // the head of a concat chain along the channels: reserve the whole dense block and the slots of the maps that will join it
+                std::vector<std::pair<int, int>> joins; // (concat node, second operand)
+                int cur = last, width = cout;
+                for (;;) {
+                    int cc = -1;
+                    for (int c : consumers[cur])
+                        if (g.nodes[c].op == gop_concat && g.nodes[c].ip[0] == 0 && g.nodes[c].src[0] == cur && !g.nodes[c].is_output) { cc = c; break; }
+                    if (cc < 0) break;
+                    const int s2n = g.nodes[cc].src[1];
+                    graph_node const& sn = g.nodes[s2n];
+                    const bool act_of_conv = (sn.op == gop_leaky_relu || sn.op == gop_relu) && !sn.constant && is_conv3x3(g.nodes[sn.src[0]], g.nodes[g.nodes[sn.src[0]].src[1]]) && uses[sn.src[0]] == 1;
+                    const bool conv_itself = !sn.constant && sn.op == gop_conv_2d && is_conv3x3(sn, g.nodes[sn.src[1]]);
+                    if (!(act_of_conv || conv_itself) || uses[s2n] != 1 || sn.is_output || sn.ne[0] % 32 || s2n < cur) break;
+                    joins.emplace_back(cc, s2n);
+                    width += (int)sn.ne[0];
+                    cur = cc;
+                }
+                om.buf = new_buffer((size_t)npix * width * 2, n.is_output);
+                int at = cout / 32;
+                for (auto const& j : joins) {
+                    placed[j.second] = {om.buf, at};
+                    at += (int)g.nodes[j.second].ne[0] / 32;
+                    planar[j.first] = {om.buf, 0, at, npix * 32};
+                    skip[j.first] = 1;
+                }
+            }
+            planar[t] = om;
+            obuf = om.buf;
+            o_off = (int64_t)om.plane0 * om.plane_elems;
+            d.out_plane = om.plane_elems;
+        }
+        char desc[320];
+        snprintf(desc, sizeof desc, "dconv3x3(planes)%s%s%s%s%s%s M=%lld N=%d K=%d <- %s", dup ? "[f32 image]" : "", up2 ? "[nearest x2 in the loader]" : "",
+                 act == 1 ? "[leaky_relu]" : (act == 2 ? "[relu]" : ""), res[0] >= 0 ? (d.x_residual ? "[*s + x]" : "[*s + res]") : "", res[1] >= 0 ? "[*s + res]" : "", rgb ? "[rgb f32]" : "",
+                 (long long)npix, cout, 9 * cin, who.c_str());
+        auto xp = ptr(in.buf), op = ptr(obuf);
+        emit(desc, reads, {obuf}, [=](void* st) {
+            vx_dconv_args r = d;
+            r.x = xp() + x_off * 2;
+            r.out = op() + o_off * 2;
+            if (rp[0]) r.res1 = rp[0]() + r_off[0] * 2;
+            if (rp[1]) r.res2 = rp[1]() + r_off[1] * 2;
+            VX(vx_dconv3x3_f16(&r, st));
+        });
+        tag(rgb ? "conv_rgb" : (dup ? "conv_first" : (up2 ? "upconv" : "conv")), 2.0 * npix * (double)cout * 9 * cin, (double)npix * ((up2 ? 0.25 : 1.0) * d_cin * 2 + (rgb ? 12 : cout * 2)));
+        if (!rgb && n.is_output) planar_to_nhwc(t); // a graph output is read back as NHWC
+        return true;
+    }
+
     // the residual-unit kernel's operand: [taps][64 n][64 c] f16, the 16-byte groups of row n at position g ^ ((n >> 1) & 7) (kernels_rcu.hip)
     void* pack_rcu(int wt, int taps) {
         return cached(wt, 7, [&](bool st) {
@@ -1009,6 +1230,11 @@ struct lowering {
 
     void gemm_like(int t) {
         graph_node& n = g.nodes[t];
+        {
+            std::string w0 = g.nodes[n.src[1]].op == gop_weight && !g.nodes[n.src[1]].name.empty() ? g.nodes[n.src[1]].name : n.name;
+            if (n.op == gop_conv_2d && planar_conv(t, w0)) return;
+        }
+        if (n.op == gop_conv_2d && n.dtype == gdt_f32 && n.ne[0] != 1) throw except("conv_2d %s to an f32 image of %lld channels is lowered onto the LDS-ring conv only (3x3 / stride 1 / pad 1 behind planar maps)", n.name.c_str(), (long long)n.ne[0]);
         if (n.op == gop_conv_2d && n.dtype == gdt_f32) return one_channel_head(t);
         const int xs = n.src[0], wt = n.src[1], bt = n.n_src == 3 ? n.src[2] : -1;
         graph_node const& x = g.nodes[xs];
@@ -1789,6 +2015,7 @@ struct lowering {
                 }
                     [[fallthrough]];
                 case gop_gelu:
+                case gop_leaky_relu:
                 case gop_scale: {
                     if (n.dtype != gdt_f16) throw except("%s on the f32 map of a one-channel head that has other readers is not built", graph_op_name(n.op));
                     const int xbuf = buf_of(n.src[0]);
@@ -1796,7 +2023,7 @@ struct lowering {
                     const int obuf = n.buffer;
                     auto xp = ptr(xbuf), op = ptr(obuf);
                     const int64_t cnt = n.n_elements();
-                    const int uop = n.op == gop_gelu ? 0 : (n.op == gop_relu ? 1 : 2);
+                    const int uop = n.op == gop_gelu ? 0 : (n.op == gop_relu ? 1 : (n.op == gop_leaky_relu ? 3 : 2));
                     const float s = n.fp[0];
                     emit(std::string(graph_op_name(n.op)) + " n=" + std::to_string(cnt), {xbuf}, {obuf}, [=](void* st) { VX(vx_unary_f16(uop, xp(), op(), cnt, s, st)); });
                 } break;
@@ -1835,6 +2062,20 @@ struct lowering {
                     tag("layernorm", 0, (double)rows * C * 4);
                 } break;
                 case gop_interpolate: {
+                    if (nearest_into_reader(t)) break;
+                    if ((n.ip[2] & 255) == 0) { // NEAREST on its own
+                        graph_node const& x = g.nodes[n.src[0]];
+                        if (x.ne[0] % 8) throw except("interpolate: %lld channels (a multiple of 8)", (long long)x.ne[0]);
+                        const int xbuf = buf_of(n.src[0]);
+                        materialise(t);
+                        const int obuf = n.buffer;
+                        auto xp = ptr(xbuf), op = ptr(obuf);
+                        const int B = (int)x.ne[3], H = (int)x.ne[2], W = (int)x.ne[1], C = (int)x.ne[0], OH = (int)n.ne[2], OW = (int)n.ne[1];
+                        char d[128];
+                        snprintf(d, sizeof d, "nearest %dx%d -> %dx%d C=%d", W, H, OW, OH, C);
+                        emit(d, {xbuf}, {obuf}, [=](void* st) { VX(vx_nearest_f16(xp(), op(), B, H, W, C, OH, OW, st)); });
+                        break;
+                    }
                     if (!n.is_output && head_tail(t)) break;
                     if (resize_into_reader(t)) break;
                     graph_node const& x = g.nodes[n.src[0]];

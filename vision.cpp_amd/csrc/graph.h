@@ -51,6 +51,7 @@ enum graph_op : int32_t {
     // extensions for callers that keep images in HBM (the batched entries of this library); the reference does both steps on the host
     gop_image_u8_to_f32,  // x u8 [3, W, H, N] -> f32: (x / 255 - f0..f2) * f3..f5     image.cpp:215-255 as depthany_process_input calls it
     gop_image_normalize,  // x f32 [1, W, H, N] -> f32: per-image min-max to [0, 1]     image.cpp:537-582 (depthany_process_output)
+    gop_leaky_relu,       // f0 = negative slope                         ggml_leaky_relu (esrgan.cpp:17, 24)
     gop_count
 };
 const char* graph_op_name(int32_t op);

@@ -92,14 +92,52 @@ __global__ __launch_bounds__(256) void unary_kernel(const f16* __restrict__ x, f
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float f = (float)v[j];
-            v[j] = (f16)(OP == 0 ? gelu_tanh_g(f) : (OP == 1 ? fmaxf(f, 0.0f) : f * s));
+            v[j] = (f16)(OP == 0 ? gelu_tanh_g(f) : (OP == 1 ? fmaxf(f, 0.0f) : (OP == 3 ? fmaxf(f, f * s) : f * s)));
         }
         *reinterpret_cast<f16x8*>(y + i * 8) = v;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { // tail
         const long i = (n8 << 3) + threadIdx.x;
         const float f = (float)x[i];
-        y[i] = (f16)(OP == 0 ? gelu_tanh_g(f) : (OP == 1 ? fmaxf(f, 0.0f) : f * s));
+        y[i] = (f16)(OP == 0 ? gelu_tanh_g(f) : (OP == 1 ? fmaxf(f, 0.0f) : (OP == 3 ? fmaxf(f, f * s) : f * s)));
+    }
+}
+
+// ggml_interpolate(NEAREST) on an NHWC f16 map (ml.cpp:782-788 -> ggml upscale: source index = floor(i / (out / in))); 8 channels per thread
+__global__ __launch_bounds__(256) void nearest_kernel(const f16* __restrict__ x, f16* __restrict__ y, int H, int W, int C8, int OH, int OW, float sy, float sx, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        long p = i / C8;
+        const int ox = (int)(p % OW);
+        p /= OW;
+        const int oy = (int)(p % OH);
+        const long b = p / OH;
+        const int iy = min((int)floorf((float)oy / sy), H - 1), ix = min((int)floorf((float)ox / sx), W - 1);
+        *reinterpret_cast<f16x8*>(y + i * 8) = *reinterpret_cast<const f16x8*>(x + (((b * H + iy) * W + ix) * C8 + c) * 8);
+    }
+}
+
+// An f32 image [pixels][C], C <= 16, as ONE 32-channel f16 plane for the LDS-ring conv: channels 0..C-1 the values rounded to f16, channels C..2C-1 what
+// the rounding dropped (x - f16(x), itself exact in f16 for an image in [0, 1]), the rest zero. The conv's operand repeats its C input columns, so the
+// products see the f32 image (what csrc/esrgan.cpp's tile loader does for the u8 image).
+__global__ __launch_bounds__(256) void image_planes_kernel(const float* __restrict__ x, f16* __restrict__ y, int C, long n_pix) {
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < n_pix; p += (long)gridDim.x * 256) {
+        f16 v[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = (f16)0;
+        for (int c = 0; c < C; ++c) {
+            const float f = x[p * C + c];
+            const f16 hi = (f16)f;
+            v[c] = hi;
+            v[C + c] = (f16)(f - (float)hi);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = v[q * 8 + j];
+            *reinterpret_cast<f16x8*>(y + p * 32 + q * 8) = o;
+        }
     }
 }
 
@@ -224,8 +262,24 @@ extern "C" int vx_unary_f16(int op, const void* x, void* y, int64_t n, float s, 
         case 0: hipLaunchKernelGGL(unary_kernel<0>, g, t, 0, as_stream(stream), (const f16*)x, (f16*)y, (long)n, s); break;
         case 1: hipLaunchKernelGGL(unary_kernel<1>, g, t, 0, as_stream(stream), (const f16*)x, (f16*)y, (long)n, s); break;
         case 2: hipLaunchKernelGGL(unary_kernel<2>, g, t, 0, as_stream(stream), (const f16*)x, (f16*)y, (long)n, s); break;
-        default: VX_REQUIRE(false, "vx_unary_f16: op %d (0 gelu, 1 relu, 2 scale)", op);
+        case 3: hipLaunchKernelGGL(unary_kernel<3>, g, t, 0, as_stream(stream), (const f16*)x, (f16*)y, (long)n, s); break;
+        default: VX_REQUIRE(false, "vx_unary_f16: op %d (0 gelu, 1 relu, 2 scale, 3 leaky relu)", op);
     }
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+extern "C" int vx_nearest_f16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, void* stream) {
+    VX_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 8 == 0, "vx_nearest_f16: bad operands (C a multiple of 8)");
+    const long n = (long)B * OH * OW * (C / 8);
+    hipLaunchKernelGGL(nearest_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), (const f16*)x, (f16*)y, H, W, C / 8, OH, OW, (float)OH / (float)H, (float)OW / (float)W, n);
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+extern "C" int vx_image_planes_f32(const float* x, void* y, int64_t n_pix, int C, void* stream) {
+    VX_REQUIRE(x && y && n_pix > 0 && C >= 1 && C <= 16, "vx_image_planes_f32: 1..16 channels");
+    hipLaunchKernelGGL(image_planes_kernel, dim3(blocks_for(n_pix)), dim3(256), 0, as_stream(stream), x, (f16*)y, C, (long)n_pix);
     VX_LAUNCH_CHECK();
     return 1;
 }

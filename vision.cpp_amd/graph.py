@@ -20,8 +20,8 @@ from ._lib import check, get_lib
 
 F32, F16, U8 = 0, 1, 24
 (OP_LINEAR, OP_LAYER_NORM, OP_GELU, OP_RELU, OP_SCALE, OP_ADD, OP_MUL, OP_CONV_2D, OP_CONV_TRANSPOSE_2D, OP_INTERPOLATE, OP_ATTENTION,
- OP_CONCAT, OP_SLICE, OP_RESHAPE, OP_REPEAT, OP_PATCH_EMBED, OP_CONT, OP_IMAGE_U8_TO_F32, OP_IMAGE_NORMALIZE) = range(2, 21)
-SCALE_MODE_BILINEAR, SCALE_MODE_BICUBIC, SCALE_FLAG_ALIGN_CORNERS = 1, 2, 256  # ggml's values (ml.cpp:782-788)
+ OP_CONCAT, OP_SLICE, OP_RESHAPE, OP_REPEAT, OP_PATCH_EMBED, OP_CONT, OP_IMAGE_U8_TO_F32, OP_IMAGE_NORMALIZE, OP_LEAKY_RELU) = range(2, 22)
+SCALE_MODE_NEAREST, SCALE_MODE_BILINEAR, SCALE_MODE_BICUBIC, SCALE_FLAG_ALIGN_CORNERS = 0, 1, 2, 256  # ggml's values (ml.cpp:782-788)
 SLICE_ALL = (0, 2**62, 1)
 
 
@@ -288,6 +288,7 @@ def scale(m, x, s): return m.graph.op(OP_SCALE, [x], fparams=[s])
 def reshape(m, x, *ne): return m.graph.op(OP_RESHAPE, [x], list(_ne(ne)))
 def repeat(m, x, *ne): return m.graph.op(OP_REPEAT, [x], list(_ne(ne)))
 def cont(m, x): return m.graph.op(OP_CONT, [x])
+def leaky_relu(m, x, slope): return m.graph.op(OP_LEAKY_RELU, [x], fparams=[slope])  # ggml_leaky_relu
 
 
 # ---- Depth-Anything-V2 against this layer (the structure of src/visp/arch/dino.cpp + depth-anything.cpp) -----------------------
@@ -397,3 +398,54 @@ def depthany_predict(m: ModelRef, image: Tensor, n_layers: int, n_heads: int, pa
     fused = dpt_neck(m["neck"], features, w // patch_size, h // patch_size)
     depth = dpt_head(m["head"], fused, w, h, max_depth)
     return m.graph.output(depth, "output")
+
+
+# ---- ESRGAN / Real-ESRGAN against this layer (the structure of src/visp/arch/esrgan.cpp) ---------------------------------------------------
+
+def esrgan_upsample(m: ModelRef, x: Tensor) -> Tensor:  # esrgan.cpp:13-19
+    c, w, h, n = x.ne
+    x = interpolate(m, x, (w * 2, h * 2), SCALE_MODE_NEAREST)
+    x = conv_2d(m, x, 1, 1)
+    return named(m, leaky_relu(m, x, 0.2))
+
+
+def esrgan_conv_block(m: ModelRef, x: Tensor) -> Tensor:  # esrgan.cpp:21-25
+    return leaky_relu(m, conv_2d(m[0], x, 1, 1), 0.2)
+
+
+def esrgan_residual_dense_block(m: ModelRef, x: Tensor) -> Tensor:  # esrgan.cpp:27-41 (channels are dimension 0 of a CWHN tensor)
+    x1 = esrgan_conv_block(m["conv1"], x)
+    c1 = concat(m, [x, x1], 0)
+    x2 = esrgan_conv_block(m["conv2"], c1)
+    c2 = concat(m, [c1, x2], 0)
+    x3 = esrgan_conv_block(m["conv3"], c2)
+    c3 = concat(m, [c2, x3], 0)
+    x4 = esrgan_conv_block(m["conv4"], c3)
+    c4 = concat(m, [c3, x4], 0)
+    x5 = scale(m, conv_2d(m["conv5.0"], c4, 1, 1), 0.2)
+    return named(m, add(m, x, x5))
+
+
+def esrgan_rrdb(m: ModelRef, x: Tensor) -> Tensor:  # esrgan.cpp:43-51
+    x_in = x
+    for k in (1, 2, 3):
+        x = esrgan_residual_dense_block(m[f"RDB{k}"], x)
+    return named(m, add(m, scale(m, x, 0.2), x_in))
+
+
+def esrgan_generate(m: ModelRef, x: Tensor, scale_factor: int, n_blocks: int) -> Tensor:  # esrgan.cpp:55-79; x = the f32 image [3, W, H, N]
+    m = m["model"]
+    x = conv_2d(m[0], x, 1, 1)
+    sub = x
+    block = m[1]["sub"]
+    for i in range(n_blocks):
+        sub = esrgan_rrdb(block[i], sub)
+    sub = conv_2d(block[n_blocks], sub, 1, 1)
+    x = add(m, x, sub)
+    seq = 2
+    for _ in range(int(np.log2(scale_factor))):
+        x = esrgan_upsample(m[seq + 1], x)
+        seq += 3
+    x = leaky_relu(m, conv_2d(m[seq], x, 1, 1), 0.2)
+    x = conv_2d(m[seq + 2], x, 1, 1)
+    return m.graph.output(x, "result")
