@@ -54,6 +54,7 @@ inline tensor mul(model_ref const& m, tensor a, tensor b) { return detail::op(m,
 inline tensor gelu(model_ref const& m, tensor x) { return detail::op(m, VISP_OP_GELU, {x}); }
 inline tensor relu(model_ref const& m, tensor x) { return detail::op(m, VISP_OP_RELU, {x}); }
 inline tensor scale(model_ref const& m, tensor x, float s) { return detail::op(m, VISP_OP_SCALE, {x}, {}, {s}); }
+inline tensor leaky_relu(model_ref const& m, tensor x, float negative_slope) { return detail::op(m, VISP_OP_LEAKY_RELU, {x}, {}, {negative_slope}); }
 inline tensor cont(model_ref const& m, tensor x) { return detail::op(m, VISP_OP_CONT, {x}); }
 inline tensor reshape_4d(model_ref const& m, tensor x, int64_t n0, int64_t n1, int64_t n2, int64_t n3) { return detail::op(m, VISP_OP_RESHAPE, {x}, {n0, n1, n2, n3}); }
 inline tensor reshape_3d(model_ref const& m, tensor x, int64_t n0, int64_t n1, int64_t n2) { return reshape_4d(m, x, n0, n1, n2, 1); }
@@ -89,6 +90,8 @@ inline tensor ggml_gelu(model_ref const& m, tensor x) { return gelu(m, x); }
 inline tensor ggml_relu(model_ref const& m, tensor x) { return relu(m, x); }
 inline tensor ggml_relu_inplace(model_ref const& m, tensor x) { return relu(m, x); }
 inline tensor ggml_scale(model_ref const& m, tensor x, float s) { return scale(m, x, s); }
+inline tensor ggml_scale_inplace(model_ref const& m, tensor x, float s) { return scale(m, x, s); }
+inline tensor ggml_leaky_relu(model_ref const& m, tensor x, float negative_slope, bool /*inplace*/) { return leaky_relu(m, x, negative_slope); }
 inline tensor ggml_cont(model_ref const& m, tensor x) { return cont(m, x); }
 inline tensor ggml_reshape_3d(model_ref const& m, tensor x, int64_t n0, int64_t n1, int64_t n2) { return reshape_3d(m, x, n0, n1, n2); }
 inline tensor ggml_reshape_4d(model_ref const& m, tensor x, int64_t n0, int64_t n1, int64_t n2, int64_t n3) { return reshape_4d(m, x, n0, n1, n2, n3); }

@@ -206,6 +206,11 @@ struct depthany_params {
     std::array<int, 4> feature_layers = {2, 5, 8, 11};
     dino_params dino;
 };
+// --- ESRGAN pipeline (vision.h:294-304): scale factor and number of RRDB blocks, from the GGUF keys esrgan.scale / esrgan.block_count
+struct esrgan_params {
+    int scale = 4;
+    int n_blocks = 23;
+};
 #ifdef VISP_ARCH_FROM_SOURCE
 // the reference's own definitions (src/visp/arch/depth-anything.cpp:112-149) are part of the build
 i32x2 depthany_image_extent(i32x2 input_extent, depthany_params const&);

@@ -1,5 +1,5 @@
 """Row b3 of SURVEY section 8 (the executor boundary the reference's arch code is written against), checked instead of claimed: the
-reference's own src/visp/arch/dino.cpp and src/visp/arch/depth-anything.cpp are compiled WHERE THEY LIE, unmodified, against this
+reference's own src/visp/arch/dino.cpp, src/visp/arch/depth-anything.cpp and (round 4) src/visp/arch/esrgan.cpp are compiled WHERE THEY LIE, unmodified, against this
 repository's include tree (include/visp/{ml,nn,vision,builders}.h, include/visp/arch/*.h forwarders, include/util/*.h), linked with
 lib/libvisioncpp.so, and run: Depth-Anything built by the reference's depthany_predict lowers to the same launch list as the graph the
 Python face builds for the same file, and the reference's process_input / process_output / image_extent agree with this backend's.
@@ -20,13 +20,14 @@ from visioncpp_amd import synth, vision
 ROOT = Path(__file__).resolve().parents[1]
 REF = Path("/root/reference/src/visp/arch")
 SOURCES = [REF / "dino.cpp", REF / "depth-anything.cpp"]
+ESRGAN_SOURCE = REF / "esrgan.cpp"
 FLAGS = ["-std=c++20", "-O1", "-Wall", "-DVISP_GGML_NAMES", "-DVISP_ARCH_FROM_SOURCE", "-I", str(ROOT / "include")]
 
 pytestmark = pytest.mark.skipif(not all(s.exists() for s in SOURCES), reason="the reference tree is only present in the build container")
 
 
 def test_reference_arch_sources_pass_the_front_end_unmodified():
-    for src in SOURCES:
+    for src in SOURCES + [ESRGAN_SOURCE]:
         r = subprocess.run(["g++", *FLAGS, "-fsyntax-only", str(src)], capture_output=True, text=True)
         assert r.returncode == 0 and "warning" not in r.stderr, f"{src.name}:\n{r.stderr}"
 
@@ -107,3 +108,44 @@ def test_host_steps_of_the_reference_sources_agree_with_the_library(driver, tmp_
     back = vision.image_scale(norm.reshape(ext[1], ext[0]), w, h, vision.ImageFormat.alpha_f32)
     s_out = float(got["process_output"].split("sum=")[1])
     assert got["process_output"].startswith(f"process_output {w}x{h} ") and abs(s_out - float(back.astype(np.float64).sum())) < 1e-3 * back.size
+
+
+# ---- the ESRGAN generator (round 4: leaky_relu, NEAREST interpolate, channel concat, scale / add chains in the graph layer) --------------------------
+
+@pytest.fixture(scope="module")
+def esrgan_driver(tmp_path_factory):
+    """esrgan.o from the reference source + tests/cpp/esrgan_source_driver.cpp + libvisioncpp.so"""
+    out = tmp_path_factory.mktemp("esrgan_from_source")
+    obj = out / "esrgan.o"
+    subprocess.run(["g++", *FLAGS, "-c", str(ESRGAN_SOURCE), "-o", str(obj)], check=True)
+    exe = out / "esrgan_source_driver"
+    lib_dir = ROOT / "vision.cpp_amd" / "lib"
+    subprocess.run(["g++", *FLAGS, str(ROOT / "tests" / "cpp" / "esrgan_source_driver.cpp"), str(obj), "-o", str(exe), "-L", str(lib_dir), "-lvisioncpp",
+                    f"-Wl,-rpath,{lib_dir}"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("cfg_name,tile", [("ESRGAN_TINY", (40, 56, 3)), ("ESRGAN_X4", (48, 32, 2))])
+def test_esrgan_built_by_the_reference_source(esrgan_driver, tmp_path, cfg_name, tile):
+    """esrgan_detect_params + esrgan_generate as src/visp/arch/esrgan.cpp defines them: the graph they build lowers to the launch list of the graph the
+    Python face builds for the same file -- the planar dense-block schedule (tests/test_graph_cpu.py says what that list is)."""
+    cfg = getattr(synth, cfg_name)
+    path = tmp_path / "e.gguf"
+    synth.write_esrgan_gguf(path, cfg, 7)
+    w, h, n = tile
+    r = subprocess.run([str(esrgan_driver), str(path), str(w), str(h), str(n)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == f"arch=esrgan scale={cfg.scale} blocks={cfg.num_blocks} graph_size={512 + cfg.num_blocks * 192}"
+    assert lines[1] == f"result ne=3,{w * cfg.scale},{h * cfg.scale},{n}"
+    g = G.Graph(None, G.Weights(path))
+    G.esrgan_generate(G.ModelRef(g), g.input((3, w, h, n), G.F32), cfg.scale, cfg.num_blocks)
+    g.allocate()
+    got, ref = [ln for ln in lines[2:] if ln.strip()], g.describe().strip().splitlines()
+    assert got == ref and len(got) == 1 + 1 + 15 * cfg.num_blocks + 1 + int(np.log2(cfg.scale)) + 2 + 1
+
+
+def test_esrgan_detect_params_refuses_another_architecture(esrgan_driver, tmp_path):
+    path = synth.write_gguf(tmp_path / "m.gguf", synth.MINI, seed=3)
+    r = subprocess.run([str(esrgan_driver), str(path), "16", "16", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Architecture expected to be 'esrgan', but was 'depthanything'" in r.stderr
