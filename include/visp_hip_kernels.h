@@ -195,6 +195,8 @@ typedef struct { int image_w, image_h, overlap_x, overlap_y, n_x, n_y, tile_w, t
 /* image_u8_to_f32 with tile offset for every tile (vision.cpp:236-241) -> one plane f16 [B*n_tiles, tile_h, tile_w, 32]
  * (channels 0..2 = value, 3..5 = f16 rounding residue, rest 0). format = visp::image_format (u8 colour). */
 VX_API int vx_esrgan_tiles_in(const uint8_t* img, int B, int w, int h, int format, const vx_tile_layout* t, void* out, void* stream);
+/* the same tiles as f32 rgb [B*n_tiles, tile_h, tile_w, 3]: the input tensor of the generator's graph (which splits it into value | residue itself) */
+VX_API int vx_esrgan_tiles_in_f32(const uint8_t* img, int B, int w, int h, int format, const vx_tile_layout* t, float* out, void* stream);
 /* tile_merge of all tiles in the reference's order + image_f32_to_u8 rgba (image.cpp:653-693, vision.cpp:246-252).
  * tiles: f32 [B, n_y, n_x, tile_h, tile_w, 3] (t = the SCALED layout); out_f32 [B,h,w,3] and/or out_rgba [B,h,w,4]. */
 VX_API int vx_esrgan_tiles_out(const float* tiles, int B, const vx_tile_layout* t, float* out_f32, uint8_t* out_rgba, void* stream);

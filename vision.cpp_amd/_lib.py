@@ -125,7 +125,7 @@ KERNEL_SYMBOLS = [
     "vx_last_error", "vx_device_count", "vx_set_device", "vx_device_info", "vx_malloc", "vx_free", "vx_memset",
     "vx_memcpy_h2d", "vx_memcpy_d2h", "vx_memcpy_d2d", "vx_malloc_host", "vx_free_host", "vx_memcpy_h2d_async", "vx_memcpy_d2h_async", "vx_event_sync", "vx_stream_create", "vx_stream_destroy", "vx_stream_sync",
     "vx_event_create", "vx_event_destroy", "vx_event_record", "vx_event_elapsed_ms", "vx_stream_wait_event", "vx_graph_begin_capture",
-    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_gemm_pick_k_splits", "vx_gemm_fp8_supported", "vx_gemm_fp8", "vx_quantize_rows_e4m3", "vx_quantize_rows_e4m3_host", "vx_conv3x3_supported", "vx_conv3x3_f16", "vx_rcu_supported", "vx_rcu_fused_f16", "vx_nearest_f16", "vx_image_planes_f32",
+    "vx_graph_end_capture", "vx_graph_launch", "vx_graph_destroy", "vx_gemm_f16", "vx_gemm_pick_k_splits", "vx_gemm_fp8_supported", "vx_gemm_fp8", "vx_quantize_rows_e4m3", "vx_quantize_rows_e4m3_host", "vx_conv3x3_supported", "vx_conv3x3_f16", "vx_rcu_supported", "vx_rcu_fused_f16", "vx_nearest_f16", "vx_image_planes_f32", "vx_esrgan_tiles_in_f32",
     "vx_attention_f16", "vx_attention_set_fast_limit", "vx_attention_set_stamps",
     "vx_layernorm_f32_f16", "vx_preprocess_patches", "vx_preprocess_f32", "vx_write_cls_rows", "vx_bilinear_ac_f16",
     "vx_head_out_f32", "vx_minmax_normalize", "vx_f32_to_u8",

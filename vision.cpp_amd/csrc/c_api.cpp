@@ -466,8 +466,8 @@ int32_t visp_esrgan_get_info(visp_model const* m, visp_esrgan_info* out) {
         esrgan_model const& em = as_esrgan(const_cast<visp_model*>(m));
         out->scale = em.params.scale;
         out->n_blocks = em.params.n_blocks;
-        out->n_filters = em.weights.nf;
-        out->growth = em.weights.gc;
+        out->n_filters = em.nf;
+        out->growth = em.gc;
         out->tile_group = em.tile_group;
     });
 }

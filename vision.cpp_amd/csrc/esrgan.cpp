@@ -7,6 +7,7 @@
 #include <map>
 
 #include "../../include/visp_hip_kernels.h"
+#include "graph.h"
 #include "visp_util.h"
 
 namespace visp {
@@ -74,73 +75,68 @@ int log2_floor(int x) { // src/util/math.h:24-31 (integer log2 of the scale)
 }
 
 //
-// weight packing
+// the generator as a graph: the nodes of the reference's esrgan_generate (src/visp/arch/esrgan.cpp:13-79), one node per call it makes. csrc/graph.cpp
+// lowers them onto the LDS-ring conv in its planar layout -- the f32 image as a value | residue plane, a dense block as six planes of one buffer (concat is
+// no launch), LeakyReLU / * 0.2 + x / (.) * 0.2 + rrdb input as epilogues, the x2 resize in the up-conv's loader, the last conv straight to f32 RGB -- which
+// is the schedule this file issued by hand in rounds 1-3 (tests/test_graph_cpu.py holds the list).
 
-struct arena_builder {
-    std::vector<uint8_t> data;
-    size_t alloc(size_t bytes) {
-        size_t off = round_up<size_t>(data.size(), 256);
-        data.resize(off + bytes, 0);
-        return off;
+struct generator_builder {
+    graph& g;
+    int weight(std::string const& name) const {
+        const int t = graph_find_weight(g, name.c_str());
+        if (t < 0) throw except("tensor not found: %s", name.c_str());
+        return t;
+    }
+    int node(int32_t op, std::vector<int> const& src, std::vector<int64_t> const& ip = {}, std::vector<float> const& fp = {}) const {
+        return graph_add(g, op, src.data(), (int)src.size(), ip.data(), (int)ip.size(), fp.data(), (int)fp.size());
+    }
+    int conv(std::string const& mod, int x) const { // conv_2d(m, x, 1, 1): 3x3, stride 1, pad 1, bias if the file has one
+        const int b = graph_find_weight(g, (mod + ".bias").c_str());
+        return b >= 0 ? node(gop_conv_2d, {x, weight(mod + ".weight"), b}, {1, 1}) : node(gop_conv_2d, {x, weight(mod + ".weight")}, {1, 1});
+    }
+    int lrelu(int x) const { return node(gop_leaky_relu, {x}, {}, {0.2f}); }
+    int conv_block(std::string const& mod, int x) const { return lrelu(conv(mod + ".0", x)); }                  // esrgan.cpp:21-25
+    int dense_block(std::string const& mod, int x) const {                                                      // esrgan.cpp:27-41
+        int c = x;
+        for (int k = 1; k <= 4; ++k) c = node(gop_concat, {c, conv_block(mod + ".conv" + std::to_string(k), c)}, {0});
+        const int x5 = node(gop_scale, {conv(mod + ".conv5.0", c)}, {}, {0.2f});
+        return node(gop_add, {x, x5});
+    }
+    int rrdb(std::string const& mod, int x) const {                                                             // esrgan.cpp:43-51
+        int y = x;
+        for (int r = 1; r <= 3; ++r) y = dense_block(mod + ".RDB" + std::to_string(r), y);
+        return node(gop_add, {node(gop_scale, {y}, {}, {0.2f}), x});
+    }
+    int build(int image, esrgan_params const& P) const {                                                        // esrgan.cpp:55-79
+        int x = conv("model.0", image);
+        int sub = x;
+        for (int i = 0; i < P.n_blocks; ++i) sub = rrdb("model.1.sub." + std::to_string(i), sub);
+        sub = conv("model.1.sub." + std::to_string(P.n_blocks), sub);
+        x = node(gop_add, {x, sub});
+        int seq = 2;
+        for (int i = 0; i < log2_floor(P.scale); ++i) {                                                         // esrgan::upsample, esrgan.cpp:13-19
+            x = node(gop_interpolate, {x}, {g.nodes[x].ne[1] * 2, g.nodes[x].ne[2] * 2, 0});
+            x = lrelu(conv("model." + std::to_string(seq + 1), x));
+            seq += 3;
+        }
+        x = lrelu(conv("model." + std::to_string(seq), x));
+        return conv("model." + std::to_string(seq + 2), x);
     }
 };
 
-float tensor_at(gguf_tensor const& t, size_t i) {
-    if (t.type == GGML_F32) return reinterpret_cast<const float*>(t.data)[i];
-    return f16_to_f32(reinterpret_cast<const uint16_t*>(t.data)[i]);
+std::unique_ptr<graph> generator_graph(esrgan_model& m, int n, int w, int h, int* in, int* out) {
+    std::unique_ptr<graph> g(graph_create(m.store));
+    const int64_t ne[4] = {3, w, h, n};
+    *in = graph_input(*g, gdt_f32, ne, "image");
+    *out = generator_builder{*g}.build(*in, m.params);
+    graph_output(*g, *out, "result");
+    return g;
 }
 
-struct packer {
-    model_file const& file;
-    arena_builder& ab;
-    bool with_data;
-    bool file_cwhn;
-
-    // conv kernel `name`.weight -> slabs [cin_pad/32][9][cout_pad][32] f16, the four 16-byte groups of every
-    // (tap, n) row stored at g ^ ((n >> 2) & 3) so that the kernel's linear LDS-DMA copy lands bank-conflict free
-    // (kernels_dconv.hip). dup_in > 0: input channels [dup_in, 2*dup_in) repeat [0, dup_in) (the first conv reads
-    // the image as value + f16 rounding residue).
-    packed_dconv conv(std::string const& name, int dup_in = 0) {
-        gguf_tensor const& t = file.tensor(name + ".weight");
-        if (t.type != GGML_F32 && t.type != GGML_F16) throw except("tensor %s: unsupported type %d", t.name.c_str(), t.type);
-        // whcn file: ne = [kw, kh, Cin, Cout] (torch OIHW); cwhn file: ne = [Cin, kw, kh, Cout] (OHWI, convert.py:120-125)
-        int kw, kh, cin, cout = (int)t.ne[3];
-        if (file_cwhn) { cin = (int)t.ne[0]; kw = (int)t.ne[1]; kh = (int)t.ne[2]; }
-        else { kw = (int)t.ne[0]; kh = (int)t.ne[1]; cin = (int)t.ne[2]; }
-        if (kw != 3 || kh != 3) throw except("tensor %s: expected a 3x3 kernel, got %dx%d", t.name.c_str(), kw, kh);
-        packed_dconv g;
-        g.cin_real = cin;
-        g.cout_real = cout;
-        g.cin = round_up(dup_in ? 2 * dup_in : cin, 32);
-        g.cout = round_up(cout, 32);
-        g.w = ab.alloc((size_t)g.cin * 9 * g.cout * 2);
-        g.b = ab.alloc((size_t)g.cout * 4);
-        if (!with_data) return g;
-        if (!t.data) throw except("tensor %s has no data", t.name.c_str());
-        uint16_t* dst = reinterpret_cast<uint16_t*>(ab.data.data() + g.w);
-        const int n_in = dup_in ? 2 * dup_in : cin;
-        for (int c = 0; c < n_in; ++c) {
-            const int cs = dup_in ? c % dup_in : c; // source input channel
-            const int chunk = c / 32, grp = (c % 32) / 8, e = c % 8;
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap % 3;
-                for (int n = 0; n < cout; ++n) {
-                    const size_t src = file_cwhn ? (((size_t)n * 3 + ky) * 3 + kx) * cin + cs : (((size_t)n * cin + cs) * 3 + ky) * 3 + kx;
-                    const size_t row = ((size_t)chunk * 9 + tap) * g.cout + n;
-                    dst[row * 32 + (size_t)(grp ^ ((n >> 2) & 3)) * 8 + e] = f32_to_f16(tensor_at(t, src));
-                }
-            }
-        }
-        if (const gguf_tensor* bt = file.find(name + ".bias")) {
-            if ((int)bt->n_elements() != cout) throw except("tensor %s: %d elements, expected %d", bt->name.c_str(), (int)bt->n_elements(), cout);
-            float* bd = reinterpret_cast<float*>(ab.data.data() + g.b);
-            for (int n = 0; n < cout; ++n) bd[n] = tensor_at(*bt, n);
-        }
-        return g;
-    }
-};
-
 } // namespace
+
+esrgan_step::esrgan_step() = default;
+esrgan_step::~esrgan_step() = default;
 
 esrgan_model* esrgan_load_model(char const* filepath, backend_device const& dev, int flags) {
     const bool with_data = !(flags & load_no_upload);
@@ -151,47 +147,54 @@ esrgan_model* esrgan_load_model(char const* filepath, backend_device const& dev,
     esrgan_params const& P = model->params;
     if (P.scale != 1 && P.scale != 2 && P.scale != 4 && P.scale != 8)
         throw except("ESRGAN: scale %d is not built in this backend (powers of two only)", P.scale);
+    model->store = weights_from_file(file); // a header-only read gives zero-filled tensors: shapes, and an arena layout to receive the broadcast into
 
-    arena_builder ab;
-    packer pk{file, ab, with_data, file.tensor_layout() == layout_cwhn};
-    esrgan_weights& Wt = model->weights;
-    Wt.first = pk.conv("model.0", 3);
-    if (Wt.first.cin_real != 3) throw except("ESRGAN: model.0 takes %d input channels, expected 3", Wt.first.cin_real);
-    Wt.nf = Wt.first.cout_real;
-    Wt.rdb.resize(P.n_blocks);
+    // the shapes the planar conv schedule is built for (64 filters, growth 32); everything else about the file is checked by the graph's shape inference
+    auto shape = [&](std::string const& name) -> weight_store::entry const& {
+        auto it = model->store->tensors.find(name);
+        if (it == model->store->tensors.end()) throw except("tensor not found: %s", name.c_str());
+        return it->second;
+    };
+    weight_store::entry const& first = shape("model.0.weight"); // ne [Cin, kw, kh, Cout]
+    if (first.ne[0] != 3) throw except("ESRGAN: model.0 takes %d input channels, expected 3", (int)first.ne[0]);
+    model->nf = (int)first.ne[3];
+    model->gc = (int)shape("model.1.sub.0.RDB1.conv1.0.weight").ne[3];
+    if (model->nf != 64 || model->gc != 32)
+        throw except("ESRGAN: %d filters / %d growth channels are not built in this backend (64 / 32 only)", model->nf, model->gc);
     for (int i = 0; i < P.n_blocks; ++i)
-        for (int r = 0; r < 3; ++r)
-            for (int k = 0; k < 5; ++k)
-                Wt.rdb[i][r][k] = pk.conv("model.1.sub." + std::to_string(i) + ".RDB" + std::to_string(r + 1) + ".conv" + std::to_string(k + 1) + ".0");
-    Wt.gc = Wt.rdb[0][0][0].cout_real;
-    if (Wt.nf != 64 || Wt.gc != 32)
-        throw except("ESRGAN: %d filters / %d growth channels are not built in this backend (64 / 32 only)", Wt.nf, Wt.gc);
-    for (auto& blk : Wt.rdb)
-        for (auto& rd : blk)
-            for (int k = 0; k < 5; ++k)
-                if (rd[k].cin_real != Wt.nf + k * Wt.gc || rd[k].cout_real != (k < 4 ? Wt.gc : Wt.nf))
-                    throw except("ESRGAN: dense block conv%d has shape %d -> %d", k + 1, rd[k].cin_real, rd[k].cout_real);
-    Wt.trunk = pk.conv("model.1.sub." + std::to_string(P.n_blocks));
-    int seq = 2;
-    for (int i = 0; i < log2_floor(P.scale); ++i) {
-        Wt.up.push_back(pk.conv("model." + std::to_string(seq + 1)));
-        seq += 3;
+        for (int r = 1; r <= 3; ++r)
+            for (int k = 1; k <= 5; ++k) {
+                weight_store::entry const& t = shape("model.1.sub." + std::to_string(i) + ".RDB" + std::to_string(r) + ".conv" + std::to_string(k) + ".0.weight");
+                if (t.ne[0] != model->nf + (k - 1) * model->gc || t.ne[3] != (k < 5 ? model->gc : model->nf))
+                    throw except("ESRGAN: dense block conv%d has shape %d -> %d", k, (int)t.ne[0], (int)t.ne[3]);
+            }
+    {
+        const int seq = 2 + 3 * log2_floor(P.scale);
+        if (shape("model." + std::to_string(seq + 2) + ".weight").ne[3] != 3) throw except("ESRGAN: the last conv has %d outputs, expected 3", (int)shape("model." + std::to_string(seq + 2) + ".weight").ne[3]);
     }
-    Wt.hr = pk.conv("model." + std::to_string(seq));
-    Wt.last = pk.conv("model." + std::to_string(seq + 2));
-    if (Wt.last.cout_real != 3) throw except("ESRGAN: the last conv has %d outputs, expected 3", Wt.last.cout_real);
-    for (packed_dconv const* g : {&Wt.trunk, &Wt.hr})
-        if (g->cin_real != Wt.nf || g->cout_real != Wt.nf) throw except("ESRGAN: trunk/HR conv has shape %d -> %d", g->cin_real, g->cout_real);
 
     device_turn turn(dev);
     VX(vx_dconv_prepare());
-    model->weight_arena.bytes = round_up<size_t>(ab.data.size(), 256);
-    VX(vx_malloc(&model->weight_arena.ptr, model->weight_arena.bytes));
-    if (with_data) {
-        VX(vx_memcpy_h2d(model->weight_arena.ptr, ab.data.data(), ab.data.size(), dev.stream));
-        VX(vx_stream_sync(dev.stream));
-        model->weights_uploaded = true;
+    // The weight arena: one planning pass of the generator's graph says how many bytes of operand images the lowering makes of the weights; the second
+    // pass packs them into one allocation in lowering order -- the same order on every rank (what the RCCL broadcast at load time moves).
+    size_t need = 0;
+    {
+        int in, out;
+        std::unique_ptr<graph> plan = generator_graph(*model, 1, 32, 32, &in, &out);
+        graph_allocate(*plan, nullptr);
+        need = plan->plan_store_bytes;
     }
+    weight_store& ws = *model->store;
+    ws.arena.bytes = need + (1u << 20);
+    VX(vx_malloc(&ws.arena.ptr, ws.arena.bytes));
+    {
+        int in, out;
+        std::unique_ptr<graph> warm = generator_graph(*model, 1, 32, 32, &in, &out);
+        graph_allocate(*warm, &dev);
+    }
+    model->weight_arena.ptr = ws.arena.ptr;
+    model->weight_arena.bytes = round_up<size_t>(ws.arena_used, 256);
+    model->weights_uploaded = with_data;
     if (const char* e = getenv("VISP_ESRGAN_TILE_GROUP")) model->tile_group = std::max(1, atoi(e));
     if (const char* e = getenv("VISP_ESRGAN_STREAMS")) model->streams = std::max(1, atoi(e));
     VX(vx_stream_create(&model->aux_stream));
@@ -200,17 +203,22 @@ esrgan_model* esrgan_load_model(char const* filepath, backend_device const& dev,
     return model.release();
 }
 
-void esrgan_weights_ready(esrgan_model& m) { m.weights_uploaded = true; }
+void esrgan_weights_ready(esrgan_model& m) {
+    m.store->no_data = true; // every operand image this rank has is the one in the arena the broadcast filled
+    m.weights_uploaded = true;
+}
 
 esrgan_model::~esrgan_model() {
+    if (backend) vx_set_device(backend->index);
     if (aux_stream) {
         vx_stream_sync(aux_stream);
         vx_stream_destroy(aux_stream);
     }
     if (fork_event) vx_event_destroy(fork_event);
     if (join_event) vx_event_destroy(join_event);
+    for (auto& lane : steps) lane.clear();
     vx_free(ws.arena.ptr);
-    vx_free(weight_arena.ptr);
+    weight_arena = {}; // (the store owns it)
 }
 
 //
@@ -218,8 +226,8 @@ esrgan_model::~esrgan_model() {
 
 namespace {
 
-// ws.img_in / ws.img_out (capacity for the host entry point's u8 staging images) are kept, everything else is sized
-// for this call
+// ws.img_in / ws.img_out (capacity for the host entry point's u8 staging images) are kept, everything else is sized for this call. The activations
+// of a tile group live in that group's graph arena (liveness-planned by the graph layer).
 void reserve(esrgan_model& m, int n_tiles_total, int tw, int th) {
     esrgan_workspace& ws = m.ws;
     const size_t img_in_bytes = ws.img_in, img_out_bytes = ws.img_out;
@@ -232,18 +240,9 @@ void reserve(esrgan_model& m, int n_tiles_total, int tw, int th) {
     const int addr_cap = (int)std::max<size_t>(1, ((size_t)1 << 30) / (px * s * s * 64));
     const int group = std::min({(n_tiles_total + lanes - 1) / lanes, m.tile_group, addr_cap});
     struct item { void** p; size_t bytes; };
-    const size_t hr_bytes = m.weights.up.empty() ? (size_t)group * px * 64 * 2 : (size_t)group * px * s * s * 64 * 2;
     std::vector<item> items = {
         {&ws.in_u8, img_in_bytes}, {&ws.out_u8, img_out_bytes},
-        {&ws.x0, (size_t)n_tiles_total * px * 32 * 2}, {&ws.tiles_out, (size_t)n_tiles_total * px * s * s * 3 * 4}};
-    for (int l = 0; l < lanes; ++l) {
-        esrgan_workspace::lane_buffers& L = ws.lane[l];
-        items.push_back({&L.fea, (size_t)group * px * 64 * 2});
-        for (int k = 0; k < 3; ++k) items.push_back({&L.d[k], (size_t)group * px * 192 * 2});
-        items.push_back({&L.tr, (size_t)group * px * 64 * 2});
-        items.push_back({&L.hr_a, hr_bytes});
-        items.push_back({&L.hr_b, hr_bytes});
-    }
+        {&ws.x0, (size_t)n_tiles_total * px * 3 * 4}, {&ws.tiles_out, (size_t)n_tiles_total * px * s * s * 3 * 4}};
     size_t total = 0;
     for (item& it : items) total += round_up<size_t>(it.bytes, 256);
     if (total > ws.arena.bytes) {
@@ -262,10 +261,31 @@ void reserve(esrgan_model& m, int n_tiles_total, int tw, int th) {
     ws.group = group; ws.lanes = lanes; ws.tile_w = tw; ws.tile_h = th; ws.scale = s;
 }
 
+// the graph of `n` tiles of this extent on `lane` (two lanes run concurrently: each has graphs -- and arenas -- of its own); the two most recent shapes
+// per lane are kept
+esrgan_step& step_for(esrgan_model& m, int lane, int n, int w, int h) {
+    auto& cache = m.steps[lane];
+    for (size_t i = 0; i < cache.size(); ++i)
+        if (cache[i]->n == n && cache[i]->w == w && cache[i]->h == h) {
+            if (i + 1 != cache.size()) std::rotate(cache.begin() + (long)i, cache.begin() + (long)i + 1, cache.end());
+            return *cache.back();
+        }
+    if (cache.size() >= 3) { // the oldest one's launches may still be queued
+        VX(vx_stream_sync(m.backend->stream));
+        if (m.aux_stream) VX(vx_stream_sync(m.aux_stream));
+        cache.erase(cache.begin());
+    }
+    auto st = std::make_unique<esrgan_step>();
+    st->n = n; st->w = w; st->h = h;
+    st->g = generator_graph(m, n, w, h, &st->in, &st->out);
+    graph_allocate(*st->g, m.backend);
+    cache.push_back(std::move(st));
+    return *cache.back();
+}
+
 struct exec {
     esrgan_model& m;
     void* stream;
-    const uint8_t* wa;
     std::vector<std::pair<std::string, void*>> marks;
     std::vector<timing_entry> acc;
 
@@ -301,86 +321,14 @@ struct exec {
         marks.clear();
     }
 
-    struct opts {
-        bool up2 = false, lrelu = false, rgb = false, x_residual = false;
-        float s1 = 1, s2 = 1;
-        const void* res1 = nullptr; int64_t res1_plane = 0;
-        const void* res2 = nullptr; int64_t res2_plane = 0;
-    };
-    // x: cin/32 planes of [n, H(/2), W(/2), 32] f16, x_plane elements apart; out: planes of [n, H, W, 32] or f32 rgb
-    void conv(packed_dconv const& g, const void* x, int64_t x_plane, int cin, int n, int H, int W, void* out, int64_t out_plane, opts const& o,
-              const char* group) {
-        vx_dconv_args a;
-        memset(&a, 0, sizeof a);
-        a.x = x; a.x_plane = x_plane; a.cin = cin; a.up2 = o.up2;
-        a.B = n; a.H = H; a.W = W;
-        a.w = wa + g.w; a.bias = reinterpret_cast<const float*>(wa + g.b); a.cout = g.cout;
-        a.epi = o.rgb ? VX_DC_RGB_F32 : VX_DC_F16;
-        a.act = o.lrelu;
-        a.s1 = o.s1; a.res1 = o.res1; a.res1_plane = o.res1_plane;
-        a.s2 = o.s2; a.res2 = o.res2; a.res2_plane = o.res2_plane;
-        a.out = out; a.out_plane = out_plane;
-        a.x_residual = o.x_residual;
-        const double px = (double)n * H * W;
-        mark(group, 2.0 * px * 9 * g.cin_real * g.cout_real,
-             px * (o.up2 ? 0.25 : 1.0) * cin * 2 + px * (o.rgb ? 12 : g.cout * 2) + (o.res1 ? px * g.cout * 2 : 0) + (o.res2 ? px * g.cout * 2 : 0));
-        VX(vx_dconv3x3_f16(&a, stream));
-    }
-
-    // esrgan_generate (esrgan.cpp:55-79) on n tiles: x0 [n,h,w,32] f16 -> rgb f32 [n, h*s, w*s, 3]
-    void generate(esrgan_workspace::lane_buffers const& lb, const void* x0, int n, int w, int h, float* out) {
-        esrgan_weights const& Wt = m.weights;
-        esrgan_workspace const& ws = m.ws;
-        // every activation buffer is planar (32 channels per plane); plane strides are those of the full tile group
-        const int64_t PL = (int64_t)ws.group * w * h * 32;             // low-resolution plane
-        const int64_t PH = PL * ws.scale * ws.scale;                    // plane of the up-sampled maps
-        auto plane = [](void* base, int64_t stride, int k) { return static_cast<void*>(static_cast<uint16_t*>(base) + stride * k); };
-        conv(Wt.first, x0, 0, 32, n, h, w, lb.fea, PL, {}, "first");
-        conv(Wt.first, x0, 0, 32, n, h, w, lb.d[0], PL, {}, "first");
-        int a = 0;
-        for (auto const& blk : Wt.rdb) { // rrdb, esrgan.cpp:43-51
-            void *A = lb.d[a], *B = lb.d[(a + 1) % 3], *C = lb.d[(a + 2) % 3];
-            void* src[3] = {A, B, C};
-            void* dst[3] = {B, C, B};
-            for (int r = 0; r < 3; ++r) { // risidual_dense_block, esrgan.cpp:27-41
-                for (int k = 0; k < 4; ++k) {
-                    opts o;
-                    o.lrelu = true;
-                    static const char* const names[4] = {"rdb_conv1", "rdb_conv2", "rdb_conv3", "rdb_conv4"};
-                    conv(blk[r][k], src[r], PL, 64 + 32 * k, n, h, w, plane(src[r], PL, 2 + k), PL, o, names[k]);
-                }
-                opts o;
-                o.s1 = 0.2f; o.x_residual = true; // x5*0.2 + x, x = planes 0,1 of the halo the conv already holds
-                if (r == 2) { o.s2 = 0.2f; o.res2 = A; o.res2_plane = PL; }
-                conv(blk[r][4], src[r], PL, 192, n, h, w, dst[r], PL, o, "rdb_conv5");
-            }
-            a = (a + 1) % 3;
-        }
-        {
-            opts o;
-            o.res1 = lb.fea; o.res1_plane = PL;
-            conv(Wt.trunk, lb.d[a], PL, 64, n, h, w, lb.tr, PL, o, "trunk");
-        }
-        const void* cur = lb.tr;
-        int64_t cur_plane = PL;
-        void* nxt[2] = {lb.hr_a, lb.hr_b};
-        int flip = 0, cw = w, ch = h;
-        for (packed_dconv const& u : Wt.up) { // esrgan::upsample, esrgan.cpp:13-19
-            cw *= 2; ch *= 2;
-            opts o;
-            o.up2 = true; o.lrelu = true;
-            conv(u, cur, cur_plane, 64, n, ch, cw, nxt[flip], PH, o, "upconv");
-            cur = nxt[flip];
-            cur_plane = PH;
-            flip ^= 1;
-        }
-        {
-            opts o;
-            o.lrelu = true;
-            conv(Wt.hr, cur, cur_plane, 64, n, ch, cw, nxt[flip], PH, o, "hrconv");
-            opts l;
-            l.rgb = true;
-            conv(Wt.last, nxt[flip], PH, 64, n, ch, cw, out, 0, l, "last");
+    // esrgan_generate (esrgan.cpp:55-79) on n tiles: rgb f32 [n, h, w, 3] -> rgb f32 [n, h*s, w*s, 3], both in the call's workspace
+    void generate(int lane, const float* x0, int n, int w, int h, float* out) {
+        esrgan_step& st = step_for(m, lane, n, w, h);
+        graph_bind_external(*st.g, st.in, const_cast<float*>(x0));
+        graph_bind_external(*st.g, st.out, out);
+        for (graph_launch const& l : st.g->launches) {
+            mark(l.group.empty() ? "other" : l.group.c_str(), l.flops, l.bytes);
+            l.run(stream);
         }
     }
 };
@@ -399,8 +347,7 @@ void run_tiles(esrgan_model& m, exec& ex, int n_total, int tw, int th) {
         const int n = std::min(m.ws.group, n_total - t0);
         const int lane = two ? gi & 1 : 0;
         ex.stream = lane ? m.aux_stream : main_stream;
-        ex.generate(m.ws.lane[lane], static_cast<const uint16_t*>(m.ws.x0) + (size_t)t0 * px * 32, n, tw, th,
-                    static_cast<float*>(m.ws.tiles_out) + (size_t)t0 * px * s * s * 3);
+        ex.generate(lane, static_cast<const float*>(m.ws.x0) + (size_t)t0 * px * 3, n, tw, th, static_cast<float*>(m.ws.tiles_out) + (size_t)t0 * px * s * s * 3);
     }
     ex.stream = main_stream;
     if (two) { // join
@@ -422,10 +369,10 @@ void esrgan_compute_batch_device(esrgan_model& m, void const* img_dev, int batch
     tile_layout tiles_out = tile_scale(tiles, m.params.scale);
     const int n_total = batch * tiles.total();
     reserve(m, n_total, tiles.tile_size[0], tiles.tile_size[1]);
-    exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
+    exec ex{m, s, {}, {}};
     vx_tile_layout tin = to_vx(tiles), tout = to_vx(tiles_out);
-    ex.mark("tiles_in", 0, (double)n_total * tiles.tile_size[0] * tiles.tile_size[1] * 67);
-    VX(vx_esrgan_tiles_in(static_cast<const uint8_t*>(img_dev), batch, w, h, int(format), &tin, m.ws.x0, s));
+    ex.mark("tiles_in", 0, (double)n_total * tiles.tile_size[0] * tiles.tile_size[1] * 15);
+    VX(vx_esrgan_tiles_in_f32(static_cast<const uint8_t*>(img_dev), batch, w, h, int(format), &tin, static_cast<float*>(m.ws.x0), s));
     run_tiles(m, ex, n_total, tiles.tile_size[0], tiles.tile_size[1]);
     ex.mark("tiles_out", 0, (double)batch * tout.image_w * tout.image_h * 20);
     VX(vx_esrgan_tiles_out(static_cast<const float*>(m.ws.tiles_out), batch, &tout, nullptr, static_cast<uint8_t*>(out_rgba_dev), s));
@@ -474,17 +421,9 @@ void esrgan_generate_host(esrgan_model& m, float const* rgb, int n, int w, int h
     device_turn turn(*m.backend);
     reserve(m, n, w, h);
     const size_t px = (size_t)n * w * h;
-    std::vector<uint16_t> x0(px * 32, 0);
-    for (size_t i = 0; i < px; ++i)
-        for (int c = 0; c < 3; ++c) {
-            const float v = rgb[i * 3 + c];
-            const uint16_t hi = f32_to_f16(v);
-            x0[i * 32 + c] = hi;
-            x0[i * 32 + 3 + c] = f32_to_f16(v - f16_to_f32(hi));
-        }
     void* s = m.backend->stream;
-    VX(vx_memcpy_h2d(m.ws.x0, x0.data(), x0.size() * 2, s));
-    exec ex{m, s, static_cast<const uint8_t*>(m.weight_arena.ptr), {}, {}};
+    VX(vx_memcpy_h2d(m.ws.x0, rgb, px * 3 * 4, s));
+    exec ex{m, s, {}, {}};
     run_tiles(m, ex, n, w, h);
     ex.finish_timing();
     const int sc = m.params.scale;

@@ -1,12 +1,13 @@
-// ESRGAN / Real-ESRGAN (RRDBNet) on the MI355X backend: model load (GGUF -> packed f16 weight slabs in HBM),
-// concat-free dense-block schedule and the tiled, batched executor. Host C++ only; all device work goes through
-// the vx_* C ABI (include/visp_hip_kernels.h).
+// ESRGAN / Real-ESRGAN (RRDBNet) on the MI355X backend: model load (GGUF -> weight store), the generator as a graph of the
+// reference's nodes that csrc/graph.cpp lowers onto the planar dense-block conv schedule, and the tiled, batched executor around it.
+// Host C++ only; all device work goes through the vx_* C ABI (include/visp_hip_kernels.h).
 //
 // Mirrors the reference's API for this family (include/visp/vision.h:284-304, 361-369;
 // src/visp/vision.cpp:208-253; src/visp/arch/esrgan.cpp; tiling: src/visp/image.cpp:612-693).
 #pragma once
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -31,37 +32,34 @@ struct tile_layout {
 };
 tile_layout tile_scale(tile_layout const&, int scale);
 
-// one 3x3 conv packed for vx_dconv3x3_f16: slabs [cin/32][9][cout][32] f16 + f32 bias [cout]
-struct packed_dconv {
-    size_t w = 0, b = 0;
-    int cin = 0, cout = 0;           // padded to 32
-    int cin_real = 0, cout_real = 0;
-};
-struct esrgan_weights {
-    int nf = 64, gc = 32;
-    packed_dconv first;                                           // model.0 (3 -> nf; input channels 3..5 repeat 0..2)
-    std::vector<std::array<std::array<packed_dconv, 5>, 3>> rdb;  // model.1.sub.<i>.RDB<r>.conv<k>.0
-    packed_dconv trunk;                                           // model.1.sub.<n_blocks>
-    std::vector<packed_dconv> up;                                 // model.3, model.6, ...
-    packed_dconv hr, last;                                        // model.<seq>, model.<seq+2>
-};
+struct graph;
+struct weight_store;
 
 struct esrgan_workspace {
     int group = 0, tile_w = 0, tile_h = 0, scale = 0; // sized for `group` tiles of this extent
     size_t img_in = 0, img_out = 0;                   // bytes reserved for the u8 in/out images
     device_buffer arena;
-    void *in_u8 = nullptr, *out_u8 = nullptr, *x0 = nullptr, *tiles_out = nullptr; // whole call
-    // activations of one tile group; two lanes, because two groups run concurrently on two streams
-    struct lane_buffers { void *fea = nullptr, *d[3] = {nullptr, nullptr, nullptr}, *tr = nullptr, *hr_a = nullptr, *hr_b = nullptr; } lane[2];
+    void *in_u8 = nullptr, *out_u8 = nullptr, *x0 = nullptr, *tiles_out = nullptr; // whole call: u8 images, f32 rgb tiles in and out
     int lanes = 1;
+};
+
+// the generator's graph for n tiles of one extent (csrc/graph.h), lowered and allocated; input / output bound to slices of the call's workspace
+struct esrgan_step {
+    int n = 0, w = 0, h = 0;
+    std::unique_ptr<graph> g;
+    int in = -1, out = -1;
+    esrgan_step();
+    ~esrgan_step();
 };
 
 struct esrgan_model : model_base { // vision.h:361-369 counterpart
     esrgan_model() : model_base(family_esrgan) {}
     backend_device const* backend = nullptr;
     esrgan_params params;
-    esrgan_weights weights;
-    device_buffer weight_arena;
+    int nf = 64, gc = 32;                    // filters / growth channels of the file
+    std::shared_ptr<weight_store> store;     // the file's tensors + their packed device images (one arena: what a load-time broadcast moves)
+    device_buffer weight_arena;              // = the store's arena
+    std::vector<std::unique_ptr<esrgan_step>> steps[2]; // per lane: graphs of the most recent tile-group shapes
     bool weights_uploaded = false;
     esrgan_workspace ws;
     int tile_group = 64;  // upper bound of tiles pushed through the network together (bounds the workspace)

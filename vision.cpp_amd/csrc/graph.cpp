@@ -1126,7 +1126,11 @@ struct lowering {
             if (rp[1]) r.res2 = rp[1]() + r_off[1] * 2;
             VX(vx_dconv3x3_f16(&r, st));
         });
-        tag(rgb ? "conv_rgb" : (dup ? "conv_first" : (up2 ? "upconv" : "conv")), 2.0 * npix * (double)cout * 9 * cin, (double)npix * ((up2 ? 0.25 : 1.0) * d_cin * 2 + (rgb ? 12 : cout * 2)));
+        std::string grp = rgb ? "last" : (dup ? "first" : (up2 ? "upconv" : "conv"));
+        if (auto k = who.find(".RDB"); k != std::string::npos && who.find(".conv", k) != std::string::npos) grp = "rdb_conv" + who.substr(who.find(".conv", k) + 5, 1);
+        else if (!rgb && !dup && !up2 && who.find(".sub.") != std::string::npos) grp = "trunk";
+        else if (!rgb && !dup && !up2 && act == 1) grp = "hrconv";
+        tag(grp.c_str(), 2.0 * npix * (double)cout * 9 * cin, (double)npix * ((up2 ? 0.25 : 1.0) * d_cin * 2 + (rgb ? 12 : cout * 2)));
         if (!rgb && n.is_output) planar_to_nhwc(t); // a graph output is read back as NHWC
         return true;
     }

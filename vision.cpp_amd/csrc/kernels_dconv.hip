@@ -988,6 +988,24 @@ __global__ void esr_tiles_in_kernel(const uint8_t* __restrict__ img, int B, int 
     o[3] = z;
 }
 
+// the same tiles as f32 rgb [tiles][tile_h][tile_w][3] (image_u8_to_f32 with a tile offset, vision.cpp:236-241): the input tensor of the generator's graph
+__global__ void esr_tiles_in_f32_kernel(const uint8_t* __restrict__ img, int B, int w, int h, int ch, int ir, int ig, int ib, vx_tile_layout t, float* __restrict__ out) {
+    const long n = (long)B * t.n_x * t.n_y * t.tile_h * t.tile_w;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % t.tile_w);
+    long q = i / t.tile_w;
+    const int y = (int)(q % t.tile_h);
+    q /= t.tile_h;
+    const int tile = (int)(q % (t.n_x * t.n_y)), b = (int)(q / (t.n_x * t.n_y));
+    const int cx = tile % t.n_x, cy = tile / t.n_x;
+    const int sx = min(cx * (t.tile_w - t.overlap_x) + x, w - 1), sy = min(cy * (t.tile_h - t.overlap_y) + y, h - 1);
+    const uint8_t* s = img + (((long)b * h + sy) * w + sx) * ch;
+    out[i * 3 + 0] = (float)s[ir] / 255.0f;
+    out[i * 3 + 1] = (float)s[ig] / 255.0f;
+    out[i * 3 + 2] = (float)s[ib] / 255.0f;
+}
+
 // tile_merge over all tiles + image_f32_to_u8 (reference src/visp/image.cpp:653-693, 257-288): one thread per
 // output pixel walks the tiles that cover it in the reference's order (t = cy*n_x + cx ascending) and repeats its
 // arithmetic (dst += (weight/norm) * tile, or dst = tile where the weight is zero), so the f32 image is the
@@ -1120,6 +1138,21 @@ extern "C" int vx_esrgan_tiles_in(const uint8_t* img, int B, int w, int h, int f
     const long n = (long)B * t->n_x * t->n_y * t->tile_h * t->tile_w;
     hipLaunchKernelGGL(esr_tiles_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), img, B, w, h, ch, ir, ig, ib, *t,
                        reinterpret_cast<f16*>(out));
+    VX_LAUNCH_CHECK();
+    return 1;
+}
+
+extern "C" int vx_esrgan_tiles_in_f32(const uint8_t* img, int B, int w, int h, int format, const vx_tile_layout* t, float* out, void* stream) {
+    int ch, ir, ig, ib;
+    switch (format) { // visp::image_format (include/visp/image.h:17-29)
+        case 0: ch = 4; ir = 0; ig = 1; ib = 2; break; // rgba_u8
+        case 1: ch = 4; ir = 2; ig = 1; ib = 0; break; // bgra_u8
+        case 2: ch = 4; ir = 1; ig = 2; ib = 3; break; // argb_u8
+        case 3: ch = 3; ir = 0; ig = 1; ib = 2; break; // rgb_u8
+        default: vx_set_error("vx_esrgan_tiles_in_f32: unsupported image format %d", format); return 0;
+    }
+    const long n = (long)B * t->n_x * t->n_y * t->tile_h * t->tile_w;
+    hipLaunchKernelGGL(esr_tiles_in_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), img, B, w, h, ch, ir, ig, ib, *t, out);
     VX_LAUNCH_CHECK();
     return 1;
 }
