@@ -410,3 +410,24 @@ def test_large_image_many_tiles(tmp_path_factory, device):
     m.set_tile_group(4)
     b = m.upscale_batch(img)
     assert np.array_equal(a, b)
+
+
+def test_weight_arena_replication(device, tmp_path):
+    """The N > 1 load path without the collective: a header-only model (what ranks != 0 load) lays out the same arena -- the graph lowering's operand images
+    in lowering order --, receives the bytes of a fully loaded model's arena and must then produce bit-identical images."""
+    from visioncpp_amd import _lib as L
+    from visioncpp_amd import synth
+    from visioncpp_amd.vision import Model
+    path = tmp_path / "e.gguf"
+    synth.write_esrgan_gguf(path, synth.ESRGAN_TINY, 7)
+    full = Model.load(path, device)
+    empty = Model.load(path, device, no_upload=True)
+    imgs = synth.images(2, 48, 40, seed=5)
+    with pytest.raises(L.Error, match="not been uploaded"):
+        empty.upscale_batch(imgs)
+    (src, n), (dst, n2) = full.weights_arena(), empty.weights_arena()
+    assert n == n2 and n > 0
+    L.vx_check(L.get_lib().vx_memcpy_d2d(dst, src, n, None))
+    L.vx_check(L.get_lib().vx_stream_sync(None))
+    empty.weights_ready()
+    np.testing.assert_array_equal(empty.upscale_batch(imgs), full.upscale_batch(imgs))
