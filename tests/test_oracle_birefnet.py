@@ -1,9 +1,10 @@
 """CPU suite: the oracle's BiRefNet restatement (oracle/visp_oracle.c vo_birefnet_*, reference src/visp/arch/birefnet.cpp).
 
-PARITY UNPINNED for the deformable convolution: the reference implements it with ggml_conv_2d_deform (a fork-only ggml op that is
-not in /root/reference) and tests it against torchvision.ops.deform_conv2d (tests/test_birefnet.py:767-795); neither is available
-here, and the reference holds no literal vector for it. What these tests can do: check the C restatement against an independent
-numpy restatement of torchvision's published algorithm, against the regular convolution where the two must coincide, and pin
+The deformable convolution: the reference implements it with ggml_conv_2d_deform (a fork-only ggml op that is not in /root/reference) and
+tests it against torchvision.ops.deform_conv2d (tests/test_birefnet.py:767-795); neither is available here, and the reference holds no
+literal vector for it. Round 4: the C restatement is pinned on torch's own bilinear sampler (torch.nn.functional.grid_sample, zero padding,
+align_corners -- the sampling rule torchvision's operator uses) + a matrix product per tap; the whole-operator comparison against
+torchvision itself stays impossible here. Also: an independent numpy restatement, the regular convolution where the two must coincide, and
 everything around it (image_to_patches against the einops pattern the reference's test uses, the two-scale encode against its
 definition in terms of already-pinned operators)."""
 import numpy as np
@@ -58,6 +59,52 @@ def test_deform_conv_against_numpy_restatement(k, pad, stride):
     want = _deform_numpy(x, w, offset, mask, stride, pad)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(oracle.deform_conv2d_nhwc(x, w, offset, None, stride, pad), _deform_numpy(x, w, offset, None, stride, pad), rtol=1e-4, atol=1e-4)
+
+
+def _deform_torch_grid_sample(x, w, offset, mask, stride, pad):
+    """The same operator out of torch's own bilinear sampler: per kernel tap, torch.nn.functional.grid_sample (bilinear, zero padding, align_corners)
+    of the input at (y*s - p + ky + dy, x*s - p + kx + dx), times the mask, then the tap's 1x1 product -- torchvision's deform_conv2d samples with exactly
+    this rule (corners outside the map are zeros, tests/test_birefnet.py:767-795 compares the reference against it). Third-party arithmetic for the part
+    of the operator that is not a plain convolution."""
+    import torch
+    import torch.nn.functional as F
+    H, W, Cin = x.shape
+    Cout, kh, kw, _ = w.shape
+    OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    xt = torch.from_numpy(x).double().permute(2, 0, 1)[None]                      # [1, Cin, H, W]
+    oy, ox = torch.meshgrid(torch.arange(OH, dtype=torch.float64), torch.arange(OW, dtype=torch.float64), indexing="ij")
+    out = torch.zeros((OH, OW, Cout), dtype=torch.float64)
+    off = torch.from_numpy(offset).double()
+    for ky in range(kh):
+        for kx in range(kw):
+            t = ky * kw + kx
+            py = oy * stride - pad + ky + off[..., 2 * t]
+            px = ox * stride - pad + kx + off[..., 2 * t + 1]
+            grid = torch.stack([2 * px / (W - 1) - 1, 2 * py / (H - 1) - 1], -1)[None]  # (x, y) in [-1, 1], align_corners
+            v = F.grid_sample(xt, grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0].permute(1, 2, 0)  # [OH, OW, Cin]
+            if mask is not None:
+                v = v * torch.from_numpy(mask).double()[..., t:t + 1]
+            out += v @ torch.from_numpy(w[:, ky, kx, :]).double().T
+    return out.float().numpy()
+
+
+@pytest.mark.parametrize("k,pad,stride", [(1, 0, 1), (3, 1, 1), (7, 3, 1), (3, 0, 2)])
+def test_deform_conv_against_torch_grid_sample(k, pad, stride):
+    """Pins the oracle's deformable convolution on torch.nn.functional.grid_sample (the bilinear rule) + a matrix product, the way the other primitives are
+    pinned on torch functionals (tests/test_primitives.py): offsets far outside the map, straddling its border and inside it, with and without the mask."""
+    rng = np.random.default_rng(100 + k)
+    H, W, Cin, Cout = 9, 11, 5, 4
+    x = rng.standard_normal((H, W, Cin)).astype(np.float32)
+    w = rng.standard_normal((Cout, k, k, Cin)).astype(np.float32)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    offset = (rng.standard_normal((OH, OW, 2 * k * k)) * 1.5).astype(np.float32)
+    offset[0, 0, :2] = [-20.0, 3.0]
+    offset[1, 1, :2] = [-0.5, -0.5]
+    offset[2, 2, :2] = [float(H), 0.25]   # one row below the map
+    mask = (rng.random((OH, OW, k * k)) * 2).astype(np.float32)
+    for m in (mask, None):
+        got = oracle.deform_conv2d_nhwc(x, w, offset, m, stride, pad)
+        np.testing.assert_allclose(got, _deform_torch_grid_sample(x, w, offset, m, stride, pad), rtol=2e-4, atol=2e-4)
 
 
 def test_deform_conv_with_zero_offsets_is_the_regular_convolution():
