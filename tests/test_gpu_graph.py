@@ -473,3 +473,35 @@ def test_esrgan_nodes_outside_the_patterns(device):
     np.testing.assert_allclose(got_a, want_a, rtol=2e-3, atol=1e-3)
     ref_b = F.interpolate(t(h(want_a)).permute(0, 3, 1, 2), size=(H * 2, W * 3), mode="nearest").permute(0, 2, 3, 1).numpy()
     np.testing.assert_allclose(got_b, ref_b, rtol=2e-3, atol=1e-3)
+
+
+def test_esrgan_interior_maps_read_back_from_their_planes(device, tmp_path):
+    """Module boundaries of the generator kept as graph outputs (the first conv's map, the two rrdb outputs, the trunk sum): each lives as planes of a dense
+    block / a planar buffer and is handed out as NHWC by one `planes_to_nhwc` copy; the schedule around them stays the planar one. Against the oracle's
+    captures of the same boundaries (esrgan.cpp:58-67)."""
+    O = oracle
+    cfg = synth.ESRGAN_TINY
+    path = tmp_path / "esrgan.gguf"
+    synth.write_esrgan_gguf(path, cfg, 7)
+    Hh, Ww, B = 24, 40, 2
+    imgs = synth.images(B, Ww, Hh, seed=5).astype(np.float32) / np.float32(255.0)
+    g = G.Graph(device, G.Weights(path))
+    img = g.input((3, Ww, Hh, B), G.F32, "image")
+    out = G.esrgan_generate(G.ModelRef(g), img, cfg.scale, cfg.num_blocks)
+    keep = {"rrdb_0": g.output(g.get_tensor("model.1.sub.0"), "rrdb_0"), "rrdb_1": g.output(g.get_tensor("model.1.sub.1"), "rrdb_1")}
+    g.allocate()
+    text = g.describe()
+    assert text.count("planes_to_nhwc") == 2 and text.count("dconv3x3(planes)") == 1 + 15 * cfg.num_blocks + 1 + 1 + 2 and "concat" not in text
+    g.set(img, imgs)
+    g.compute()
+    got = {k: g.get(v) for k, v in keep.items()}
+    res = g.get(out)
+    sd = synth.esrgan_state_dict(cfg, 7)
+    tensors, conv2d = synth.esrgan_gguf_tensors(sd)
+    om = O.Model(tensors, conv2d, "whcn")
+    for i in range(B):
+        ref, caps = O.esrgan_generate(om, cfg.scale, cfg.num_blocks, imgs[i], {"rrdb_0": Hh * Ww * 64, "rrdb_1": Hh * Ww * 64})
+        assert np.abs(res[i] - ref).mean() < 1e-3
+        for k in keep:
+            want = caps[k].reshape(Hh, Ww, 64)
+            assert got[k].shape == (B, Hh, Ww, 64) and rel(got[k][i], want) < 6e-3, k
