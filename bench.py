@@ -303,6 +303,8 @@ def main():
         # the same leg from a process that never loads torch -- what a C or ctypes caller of the library gets: the system ROCm runtime. The 0.90 x of
         # the resident rate measured in round 3 was the bundled runtime's copy path, not the pipeline.
         try:
+            if world > 1:
+                raise ValueError("N > 1: no extra process next to the ranks")
             r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--pipeline-child", "--batch", str(B), "--steps", str(max(args.steps, 60)), "--device", str(device_index)],
                                capture_output=True, text=True, timeout=600)
             child = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
