@@ -505,3 +505,35 @@ def test_esrgan_interior_maps_read_back_from_their_planes(device, tmp_path):
         for k in keep:
             want = caps[k].reshape(Hh, Ww, 64)
             assert got[k].shape == (B, Hh, Ww, 64) and rel(got[k][i], want) < 6e-3, k
+
+
+def test_dense_block_that_does_not_fit_the_pattern_falls_back_correctly(device):
+    """A conv_block whose activation the conv epilogue cannot absorb (LeakyReLU 0.1) in a concat chain: the chain is NOT taken as planes of one buffer --
+    the planar first map is copied out as NHWC once, the activation and the concat are launches of their own, the next conv runs on the NHWC map -- and
+    the numbers are those of the same ops in torch."""
+    rng = np.random.default_rng(9)
+    H, W, B = 20, 24, 2
+    img = rng.random((B, H, W, 3)).astype(np.float32)
+    w0, b0 = h(rng.standard_normal((64, 3, 3, 3)) / math.sqrt(27)), 0.1 * rng.standard_normal(64)
+    w1, b1 = h(rng.standard_normal((32, 3, 3, 64)) / math.sqrt(576)), 0.1 * rng.standard_normal(32)
+    w2, b2 = h(rng.standard_normal((64, 3, 3, 96)) / math.sqrt(864)), 0.1 * rng.standard_normal(64)
+    g = G.Graph(device)
+    for k, (w, b) in {"c0": (w0, b0), "c1": (w1, b1), "c2": (w2, b2)}.items():
+        g.add_weight(f"{k}.weight", w); g.add_weight(f"{k}.bias", b, G.F32)
+    m = G.ModelRef(g)
+    x = g.input((3, W, H, B), G.F32, "image")
+    x0 = G.conv_2d(m["c0"], x, 1, 1)
+    x1 = G.leaky_relu(m, G.conv_2d(m["c1"], x0, 1, 1), 0.1)
+    c = G.concat(m, [x0, x1], 0)
+    y = g.output(G.relu(m, G.conv_2d(m["c2"], c, 1, 1)), "y")
+    (got,) = run(g, {x: img}, [y])
+    d = g.describe()
+    assert "planes_to_nhwc" in d and "concat part 0" in d and "leaky_relu n=" in d and d.count("dconv3x3(planes)") == 2
+
+    def conv(v, w, b):
+        return F.conv2d(v, t(w).permute(0, 3, 1, 2), t(b), padding=1)
+
+    v0 = t(h(conv(t(img).permute(0, 3, 1, 2), w0, b0).numpy()))
+    v1 = t(h(F.leaky_relu(t(h(conv(v0, w1, b1).numpy())), 0.1).numpy()))
+    ref = torch.relu(conv(torch.cat([v0, v1], 1), w2, b2)).permute(0, 2, 3, 1).numpy()
+    assert rel(got, ref) < 4e-3

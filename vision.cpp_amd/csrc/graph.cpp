@@ -1080,7 +1080,7 @@ struct lowering {
             obuf = n.buffer;
         } else {
             planar_map om{-1, 0, cout / 32, npix * 32};
-            if (auto it = placed.find(last); it != placed.end()) { om.buf = it->second.first; om.plane0 = it->second.second; }
+            if (auto it = placed.find(last); it != placed.end()) { om.buf = it->second.first; om.plane0 = it->second.second; placed.erase(it); }
             else {
                 // the head of a concat chain along the channels: reserve the whole dense block and the slots of the maps that will join it
                 std::vector<std::pair<int, int>> joins; // (concat node, second operand)
@@ -1092,9 +1092,17 @@ struct lowering {
                     if (cc < 0) break;
                     const int s2n = g.nodes[cc].src[1];
                     graph_node const& sn = g.nodes[s2n];
-                    const bool act_of_conv = (sn.op == gop_leaky_relu || sn.op == gop_relu) && !sn.constant && is_conv3x3(g.nodes[sn.src[0]], g.nodes[g.nodes[sn.src[0]].src[1]]) && uses[sn.src[0]] == 1;
-                    const bool conv_itself = !sn.constant && sn.op == gop_conv_2d && is_conv3x3(sn, g.nodes[sn.src[1]]);
-                    if (!(act_of_conv || conv_itself) || uses[s2n] != 1 || sn.is_output || sn.ne[0] % 32 || s2n < cur) break;
+                    // the joining map must be one this function will write: a 3x3 conv of the chain so far to 32 or 64 channels (constant bias), alone or behind
+                    // an activation its epilogue absorbs
+                    auto joins_by_conv = [&](int cn) {
+                        graph_node const& c = g.nodes[cn];
+                        return !c.constant && c.op == gop_conv_2d && c.dtype == gdt_f16 && is_conv3x3(c, g.nodes[c.src[1]]) && (c.n_src == 2 || g.nodes[c.src[2]].constant) &&
+                               (c.ne[0] == 32 || c.ne[0] == 64) && c.src[0] == cur;
+                    };
+                    const bool act_of_conv = (sn.op == gop_relu || (sn.op == gop_leaky_relu && sn.fp[0] == 0.2f)) && !sn.constant && joins_by_conv(sn.src[0]) && uses[sn.src[0]] == 1 &&
+                                             !g.nodes[sn.src[0]].is_output;
+                    const bool conv_itself = joins_by_conv(s2n);
+                    if (!(act_of_conv || conv_itself) || uses[s2n] != 1 || sn.is_output || s2n < cur) break;
                     joins.emplace_back(cc, s2n);
                     width += (int)sn.ne[0];
                     cur = cc;
@@ -2137,6 +2145,7 @@ struct lowering {
                 default: throw except("graph_allocate: %s is not lowered", graph_op_name(n.op));
             }
         }
+        if (!placed.empty()) throw except("graph: internal: a plane reserved for tensor %d of a dense block was never written", placed.begin()->first);
         plan_arena();
     }
 
